@@ -1,0 +1,331 @@
+"""Stand-ins for the reference's *third-party* dependencies, so that the reference's own
+Python (``/root/reference/commonroad_rp``) can be imported unmodified in the build container
+to generate golden vectors.
+
+TEST INFRASTRUCTURE ONLY.  Used by ``make_golden.py`` in the build container; nothing here
+(and nothing of the reference) travels to the GPU box or is imported by the product package.
+
+None of this is reference code: these are minimal duck-typed substitutes for packages that
+are not installed here (methodtools, omegaconf, commonroad-io, commonroad-drivability-checker,
+commonroad-route-planner, commonroad-vehicle-models).  Numerical semantics that matter on the
+hot path and are restated from the packages' published behaviour (source not under
+/root/reference => unpinned):
+  * ``commonroad.common.util.make_valid_orientation``      (commonroad-io 2024.1)
+  * vehicle-2 parameter values                             (commonroad-vehicle-models 3.0.2)
+  * ``pycrcc`` collision semantics and ``pycrccosy`` (s,d)->(x,y): *defined* by this build
+    (closed-set SAT; polyline + interpolated vertex tangent), see DESIGN.md.
+"""
+from __future__ import annotations
+
+import dataclasses
+import functools
+import math
+import sys
+import types
+from typing import Any, List, Optional
+
+import numpy as np
+
+REFERENCE_ROOT = "/root/reference"
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------
+def _mod(name: str, **attrs) -> types.ModuleType:
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent:
+        if parent not in sys.modules:
+            _mod(parent)
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+class _Anything:
+    """Placeholder class for type names that are only used in annotations/isinstance-free code."""
+
+    def __init__(self, *a, **k):
+        self.__dict__.update(k)
+
+
+# ----------------------------------------------------------------------------------------------
+# methodtools.lru_cache  (usable as ``@lru_cache(n)`` *above* ``@classmethod``)
+# ----------------------------------------------------------------------------------------------
+def _lru_cache(maxsize=128):
+    def deco(obj):
+        if isinstance(obj, classmethod):
+            fn = obj.__func__
+            cached = functools.lru_cache(maxsize)(fn)
+            return classmethod(lambda cls, *a: cached(cls, *a))
+        return functools.lru_cache(maxsize)(obj)
+
+    return deco
+
+
+# ----------------------------------------------------------------------------------------------
+# commonroad.common.validity / util
+# ----------------------------------------------------------------------------------------------
+def is_real_number(x) -> bool:
+    return isinstance(x, (int, float, np.integer, np.floating)) and not isinstance(x, bool)
+
+
+def is_natural_number(x) -> bool:
+    return isinstance(x, (int, np.integer)) and x >= 0
+
+
+def is_positive(x) -> bool:
+    return is_real_number(x) and x > 0
+
+
+def is_real_number_vector(x, length=None) -> bool:
+    if not isinstance(x, (np.ndarray, list, tuple)):
+        return False
+    a = np.asarray(x)
+    return a.ndim >= 1 and np.issubdtype(a.dtype, np.number) and (length is None or len(a) == length)
+
+
+TWO_PI = 2.0 * np.pi
+
+
+def make_valid_orientation(angle: float) -> float:
+    angle = angle % TWO_PI
+    if np.pi <= angle <= TWO_PI:
+        angle = angle - TWO_PI
+    return angle
+
+
+# ----------------------------------------------------------------------------------------------
+# commonroad.scenario.state / trajectory
+# ----------------------------------------------------------------------------------------------
+@dataclasses.dataclass(eq=False)
+class KSState:
+    position: Any = None
+    orientation: Any = None
+    velocity: Any = None
+    steering_angle: Any = None
+    time_step: Any = None
+
+    def translate_rotate(self, translation, angle):
+        new = dataclasses.replace(self)
+        new.position = np.asarray(self.position, dtype=float) + np.asarray(translation, dtype=float)
+        return new
+
+    def convert_state_to_state(self, other):
+        for f in dataclasses.fields(other) if dataclasses.is_dataclass(other) else []:
+            if hasattr(self, f.name):
+                setattr(other, f.name, getattr(self, f.name))
+        return other
+
+
+class CustomState(_Anything):
+    pass
+
+
+class InputState(_Anything):
+    pass
+
+
+@dataclasses.dataclass(eq=False)
+class InitialState(KSState):
+    yaw_rate: Any = None
+    slip_angle: Any = None
+    acceleration: Any = None
+
+
+class Trajectory:
+    def __init__(self, initial_time_step, state_list):
+        self.initial_time_step = initial_time_step
+        self.state_list = state_list
+
+
+# ----------------------------------------------------------------------------------------------
+# vehicle parameters (commonroad-vehicle-models 3.0.2, vehicle 2 = BMW 320i)
+# ----------------------------------------------------------------------------------------------
+class _Plain:
+    def __init__(self, **k):
+        self.__dict__.update(k)
+
+
+VEHICLE2 = _Plain(
+    l=4.508, w=1.610, a=1.1562, b=1.4227,
+    longitudinal=_Plain(a_max=11.5, v_switch=7.319, v_max=50.8, v_min=-13.6),
+    steering=_Plain(min=-1.066, max=1.066, v_min=-0.4, v_max=0.4),
+)
+
+
+class VehicleParameterMapping:
+    @staticmethod
+    def from_vehicle_type(vt):
+        return VEHICLE2
+
+
+class VehicleType:
+    def __init__(self, i):
+        self.value = i
+
+
+# ----------------------------------------------------------------------------------------------
+# geometry defined by this build: polyline coordinate system and SAT collision checker
+# ----------------------------------------------------------------------------------------------
+def _obb_axes(theta):
+    c, s = math.cos(theta), math.sin(theta)
+    return (c, s), (-s, c)
+
+
+def obb_obb_collide(a, b) -> bool:
+    """a, b = (cx, cy, theta, half_l, half_w).  Closed sets: touching counts as a collision."""
+    (aux, auy), (avx, avy) = _obb_axes(a[2])
+    (bux, buy), (bvx, bvy) = _obb_axes(b[2])
+    tx, ty = b[0] - a[0], b[1] - a[1]
+    uu = aux * bux + auy * buy
+    uv = aux * bvx + auy * bvy
+    vu = avx * bux + avy * buy
+    vv = avx * bvx + avy * bvy
+    if abs(tx * aux + ty * auy) > a[3] + (b[3] * abs(uu) + b[4] * abs(uv)):
+        return False
+    if abs(tx * avx + ty * avy) > a[4] + (b[3] * abs(vu) + b[4] * abs(vv)):
+        return False
+    if abs(tx * bux + ty * buy) > b[3] + (a[3] * abs(uu) + a[4] * abs(vu)):
+        return False
+    if abs(tx * bvx + ty * bvy) > b[4] + (a[3] * abs(uv) + a[4] * abs(vv)):
+        return False
+    return True
+
+
+def obb_tri_collide(a, tri) -> bool:
+    (ux, uy), (vx, vy) = _obb_axes(a[2])
+    hl, hw = a[3], a[4]
+    lx = []
+    ly = []
+    for k in range(3):
+        px, py = tri[2 * k] - a[0], tri[2 * k + 1] - a[1]
+        lx.append(px * ux + py * uy)
+        ly.append(px * vx + py * vy)
+    if min(lx) > hl or max(lx) < -hl:
+        return False
+    if min(ly) > hw or max(ly) < -hw:
+        return False
+    for k in range(3):
+        k2 = (k + 1) % 3
+        ex, ey = lx[k2] - lx[k], ly[k2] - ly[k]
+        nx, ny = -ey, ex
+        pr = [lx[j] * nx + ly[j] * ny for j in range(3)]
+        r = hl * abs(nx) + hw * abs(ny)
+        if min(pr) > r or max(pr) < -r:
+            return False
+    return True
+
+
+def obb_circle_collide(a, circ) -> bool:
+    (ux, uy), (vx, vy) = _obb_axes(a[2])
+    px, py = circ[0] - a[0], circ[1] - a[1]
+    lx = px * ux + py * uy
+    ly = px * vx + py * vy
+    dx = max(abs(lx) - a[3], 0.0)
+    dy = max(abs(ly) - a[4], 0.0)
+    return dx * dx + dy * dy <= circ[2] * circ[2]
+
+
+class RectOBB:
+    def __init__(self, half_length, half_width, theta, cx, cy):
+        self.t = (float(cx), float(cy), float(theta), float(half_length), float(half_width))
+
+
+class TimeVariantCollisionObject:
+    def __init__(self, time_start_idx):
+        self.time_start_idx = int(time_start_idx)
+        self.shapes: List[RectOBB] = []
+
+    def append_obstacle(self, shape):
+        self.shapes.append(shape)
+
+
+class CollisionChecker:
+    """Holds obstacle tables in the layout of ``commonroad_rp_amd.collision.ObstacleTables``."""
+
+    def __init__(self, tables=None):
+        self.tables = tables
+        self.n_queries = 0
+
+    def add_collision_object(self, obj):
+        raise NotImplementedError("fake checker is built from tables")
+
+    def collide(self, tvo: TimeVariantCollisionObject) -> bool:
+        self.n_queries += 1
+        tb = self.tables
+        if tb is None:
+            return False
+        for k, shape in enumerate(tvo.shapes):
+            t = tvo.time_start_idx + k
+            ego = shape.t
+            for o in tb.static_obb:
+                if obb_obb_collide(ego, o):
+                    return True
+            for tr in tb.static_tri:
+                if obb_tri_collide(ego, tr):
+                    return True
+            for c in tb.static_circ:
+                if obb_circle_collide(ego, c):
+                    return True
+            j = t - tb.dyn_t0
+            if 0 <= j < tb.dyn_obb.shape[1]:
+                for o in tb.dyn_obb[:, j, :]:
+                    if not np.isnan(o[0]) and obb_obb_collide(ego, o):
+                        return True
+        return False
+
+
+# ----------------------------------------------------------------------------------------------
+def install():
+    """Inject the stand-ins into ``sys.modules`` and put the reference on ``sys.path``."""
+    sys.dont_write_bytecode = True
+    _mod("methodtools", lru_cache=_lru_cache)
+    _mod("omegaconf", OmegaConf=_Anything)
+    # commonroad-io
+    _mod("commonroad")
+    _mod("commonroad.common")
+    _mod("commonroad.common.validity", is_real_number=is_real_number, is_natural_number=is_natural_number,
+         is_positive=is_positive, is_real_number_vector=is_real_number_vector)
+    _mod("commonroad.common.util", make_valid_orientation=make_valid_orientation)
+    _mod("commonroad.common.solution", VehicleType=VehicleType)
+    _mod("commonroad.common.file_reader", CommonRoadFileReader=_Anything)
+    _mod("commonroad.geometry")
+    _mod("commonroad.geometry.shape", Rectangle=_Anything)
+    _mod("commonroad.prediction")
+    _mod("commonroad.prediction.prediction", TrajectoryPrediction=_Anything)
+    _mod("commonroad.planning")
+    _mod("commonroad.planning.planning_problem", PlanningProblem=_Anything, PlanningProblemSet=_Anything)
+    _mod("commonroad.scenario")
+    _mod("commonroad.scenario.obstacle", DynamicObstacle=_Anything, ObstacleType=_Anything)
+    _mod("commonroad.scenario.trajectory", Trajectory=Trajectory)
+    _mod("commonroad.scenario.state", CustomState=CustomState, InputState=InputState, InitialState=InitialState,
+         KSState=KSState, FloatExactOrInterval=Any)
+    _mod("commonroad.scenario.scenario", Scenario=_Anything)
+    # commonroad-drivability-checker
+    _mod("commonroad_dc")
+    _mod("commonroad_dc.pycrcc", CollisionChecker=CollisionChecker, RectOBB=RectOBB,
+         TimeVariantCollisionObject=TimeVariantCollisionObject)
+    _mod("commonroad_dc.pycrccosy", CurvilinearCoordinateSystem=_Anything)
+    _mod("commonroad_dc.boundary")
+    _mod("commonroad_dc.boundary.boundary", create_road_boundary_obstacle=None)
+    _mod("commonroad_dc.collision")
+    _mod("commonroad_dc.collision.collision_detection")
+    _mod("commonroad_dc.collision.collision_detection.pycrcc_collision_dispatch", create_collision_object=None)
+    _mod("commonroad_dc.collision.trajectory_queries")
+    _mod("commonroad_dc.collision.trajectory_queries.trajectory_queries", trajectory_preprocess_obb_sum=None)
+    _mod("commonroad_dc.feasibility")
+    _mod("commonroad_dc.feasibility.vehicle_dynamics", VehicleParameterMapping=VehicleParameterMapping)
+    _mod("commonroad_dc.geometry")
+    _mod("commonroad_dc.geometry.util", compute_pathlength_from_polyline=None,
+         compute_curvature_from_polyline=None, compute_orientation_from_polyline=None,
+         resample_polyline=None, chaikins_corner_cutting=None)
+    # route planner / vehicle models
+    _mod("commonroad_route_planner")
+    _mod("commonroad_route_planner.route", Route=_Anything)
+    _mod("vehiclemodels")
+    _mod("vehiclemodels.vehicle_parameters", VehicleParameters=_Plain)
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
