@@ -1,0 +1,326 @@
+"""ctypes binding of the C ABI in ``include/rp_amd.h`` (``librp_amd.so``, built from ``csrc/``).
+
+This is the whole Python<->HIP boundary: plain pointers and sizes, no torch types.  The library is
+loaded from ``<package root>/lib/librp_amd.so`` (built in-tree by ``__graft_entry__.build()`` or
+``make -C commonroad-reactive-planner_amd/csrc``).  There is NO CPU fallback: if the library is
+missing, importing the binding works but creating a context raises ``RpLibraryMissing``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+N_ARRAYS = 14
+ARRAY_NAMES = ("x", "y", "theta", "v", "a", "kappa", "kappa_dot",
+               "s", "d", "theta_cl", "s_dot", "s_ddot", "d_dot", "d_ddot")
+
+LABEL_NONE, LABEL_FEASIBLE, LABEL_INFEASIBLE_KINEMATIC, LABEL_INFEASIBLE_COLLISION = 0, 1, 2, 3
+REASON_NAMES = ("none", "velocity", "acceleration", "kappa", "kappa_dot", "yaw_rate", "out_of_domain")
+CHECK_BITS = {"velocity": 1, "acceleration": 2, "kappa": 4, "kappa_dot": 8, "yaw_rate": 16}
+LON_VELOCITY_KEEPING, LON_STOPPING = 0, 1
+COST_DEFAULT, COST_FAILSAFE, COST_EXTERNAL = 0, 1, 2
+FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, FLAG_SKIP_COLLISION = 1, 2, 4
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "librp_amd.so")
+
+
+class RpLibraryMissing(RuntimeError):
+    pass
+
+
+class RpError(RuntimeError):
+    pass
+
+
+class RpParams(C.Structure):
+    _fields_ = [
+        ("dt", C.c_double), ("N", C.c_int32), ("factor", C.c_int32), ("time_step0", C.c_int32),
+        ("low_vel_mode", C.c_int32), ("lon_mode", C.c_int32), ("constraint_mask", C.c_uint32),
+        ("flags", C.c_uint32), ("reserved_", C.c_int32),
+        ("x0_lon", C.c_double * 3), ("x0_lat", C.c_double * 3), ("x0_orientation", C.c_double),
+        ("wheelbase", C.c_double), ("wb_rear_axle", C.c_double), ("length", C.c_double), ("width", C.c_double),
+        ("a_max", C.c_double), ("v_switch", C.c_double), ("delta_max", C.c_double), ("v_delta_max", C.c_double),
+    ]
+
+
+class RpCost(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved_", C.c_int32), ("w_a", C.c_double), ("desired_speed", C.c_double),
+                ("desired_d", C.c_double), ("desired_s", C.c_double)]
+
+
+class RpGrids(C.Structure):
+    _fields_ = [("nT", C.c_int32), ("nL", C.c_int32), ("nD", C.c_int32), ("reserved_", C.c_int32),
+                ("T", C.POINTER(C.c_double)), ("traj_len", C.POINTER(C.c_int32)),
+                ("L", C.POINTER(C.c_double)), ("D", C.POINTER(C.c_double))]
+
+
+class RpResult(C.Structure):
+    _fields_ = [("best_index", C.c_int64), ("best_cost", C.c_double), ("n_candidates", C.c_int64),
+                ("n_feasible", C.c_int64), ("n_collision_before_best", C.c_int64), ("n_collision", C.c_int64),
+                ("reason_counts", C.c_int64 * 8), ("best_lon_coeffs", C.c_double * 6),
+                ("best_lat_coeffs", C.c_double * 6), ("best_lat_T", C.c_double), ("kernel_ms", C.c_double)]
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+@dataclasses.dataclass
+class PlanInputs:
+    """Everything one ``rp_plan`` call consumes besides the tables held by the context."""
+    params: RpParams
+    cost: RpCost
+    T: np.ndarray
+    traj_len: np.ndarray
+    L: np.ndarray
+    D: np.ndarray
+
+    def __post_init__(self):
+        self.T = f64(self.T)
+        self.L = f64(self.L)
+        self.D = f64(self.D)
+        self.traj_len = np.ascontiguousarray(self.traj_len, dtype=np.int32)
+        assert self.T.ndim == self.L.ndim == self.D.ndim == 1 and self.traj_len.shape == self.T.shape
+
+    @property
+    def n_candidates(self) -> int:
+        return len(self.T) * len(self.L) * len(self.D)
+
+    def grids(self) -> RpGrids:
+        return RpGrids(len(self.T), len(self.L), len(self.D), 0, dptr(self.T),
+                       self.traj_len.ctypes.data_as(C.POINTER(C.c_int32)), dptr(self.L), dptr(self.D))
+
+
+@dataclasses.dataclass
+class PlanOutput:
+    best_index: int
+    best_cost: float
+    n_candidates: int
+    n_feasible: int
+    n_collision_before_best: int
+    n_collision: int
+    reason_counts: np.ndarray          # [8], index = reason code
+    best_lon_coeffs: np.ndarray
+    best_lat_coeffs: np.ndarray
+    best_lat_T: float
+    kernel_ms: float
+    best_states: Optional[np.ndarray]  # [14, N+1] or None
+
+    @classmethod
+    def from_c(cls, r: RpResult, best_states):
+        return cls(int(r.best_index), float(r.best_cost), int(r.n_candidates), int(r.n_feasible),
+                   int(r.n_collision_before_best), int(r.n_collision), np.array(r.reason_counts[:], dtype=np.int64),
+                   np.array(r.best_lon_coeffs[:]), np.array(r.best_lat_coeffs[:]), float(r.best_lat_T),
+                   float(r.kernel_ms), best_states if r.best_index >= 0 else None)
+
+    @property
+    def n_infeasible_kinematics(self) -> int:
+        """``ReactivePlanner.infeasible_count_kinematics`` (reactive_planner.py:1119)."""
+        return self.n_candidates - self.n_feasible
+
+
+def make_params(*, dt: float, N: int, x0_lon: Sequence[float], x0_lat: Sequence[float], x0_orientation: float,
+                wheelbase: float, wb_rear_axle: float, length: float, width: float, a_max: float, v_switch: float,
+                delta_max: float, v_delta_max: float, factor: int = 1, time_step0: int = 0, low_vel_mode: bool = False,
+                lon_mode: int = LON_VELOCITY_KEEPING, constraint_mask: int = 0x1F, flags: int = 0) -> RpParams:
+    p = RpParams()
+    p.dt, p.N, p.factor, p.time_step0 = float(dt), int(N), int(factor), int(time_step0)
+    p.low_vel_mode, p.lon_mode = int(bool(low_vel_mode)), int(lon_mode)
+    p.constraint_mask, p.flags = int(constraint_mask), int(flags)
+    p.x0_lon[:] = [float(v) for v in x0_lon]
+    p.x0_lat[:] = [float(v) for v in x0_lat]
+    p.x0_orientation = float(x0_orientation)
+    p.wheelbase, p.wb_rear_axle, p.length, p.width = float(wheelbase), float(wb_rear_axle), float(length), float(width)
+    p.a_max, p.v_switch, p.delta_max, p.v_delta_max = float(a_max), float(v_switch), float(delta_max), float(v_delta_max)
+    return p
+
+
+def make_cost(kind: int = COST_DEFAULT, w_a: float = 5.0, desired_speed: Optional[float] = None,
+              desired_d: float = 0.0, desired_s: Optional[float] = None) -> RpCost:
+    nan = float("nan")
+    return RpCost(int(kind), 0, float(w_a), nan if desired_speed is None else float(desired_speed), float(desired_d),
+                  nan if desired_s is None else float(desired_s))
+
+
+def copy_params(p: RpParams) -> RpParams:
+    q = RpParams()
+    C.memmove(C.byref(q), C.byref(p), C.sizeof(RpParams))
+    return q
+
+
+# ------------------------------------------------------------------------------------------------
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load ``librp_amd.so`` and declare every entry point of ``include/rp_amd.h``."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("RP_AMD_LIBRARY", LIB_PATH)
+    if not os.path.exists(path):
+        raise RpLibraryMissing(
+            f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
+            f"or make -C commonroad-reactive-planner_amd/csrc). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    ctx = C.c_void_p
+    dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    sig = {
+        "rp_abi_version": (C.c_int, []),
+        "rp_create": (C.c_int, [C.POINTER(ctx), C.c_int]),
+        "rp_destroy": (None, [ctx]),
+        "rp_last_error": (C.c_char_p, [ctx]),
+        "rp_set_profiling": (C.c_int, [ctx, C.c_int]),
+        "rp_set_reference": (C.c_int, [ctx, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double]),
+        "rp_set_obstacles": (C.c_int, [ctx, C.c_int32, dp, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32,
+                                       C.c_int32, dp]),
+        "rp_plan": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64,
+                              C.POINTER(RpResult), dp]),
+        "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
+                                     C.POINTER(RpResult), dp]),
+        "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
+        "rp_fetch_states": (C.c_int, [ctx, C.c_int64, C.c_int64, dp]),
+        "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
+        "rp_count_collisions_before": (C.c_int, [ctx, C.c_double, C.c_int64, C.POINTER(C.c_int64)]),
+        "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export the header's symbol
+        fn.restype, fn.argtypes = res, args
+    if lib.rp_abi_version() != 1:
+        raise RpError(f"librp_amd.so ABI version {lib.rp_abi_version()} != 1")
+    if path == LIB_PATH or _lib is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
+                    "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select")
+
+
+class RpContext:
+    """Owner of one ``rp_ctx`` (device tables, work buffers, one HIP stream)."""
+
+    def __init__(self, device: int = 0, library: Optional[str] = None):
+        self._lib = load_library(library)
+        self._h = C.c_void_p()
+        rc = self._lib.rp_create(C.byref(self._h), int(device))
+        if rc != 0:
+            msg = self._lib.rp_last_error(self._h) if self._h else b"rp_create failed"
+            raise RpError(f"rp_create(device={device}) -> {rc}: {(msg or b'').decode()}")
+        self.device = device
+        self._N = None
+        self._last_count = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RpError(f"{what} -> {rc}: {(self._lib.rp_last_error(self._h) or b'').decode()}")
+
+    def set_profiling(self, enable: bool):
+        self._check(self._lib.rp_set_profiling(self._h, int(enable)), "rp_set_profiling")
+
+    def set_reference(self, ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit: float = 20.0):
+        ref_pos, ref_theta, ref_curv, ref_curv_d = f64(ref_pos), f64(ref_theta), f64(ref_curv), f64(ref_curv_d)
+        xy = f64(ref_xy)
+        n = len(ref_pos)
+        assert xy.shape == (n, 2) and len(ref_theta) == len(ref_curv) == len(ref_curv_d) == n
+        x, y = f64(xy[:, 0]), f64(xy[:, 1])
+        self._check(self._lib.rp_set_reference(self._h, n, dptr(ref_pos), dptr(ref_theta), dptr(ref_curv),
+                                               dptr(ref_curv_d), dptr(x), dptr(y), float(proj_domain_d_limit)),
+                    "rp_set_reference")
+
+    def set_coordinate_system(self, co):
+        """Accepts anything with the reference ``CoordinateSystem`` attributes
+        (utils_coordinate_system.py:114-118, :120-123)."""
+        self.set_reference(co.ref_pos, co.ref_theta, co.ref_curv, co.ref_curv_d, co.reference,
+                           getattr(co, "proj_domain_d_limit", 20.0))
+
+    def set_obstacles(self, tables=None):
+        from .collision import ObstacleTables
+        tb = tables if tables is not None else ObstacleTables()
+        nd, ns = tb.dyn_obb.shape[0], tb.dyn_obb.shape[1]
+        self._check(self._lib.rp_set_obstacles(
+            self._h, len(tb.static_obb), dptr(tb.static_obb), len(tb.static_tri), dptr(tb.static_tri),
+            len(tb.static_circ), dptr(tb.static_circ), nd, ns, int(tb.dyn_t0), dptr(tb.dyn_obb)), "rp_set_obstacles")
+
+    def plan(self, inp: PlanInputs, cand_begin: int = 0, cand_end: int = -1, want_best_states: bool = True) -> PlanOutput:
+        res = RpResult()
+        n = inp.params.N + 1
+        best = np.empty((N_ARRAYS, n)) if want_best_states else None
+        g = inp.grids()
+        self._check(self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), int(cand_begin),
+                                      int(cand_end), C.byref(res), dptr(best)), "rp_plan")
+        self._N = inp.params.N
+        self._last_count = int(res.n_candidates)
+        return PlanOutput.from_c(res, best)
+
+    def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,
+                    want_best_states: bool = True) -> PlanOutput:
+        lon_coeffs, lat_coeffs, lon_T = f64(lon_coeffs), f64(lat_coeffs), f64(lon_T)
+        traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
+        cnt = len(traj_len)
+        assert lon_coeffs.shape == (cnt, 6) and lat_coeffs.shape == (cnt, 6) and lon_T.shape == (cnt,)
+        res = RpResult()
+        best = np.empty((N_ARRAYS, params.N + 1)) if want_best_states else None
+        self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs),
+                                             dptr(lat_coeffs), dptr(lon_T),
+                                             traj_len.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res), dptr(best)),
+                    "rp_plan_coeffs")
+        self._N = params.N
+        self._last_count = cnt
+        return PlanOutput.from_c(res, best)
+
+    def fetch_status(self, first: int = 0, count: Optional[int] = None):
+        count = self._last_count - first if count is None else count
+        status = np.empty(count, dtype=np.uint32)
+        cost = np.empty(count, dtype=np.float64)
+        self._check(self._lib.rp_fetch_status(self._h, first, count, status.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                              dptr(cost)), "rp_fetch_status")
+        return status, cost
+
+    def fetch_states(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self._last_count - first if count is None else count
+        out = np.empty((count, N_ARRAYS, self._N + 1))
+        self._check(self._lib.rp_fetch_states(self._h, first, count, dptr(out)), "rp_fetch_states")
+        return out
+
+    def eval_one(self, index: int):
+        out = np.empty((N_ARRAYS, self._N + 1))
+        st = C.c_uint32()
+        cost = C.c_double()
+        self._check(self._lib.rp_eval_one(self._h, int(index), dptr(out), C.byref(st), C.byref(cost)), "rp_eval_one")
+        return out, int(st.value), float(cost.value)
+
+    def count_collisions_before(self, cost: float, index: int) -> int:
+        n = C.c_int64()
+        self._check(self._lib.rp_count_collisions_before(self._h, float(cost), int(index), C.byref(n)),
+                    "rp_count_collisions_before")
+        return int(n.value)
+
+    def select(self, costs, want_best_states: bool = True) -> PlanOutput:
+        costs = f64(costs)
+        res = RpResult()
+        best = np.empty((N_ARRAYS, self._N + 1)) if want_best_states else None
+        self._check(self._lib.rp_select(self._h, dptr(costs), len(costs), C.byref(res), dptr(best)), "rp_select")
+        return PlanOutput.from_c(res, best)

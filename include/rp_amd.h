@@ -1,0 +1,204 @@
+/*
+ * rp_amd.h -- C ABI of the MI355X-native batch trajectory sampler/evaluator.
+ *
+ * One call (rp_plan) replaces, for one sampling level of one replanning cycle, the reference's
+ *
+ *   SamplingSpace.generate_trajectories_at_level      commonroad_rp/sampling.py:202-242
+ *   Quartic/QuinticTrajectory coefficient solves       commonroad_rp/polynomial_trajectory.py:292-320,341-360
+ *   ReactivePlanner._check_kinematics                  commonroad_rp/reactive_planner.py:715-969
+ *   ReactivePlanner._check_constraints                 commonroad_rp/reactive_planner.py:971-1017
+ *   CartesianSample.enlarge / CurviLinearSample.enlarge commonroad_rp/trajectories.py:168-197,302-332
+ *   DefaultCostFunction(.FailSafe).evaluate            commonroad_rp/cost_function.py:51-71,82-92
+ *   TrajectoryBundle.sort + _check_collisions          commonroad_rp/trajectories.py:502-510,
+ *                                                      commonroad_rp/reactive_planner.py:1019-1063
+ *   ReactivePlanner._get_optimal_trajectory            commonroad_rp/reactive_planner.py:1065-1136
+ *
+ * i.e. the two calls plan() makes per level (reactive_planner.py:620,624).  The reference is pure
+ * Python and has no FFI of its own; the binding a maintainer adds is the ctypes stub shown in
+ * INTEGRATION.md (shipped as commonroad_rp_amd/_capi.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every host buffer is caller-owned, C-contiguous, and only read
+ *     or written during the call.  The library owns all device memory inside rp_ctx.
+ *   - all functions return 0 on success and a negative RP_E* code on error; the message is
+ *     available from rp_last_error().  Nothing throws across the ABI.  Numerical failures (NaN
+ *     coefficients, leaving the projection domain) become per-candidate labels, never errors.
+ *   - one rp_ctx per thread / HIP stream; calls on one ctx must be serialised by the caller.
+ *     A ctx must not be used across fork() (the reference's debug.multiproc fan-out,
+ *     reactive_planner.py:1084-1111, is what the GPU batch replaces).
+ *   - candidate index = (iT * nL + iL) * nD + iD: the reference's list order
+ *     (for t in T: for lon in L: for d in D, sampling.py:218-241) when the grids are passed in
+ *     the reference's set-iteration order.
+ */
+#ifndef RP_AMD_H
+#define RP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_ABI_VERSION 1
+
+/* error codes */
+#define RP_OK 0
+#define RP_EINVAL (-1)  /* bad argument / inconsistent sizes */
+#define RP_EHIP (-2)    /* HIP runtime error (message has the hipError string) */
+#define RP_ESTATE (-3)  /* call sequence error (e.g. rp_plan before rp_set_reference) */
+#define RP_ENOMEM (-4)
+
+/* per-candidate status word:  label | reason << 4 | first_bad_step << 8 */
+#define RP_LABEL_NONE 0u                 /* reference label None: pre-filtered or left the projection domain */
+#define RP_LABEL_FEASIBLE 1u             /* FeasibilityStatus.FEASIBLE and (eagerly checked) collision-free */
+#define RP_LABEL_INFEASIBLE_KINEMATIC 2u /* FeasibilityStatus.INFEASIBLE_KINEMATIC */
+#define RP_LABEL_INFEASIBLE_COLLISION 3u /* kinematically feasible but colliding.  The reference marks
+                                            these lazily (only samples cheaper than the winner); here
+                                            every colliding feasible sample carries the label. */
+#define RP_STATUS_LABEL(s) ((s) & 3u)
+#define RP_STATUS_REASON(s) (((s) >> 4) & 7u)
+#define RP_STATUS_STEP(s) (((s) >> 8) & 0xFFFu)
+
+/* first-failure reasons; 1..5 index infeasible_reason_dict (reactive_planner.py:799,803,981-1015) */
+#define RP_REASON_NONE 0u
+#define RP_REASON_VELOCITY 1u
+#define RP_REASON_ACCELERATION 2u
+#define RP_REASON_KAPPA 3u
+#define RP_REASON_KAPPA_DOT 4u
+#define RP_REASON_YAW_RATE 5u
+#define RP_REASON_OUT_OF_DOMAIN 6u /* convert_to_cartesian_coords returned None (reactive_planner.py:910-917) */
+
+/* constraints_to_check bit mask (config.py:127-128) */
+#define RP_CHECK_VELOCITY (1u << 0)
+#define RP_CHECK_ACCELERATION (1u << 1)
+#define RP_CHECK_KAPPA (1u << 2)
+#define RP_CHECK_KAPPA_DOT (1u << 3)
+#define RP_CHECK_YAW_RATE (1u << 4)
+#define RP_CHECK_ALL 0x1Fu
+
+/* state block of one candidate: RP_N_ARRAYS rows of (N + 1) doubles, in this order
+ * (CartesianSample then CurviLinearSample, trajectories.py:61-75,200-213) */
+#define RP_N_ARRAYS 14
+enum rp_array {
+    RP_X = 0, RP_Y, RP_THETA, RP_V, RP_A, RP_KAPPA, RP_KAPPA_DOT,
+    RP_S, RP_D, RP_THETA_CL, RP_S_DOT, RP_S_DDOT, RP_D_DOT, RP_D_DDOT
+};
+
+#define RP_LON_VELOCITY_KEEPING 0 /* quartic longitudinal, L = target velocities (sampling.py:254-258) */
+#define RP_LON_STOPPING 1         /* quintic longitudinal, L = target positions  (sampling.py:259-263) */
+
+#define RP_COST_DEFAULT 0  /* DefaultCostFunction          cost_function.py:35-71 */
+#define RP_COST_FAILSAFE 1 /* DefaultCostFunctionFailSafe  cost_function.py:74-92 */
+#define RP_COST_EXTERNAL 2 /* plug-in cost: states are materialised, costs come back through rp_select */
+
+/* flags in rp_params.flags */
+#define RP_FLAG_DRAW_ALL (1u << 0)        /* _draw_traj_set: no pre-filter, no early exit (reactive_planner.py:796,903) */
+#define RP_FLAG_MATERIALIZE_ALL (1u << 1) /* keep every candidate's state block on the device (rp_fetch_states) */
+#define RP_FLAG_SKIP_COLLISION (1u << 2)  /* do not test against the obstacle tables */
+
+typedef struct rp_params {
+    double dt;              /* planning.dt */
+    int32_t N;              /* planning.time_steps_computation; arrays have N + 1 entries */
+    int32_t factor;         /* planning.factor (collision time index = time_step0 + i * factor) */
+    int32_t time_step0;     /* x_0.time_step */
+    int32_t low_vel_mode;   /* reactive_planner.py:594 */
+    int32_t lon_mode;       /* RP_LON_* */
+    uint32_t constraint_mask; /* RP_CHECK_* */
+    uint32_t flags;         /* RP_FLAG_* */
+    int32_t reserved_;
+    double x0_lon[3];       /* s, s_dot, s_ddot */
+    double x0_lat[3];       /* d, d_dot, d_ddot (derivatives w.r.t. s in low-velocity mode) */
+    double x0_orientation;  /* x_0.orientation (standstill branch, reactive_planner.py:866) */
+    double wheelbase, wb_rear_axle, length, width;
+    double a_max, v_switch, delta_max, v_delta_max;
+} rp_params;
+
+typedef struct rp_cost {
+    int32_t kind;         /* RP_COST_* */
+    int32_t reserved_;
+    double w_a;           /* DefaultCostFunction.w_a (5, or 1 in stopping mode) */
+    double desired_speed; /* NaN = None */
+    double desired_d;
+    double desired_s;     /* NaN = None */
+} rp_cost;
+
+typedef struct rp_grids {
+    int32_t nT, nL, nD, reserved_;
+    const double *T;         /* [nT] durations, reference iteration order */
+    const int32_t *traj_len; /* [nT] len(np.arange(0, round(T + dt, 5), dt)) (reactive_planner.py:733,748) */
+    const double *L;         /* [nL] longitudinal samples (stopping mode: already filtered by
+                                filter_goals_behind, trajectories.py:545-550) */
+    const double *D;         /* [nD] lateral samples including the appended d0 (sampling.py:226) */
+} rp_grids;
+
+typedef struct rp_result {
+    int64_t best_index;       /* winner = lexicographic min over (cost, index) among feasible,
+                                 collision-free candidates of this call's range; -1 if none */
+    double best_cost;         /* NaN if none */
+    int64_t n_candidates;     /* candidates evaluated by this call (cand_end - cand_begin) */
+    int64_t n_feasible;       /* kinematically feasible (colliding ones included):
+                                 infeasible_count_kinematics = n_candidates - n_feasible */
+    int64_t n_collision_before_best; /* infeasible_count_collision (lazy semantics of _check_collisions) */
+    int64_t n_collision;      /* all colliding feasible candidates (eager) */
+    int64_t reason_counts[8]; /* [RP_REASON_*]: 1..5 = infeasible_reason_dict, 6 = out of domain */
+    double best_lon_coeffs[6];
+    double best_lat_coeffs[6];
+    double best_lat_T;        /* delta_tau of the winner's lateral polynomial (low-velocity mode: a distance) */
+    double kernel_ms;         /* device time of this call's kernels (HIP events on the ctx stream);
+                                 0 unless profiling is enabled */
+} rp_result;
+
+typedef struct rp_ctx rp_ctx;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+int rp_abi_version(void);
+int rp_create(rp_ctx **out, int device);
+void rp_destroy(rp_ctx *ctx);
+const char *rp_last_error(const rp_ctx *ctx);
+/* record HIP events around the evaluation kernel of every rp_plan (rp_result.kernel_ms) */
+int rp_set_profiling(rp_ctx *ctx, int enable);
+
+/* ---- tables (once per reset / reference path) -------------------------------------------------- */
+/* CoordinateSystem tables (utils_coordinate_system.py:114-118) + polyline vertices (.reference). */
+int rp_set_reference(rp_ctx *ctx, int32_t n, const double *ref_pos, const double *ref_theta,
+                     const double *ref_curv, const double *ref_curv_d, const double *ref_x,
+                     const double *ref_y, double proj_domain_d_limit);
+/* Obstacle content of the collision checker (reactive_planner.py:234-251) as flat tables:
+ * sobb[n_sobb][5] = cx,cy,theta,half_l,half_w; tri[n_tri][6]; circ[n_circ][3] = cx,cy,r;
+ * dyn[n_dyn][n_steps][5] for scenario time steps dyn_t0 .. dyn_t0+n_steps-1 (cx = NaN: absent). */
+int rp_set_obstacles(rp_ctx *ctx, int32_t n_sobb, const double *sobb, int32_t n_tri, const double *tri,
+                     int32_t n_circ, const double *circ, int32_t n_dyn, int32_t n_steps, int32_t dyn_t0,
+                     const double *dyn);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+/* Evaluate candidates [cand_begin, cand_end) of the nT*nL*nD grid (cand_end < 0: all).
+ * best_states: NULL or [RP_N_ARRAYS][N + 1] receiving the winner's state block. */
+int rp_plan(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids,
+            int64_t cand_begin, int64_t cand_end, rp_result *result, double *best_states);
+
+/* Generic entry for foreign SamplingSpace plug-ins (sampling.py:165-175): the polynomials come
+ * from the plug-in's TrajectorySample objects.  lon_coeffs/lat_coeffs: [C][6]; lon_T/lat_T: [C]
+ * delta_tau of each polynomial; traj_len: [C].  Candidate index = list index. */
+int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C,
+                   const double *lon_coeffs, const double *lat_coeffs, const double *lon_T,
+                   const int32_t *traj_len, rp_result *result, double *best_states);
+
+/* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
+/* status[count], cost[count] (NaN where no cost) for local candidates first .. first+count-1
+ * (local = relative to cand_begin).  Either pointer may be NULL. */
+int rp_fetch_status(rp_ctx *ctx, int64_t first, int64_t count, uint32_t *status, double *cost);
+/* state blocks [count][RP_N_ARRAYS][N + 1]; needs RP_FLAG_MATERIALIZE_ALL in the last plan. */
+int rp_fetch_states(rp_ctx *ctx, int64_t first, int64_t count, double *states);
+/* state block of one (global) candidate index of the last plan, re-evaluated on the device. */
+int rp_eval_one(rp_ctx *ctx, int64_t index, double *states, uint32_t *status, double *cost);
+/* Multi-GPU second pass: number of colliding feasible local candidates that precede the global
+ * winner (cost, index) in the reference's sorted order. */
+int rp_count_collisions_before(rp_ctx *ctx, double cost, int64_t index, int64_t *count);
+/* Plug-in cost functions (RP_COST_EXTERNAL): upload one cost per local candidate (NaN = skip) and
+ * redo the selection (argmin + collision counters) on the device. */
+int rp_select(rp_ctx *ctx, const double *costs, int64_t count, rp_result *result, double *best_states);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RP_AMD_H */
