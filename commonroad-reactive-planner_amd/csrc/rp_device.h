@@ -1,0 +1,223 @@
+// rp_device.h -- device-side building blocks of the fused trajectory kernel (gfx950 / CDNA4).
+//
+// Layout idea: one *group* of G lanes (G = 32 or 64, i.e. half or a whole
+// wavefront) evaluates one candidate trajectory; lane l of the group owns time steps
+// l, l+G, l+2G, ...  Neighbour-step dependencies of the reference loop
+// (theta_gl[i-1], kappa_gl[i-1], the standstill orientation carry, "first failing step",
+// the horizon extension and the cost sums) become cross-lane operations inside the group.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rp_amd.h"
+
+#define RP_EPS 1e-5  // _EPS, commonroad_rp/reactive_planner.py:49
+#define RP_PI 3.14159265358979323846
+#define RP_TWO_PI 6.28318530717958647692
+
+// ------------------------------------------------------------------------------------------------
+// group-level cross-lane helpers (all 64 lanes of the wave must execute them)
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ uint64_t group_ballot(bool p, int gbase) {
+    uint64_t b = __ballot(p);
+    if (G == 64) return b;
+    return (b >> gbase) & ((1ull << G) - 1ull);
+}
+
+template <int G>
+__device__ __forceinline__ double group_bcast(double v, int src) { return __shfl(v, src, G); }
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+// inclusive prefix sum over the lanes of a group (Hillis-Steele)
+template <int G>
+__device__ __forceinline__ double group_scan(double v, int gl) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) {
+        double u = __shfl_up(v, o, G);
+        if (gl >= o) v += u;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// polynomials (PolynomialTrajectory.calc_*, commonroad_rp/polynomial_trajectory.py:240-271),
+// evaluated in Horner form; ps = {c0..c5}, pv = {c1,2c2,3c3,4c4,5c5}, pa = {2c2,6c3,12c4,20c5}
+// ------------------------------------------------------------------------------------------------
+struct Poly {
+    double c0, c1, c2, c3, c4, c5;
+    __device__ __forceinline__ double pos(double t) const { return ((((c5 * t + c4) * t + c3) * t + c2) * t + c1) * t + c0; }
+    __device__ __forceinline__ double vel(double t) const {
+        return (((5.0 * c5 * t + 4.0 * c4) * t + 3.0 * c3) * t + 2.0 * c2) * t + c1;
+    }
+    __device__ __forceinline__ double acc(double t) const { return ((20.0 * c5 * t + 12.0 * c4) * t + 6.0 * c3) * t + 2.0 * c2; }
+};
+
+// QuinticTrajectory._calc_coeffs_static (polynomial_trajectory.py:292-320): closed-form solution of
+// the 3x3 system instead of LAPACK gesv.
+__device__ __forceinline__ Poly quintic_coeffs(double p0, double v0, double a0, double pf, double vf, double af, double T) {
+    double T2 = T * T, T3 = T2 * T, T4 = T2 * T2, T5 = T4 * T;
+    double bp = pf - (p0 + v0 * T + 0.5 * a0 * T2);
+    double bv = vf - (v0 + a0 * T);
+    double ba = af - a0;
+    Poly c;
+    c.c0 = p0; c.c1 = v0; c.c2 = 0.5 * a0;
+    c.c3 = (20.0 * bp - 8.0 * T * bv + T2 * ba) / (2.0 * T3);
+    c.c4 = (-30.0 * bp + 14.0 * T * bv - 2.0 * T2 * ba) / (2.0 * T4);
+    c.c5 = (12.0 * bp - 6.0 * T * bv + T2 * ba) / (2.0 * T5);
+    return c;
+}
+
+// QuarticTrajectory._calc_coeffs_static_ (polynomial_trajectory.py:341-360), closed form of the 2x2.
+__device__ __forceinline__ Poly quartic_coeffs(double p0, double v0, double a0, double T, double vd) {
+    double T2 = T * T, T3 = T2 * T;
+    double bv = vd - v0 - a0 * T;
+    double ba = -a0;
+    Poly c;
+    c.c0 = p0; c.c1 = v0; c.c2 = 0.5 * a0;
+    c.c3 = (3.0 * bv - T * ba) / (3.0 * T2);
+    c.c4 = (T * ba - 2.0 * bv) / (4.0 * T3);
+    c.c5 = 0.0;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference-path tables.  Eight rows of n doubles, contiguous: pos, theta, curv, curv_d, x, y, tx, ty
+// (utils_coordinate_system.py:114-118 + the polyline and its vertex tangents).
+// ------------------------------------------------------------------------------------------------
+enum { TB_POS = 0, TB_THETA, TB_CURV, TB_CURV_D, TB_X, TB_Y, TB_TX, TB_TY, TB_ROWS };
+
+// make_valid_orientation (commonroad-io, used by interpolate_angle, utils_coordinate_system.py:43)
+__device__ __forceinline__ double make_valid_orientation(double a) {
+    double m = a;
+    if (!(fabs(a) < RP_TWO_PI)) m = fmod(a, RP_TWO_PI);  // exact either way; fmod only off the fast path
+    if (m < 0.0) m += RP_TWO_PI;
+    if (RP_PI <= m && m <= RP_TWO_PI) m -= RP_TWO_PI;
+    return m;
+}
+
+// first index with pos[idx] > s (n if none): np.argmax(ref_pos > s) (reactive_planner.py:835) is
+// this index, or 0 when it is n.  Fixed trip count, no divergence.
+__device__ __forceinline__ int upper_bound(const double *pos, int n, int iters, double s) {
+    int lo = 0, hi = n;
+    for (int it = 0; it < iters; ++it) {
+        int mid = (lo + hi) >> 1;
+        mid = mid < n ? mid : n - 1;
+        bool right = (lo < hi) && !(pos[mid] > s);
+        bool left = (lo < hi) && (pos[mid] > s);
+        lo = right ? mid + 1 : lo;
+        hi = left ? mid : hi;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// collision primitives: ego OBB (RectOBB of reactive_planner.py:1041) against the obstacle tables.
+// Closed sets, separating-axis tests; same formulas as oracle/rp_oracle.c.
+// ------------------------------------------------------------------------------------------------
+struct Obb { double cx, cy, ux, uy, hl, hw; };
+
+__device__ __forceinline__ bool obb_obb(const Obb &a, const Obb &b) {
+    double avx = -a.uy, avy = a.ux, bvx = -b.uy, bvy = b.ux;
+    double tx = b.cx - a.cx, ty = b.cy - a.cy;
+    double uu = a.ux * b.ux + a.uy * b.uy;
+    double uv = a.ux * bvx + a.uy * bvy;
+    double vu = avx * b.ux + avy * b.uy;
+    double vv = avx * bvx + avy * bvy;
+    bool sep = fabs(tx * a.ux + ty * a.uy) > a.hl + (b.hl * fabs(uu) + b.hw * fabs(uv));
+    sep |= fabs(tx * avx + ty * avy) > a.hw + (b.hl * fabs(vu) + b.hw * fabs(vv));
+    sep |= fabs(tx * b.ux + ty * b.uy) > b.hl + (a.hl * fabs(uu) + a.hw * fabs(vu));
+    sep |= fabs(tx * bvx + ty * bvy) > b.hw + (a.hl * fabs(uv) + a.hw * fabs(vv));
+    return !sep;
+}
+
+__device__ __forceinline__ bool obb_tri(const Obb &a, const double *t) {
+    double vx = -a.uy, vy = a.ux;
+    double lx[3], ly[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double px = t[2 * k] - a.cx, py = t[2 * k + 1] - a.cy;
+        lx[k] = px * a.ux + py * a.uy;
+        ly[k] = px * vx + py * vy;
+    }
+    bool sep = fmin(lx[0], fmin(lx[1], lx[2])) > a.hl || fmax(lx[0], fmax(lx[1], lx[2])) < -a.hl;
+    sep |= fmin(ly[0], fmin(ly[1], ly[2])) > a.hw || fmax(ly[0], fmax(ly[1], ly[2])) < -a.hw;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int k2 = (k + 1) % 3;
+        double ex = lx[k2] - lx[k], ey = ly[k2] - ly[k];
+        double nx = -ey, ny = ex;
+        double p0 = lx[0] * nx + ly[0] * ny, p1 = lx[1] * nx + ly[1] * ny, p2 = lx[2] * nx + ly[2] * ny;
+        double r = a.hl * fabs(nx) + a.hw * fabs(ny);
+        sep |= fmin(p0, fmin(p1, p2)) > r || fmax(p0, fmax(p1, p2)) < -r;
+    }
+    return !sep;
+}
+
+__device__ __forceinline__ bool obb_circ(const Obb &a, double cx, double cy, double r) {
+    double vx = -a.uy, vy = a.ux;
+    double px = cx - a.cx, py = cy - a.cy;
+    double lx = px * a.ux + py * a.uy, ly = px * vx + py * vy;
+    double dx = fmax(fabs(lx) - a.hl, 0.0), dy = fmax(fabs(ly) - a.hw, 0.0);
+    return dx * dx + dy * dy <= r * r;
+}
+
+// Obstacle tables on the device.  Static shapes: array-of-structs rows of 8 doubles, every lane
+// reads the same row (broadcast).  Dynamic OBBs: struct-of-arrays [7][n_dyn][n_steps] so that the
+// lanes of a group (consecutive time steps) read consecutive addresses.
+enum { OB_CX = 0, OB_CY, OB_UX, OB_UY, OB_HL, OB_HW, OB_R, OB_PAD, OB_ROW };  // static obb row
+struct ObsTables {
+    const double *sobb;  // [n_sobb][8]  cx, cy, ux, uy, hl, hw, r_bound, -
+    const double *tri;   // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
+    const double *circ;  // [n_circ][4]  cx, cy, r, -
+    const double *dyn;   // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent)
+    int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0;
+};
+
+// cc.collide(ego pose at scenario time index t)  (reactive_planner.py:1040-1042).
+// Bounding-circle rejection first (conservative: a small relative margin keeps it from ever
+// rejecting a pair the exact test would accept).
+__device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t) {
+    bool hit = false;
+    for (int j = 0; j < ob.n_sobb; ++j) {
+        const double *o = ob.sobb + j * OB_ROW;
+        double dx = o[OB_CX] - ego.cx, dy = o[OB_CY] - ego.cy, rr = ego_r + o[OB_R];
+        if (dx * dx + dy * dy <= rr * rr * 1.000001) {
+            Obb b = {o[OB_CX], o[OB_CY], o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
+            hit |= obb_obb(ego, b);
+        }
+    }
+    for (int j = 0; j < ob.n_tri; ++j) {
+        const double *o = ob.tri + j * 10;
+        double dx = o[6] - ego.cx, dy = o[7] - ego.cy, rr = ego_r + o[8];
+        if (dx * dx + dy * dy <= rr * rr * 1.000001) hit |= obb_tri(ego, o);
+    }
+    for (int j = 0; j < ob.n_circ; ++j) {
+        const double *o = ob.circ + j * 4;
+        hit |= obb_circ(ego, o[0], o[1], o[2]);
+    }
+    int k = t - ob.dyn_t0;
+    if (k >= 0 && k < ob.n_steps) {
+        const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+        for (int j = 0; j < ob.n_dyn; ++j) {
+            const double *o = ob.dyn + (size_t)j * ob.n_steps + k;
+            double cx = o[0];
+            if (cx == cx) {  // not NaN
+                double cy = o[plane], rr = ego_r + o[6 * plane];
+                double dx = cx - ego.cx, dy = cy - ego.cy;
+                if (dx * dx + dy * dy <= rr * rr * 1.000001) {
+                    Obb b = {cx, cy, o[2 * plane], o[3 * plane], o[4 * plane], o[5 * plane]};
+                    hit |= obb_obb(ego, b);
+                }
+            }
+        }
+    }
+    return hit;
+}

