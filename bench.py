@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: candidate trajectories / s (sample + convert + check + cost + collide
++ select) per replanning step, through the C ABI of librp_amd.so.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--mode draw|materialize|fused]
+
+One *step* = one ``rp_plan`` call over the whole candidate batch of one replanning cycle (grids and
+parameters staged host->device inside the call: a few hundred bytes; tables resident), including
+the winner's state block coming back to the host.  N > 1: one process per GPU, every rank evaluates
+its contiguous shard of an N-times denser longitudinal grid (weak scaling) and the ranks exchange
+one (cost, index) pair + counters per step over RCCL.
+
+Prints ONE JSON line (rank 0).  Modes:
+  draw        every candidate fully evaluated (no pre-filter / early exit, the reference's
+              draw_traj_set semantics) and all 14 state rows of every candidate written to HBM.
+              Default: work per candidate is data independent and the byte count is SURVEY 8(d)'s
+              bytes = C*12 + C*112*(N+1) + 112*(N+1).
+  materialize production early-exit semantics, state rows of feasible candidates written
+  fused       production semantics, 12 B per candidate leave the kernel
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import (RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL)
+    from commonroad_rp_amd.distributed import shard_range, exchange_winner
+
+    flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[args.mode]
+    base = W.WORKLOADS[args.workload]()
+    w = W.replicate_for_ranks(base, world)
+    p = copy_params(w.inputs.params)
+    p.flags |= flags
+    inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
+    C_total = inp.n_candidates
+    lo, hi = shard_range(C_total, rank, world)
+    N = p.N
+
+    ctx = RpContext(local_rank)
+    w.setup(ctx)
+    ctx.set_profiling(True)
+
+    def step():
+        out = ctx.plan(inp, lo, hi)
+        if world > 1:
+            return exchange_winner(ctx, out, dist, torch.device("cuda", local_rank)), out
+        return out, out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kernel_ms = []
+    n_feasible = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, loc = step()
+        kernel_ms.append(loc.kernel_ms)
+        n_feasible = loc.n_feasible
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (rp_eval_kernel): algorithmic bytes per launch / avg duration
+    C_loc = hi - lo
+    blk = 112 * (N + 1)
+    if args.mode == "draw":
+        bytes_per_launch = C_loc * 12 + C_loc * blk
+    elif args.mode == "materialize":
+        bytes_per_launch = C_loc * 12 + n_feasible * blk
+    else:
+        bytes_per_launch = C_loc * 12
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else float("nan")
+
+    result = {
+        "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
+        "value": C_total * args.steps / elapsed,
+        "unit": "candidates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{base.name}: {w.description}", "mode": args.mode, "candidates_per_step": C_total,
+                   "candidates_per_gpu": C_loc, "horizon_steps": N,
+                   "n_obstacles": int(w.obstacles.dyn_obb.shape[0] + len(w.obstacles.static_obb)),
+                   "parallelism": f"candidate-range sharding x{world}"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rp_eval_kernel",
+                     "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
+    }
+
+    if rank == 0 and world == 1:
+        # production-mode rate beside the headline (same workload, early exits, 12 B / candidate)
+        if args.mode != "fused":
+            pf = copy_params(w.inputs.params)
+            inf = PlanInputs(pf, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
+            for _ in range(5):
+                ctx.plan(inf)
+            t1 = time.perf_counter()
+            kk = []
+            for _ in range(max(20, args.steps // 4)):
+                kk.append(ctx.plan(inf).kernel_ms)
+            el = time.perf_counter() - t1
+            result["fused_mode"] = {"value": C_total * len(kk) / el, "unit": "candidates/s",
+                                    "ms_per_step": el / len(kk) * 1e3, "kernel_ms": float(np.mean(kk))}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(w, inp, args.cpu_seconds)
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(w, inp, budget_s: float):
+    """The CPU oracle (C port of the reference's algorithm, oracle/rp_oracle.c) timed on one host
+    core on the same workload and mode, repeated for about ``budget_s`` seconds."""
+    from oracle import oracle
+    tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+    C = inp.n_candidates
+    sample = min(C, 20000)
+    t0 = time.perf_counter()
+    oracle.plan(inp, tb, 0, sample, want_states=True)
+    one = time.perf_counter() - t0
+    reps = max(1, int(budget_s / max(one, 1e-4)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.plan(inp, tb, 0, sample, want_states=True)
+    el = time.perf_counter() - t0
+    return {"value": sample * reps / el, "unit": "candidates/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} candidates of the same workload and mode, {reps} repetitions, "
+                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores (C port; the Python reference itself ran "
+                      f"~3.9e3 candidates/s/core in the build container, BASELINE.md)"}
+
+
+if __name__ == "__main__":
+    main()

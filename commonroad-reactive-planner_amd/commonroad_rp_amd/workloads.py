@@ -1,0 +1,224 @@
+"""The five BASELINE.json configurations as concrete ``PlanInputs`` + tables.
+
+Scenario geometry (route centre line, obstacle boxes per time step, initial state) comes from the
+small ``tests/golden/scenario_*.npz`` fixtures extracted from the reference's example XML files by
+``tests/golden/make_scenarios.py``; grids, horizons and synthetic obstacles follow SURVEY 8d.
+Everything here is deterministic (seeded) synthetic input of the configured shape.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import os
+from typing import Optional
+
+import numpy as np
+
+from ._capi import PlanInputs, make_cost, make_params
+from .collision import ObstacleTables
+from .coordinate_system import CoordinateSystem, interpolate_angle, resample_polyline
+
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SCENARIO_DIR = os.path.join(_REPO, "tests", "golden")
+
+# commonroad-vehicle-models 3.0.2, vehicle 2 (BMW 320i) as used by all shipped configurations
+# (configurations/*.yaml: id_type_vehicle 2; commonroad_rp/utility/config.py:198-222)
+VEHICLE2 = dict(length=4.508, width=1.610, wb_rear_axle=1.4227, wheelbase=1.1562 + 1.4227, a_max=11.5,
+                v_switch=7.319, delta_max=1.066, v_delta_max=0.4)
+
+
+@dataclasses.dataclass
+class Workload:
+    name: str
+    description: str
+    inputs: PlanInputs
+    coordinate_system: CoordinateSystem
+    obstacles: ObstacleTables
+
+    @property
+    def n_candidates(self) -> int:
+        return self.inputs.n_candidates
+
+    def setup(self, ctx):
+        ctx.set_coordinate_system(self.coordinate_system)
+        ctx.set_obstacles(self.obstacles)
+
+
+def smooth_ref_path(ref_path: np.ndarray, resample_step: float = 1.0) -> np.ndarray:
+    """Cubic-spline smoothing + equidistant resampling of a route centre line, as
+    ``smooth_ref_path`` does (utils_coordinate_system.py:74-83: splprep k=3 s=0, 200 samples)."""
+    from scipy.interpolate import splprep, splev
+    ref_path = np.asarray(ref_path, dtype=np.float64)
+    keep = np.ones(len(ref_path), dtype=bool)
+    keep[1:] = np.any(np.diff(ref_path, axis=0) != 0.0, axis=1)
+    ref_path = ref_path[keep]
+    tck, u = splprep(ref_path.T, u=None, k=3, s=0.0)
+    u_new = np.linspace(u.min(), u.max(), 200)
+    x_new, y_new = splev(u_new, tck, der=0)
+    return resample_polyline(np.array([x_new, y_new]).transpose(), resample_step)
+
+
+def traj_len_of(T, dt: float) -> np.ndarray:
+    """``len(np.arange(0, np.round(T + dt, 5), dt))`` (reactive_planner.py:733,748)."""
+    return np.array([len(np.arange(0, np.round(t + dt, 5), dt)) for t in np.atleast_1d(T)], dtype=np.int32)
+
+
+def initial_curvilinear_state(co: CoordinateSystem, x: float, y: float, orientation: float, velocity: float,
+                              acceleration: float = 0.0, steering_angle: float = 0.0, low_vel_mode: bool = False,
+                              wheelbase: float = VEHICLE2["wheelbase"]):
+    """``ReactivePlanner._compute_initial_states`` (reactive_planner.py:446-512), once per replan."""
+    s, d = co.convert_to_curvilinear_coords(x, y)
+    ref_pos = co.ref_pos
+    s_idx = int(np.argmax(ref_pos > s)) - 1
+    s_lambda = (s - ref_pos[s_idx]) / (ref_pos[s_idx + 1] - ref_pos[s_idx])
+    ref_theta = np.unwrap(co.ref_theta)
+    theta_cl = orientation - interpolate_angle(s, ref_pos[s_idx], ref_pos[s_idx + 1], ref_theta[s_idx],
+                                               ref_theta[s_idx + 1])
+    kr = (co.ref_curv[s_idx + 1] - co.ref_curv[s_idx]) * s_lambda + co.ref_curv[s_idx]
+    kr_d = (co.ref_curv_d[s_idx + 1] - co.ref_curv_d[s_idx]) * s_lambda + co.ref_curv_d[s_idx]
+    kappa_0 = np.tan(steering_angle) / wheelbase
+    d_p = (1 - kr * d) * np.tan(theta_cl)
+    d_pp = -(kr_d * d + kr * d_p) * np.tan(theta_cl) + ((1 - kr * d) / (math.cos(theta_cl) ** 2)) * (
+        kappa_0 * (1 - kr * d) / math.cos(theta_cl) - kr)
+    s_velocity = velocity * math.cos(theta_cl) / (1 - kr * d)
+    if s_velocity < 0:
+        raise Exception("Initial state or reference incorrect! Curvilinear velocity is negative which indicates"
+                        "that the ego vehicle is not driving in the same direction as specified by the reference")
+    s_acceleration = acceleration
+    s_acceleration -= (s_velocity ** 2 / math.cos(theta_cl)) * (
+        (1 - kr * d) * np.tan(theta_cl) * (kappa_0 * (1 - kr * d) / (math.cos(theta_cl)) - kr) - (kr_d * d + kr * d_p))
+    s_acceleration /= ((1 - kr * d) / (math.cos(theta_cl)))
+    if low_vel_mode:
+        d_velocity, d_acceleration = d_p, d_pp
+    else:
+        d_velocity = velocity * math.sin(theta_cl)
+        d_acceleration = s_acceleration * d_p + s_velocity ** 2 * d_pp
+    return [float(s), float(s_velocity), float(s_acceleration)], [float(d), float(d_velocity), float(d_acceleration)]
+
+
+def velocity_range(v0: float, horizon: float, a_max: float = VEHICLE2["a_max"]):
+    """``set_desired_velocity`` sampling interval (reactive_planner.py:332-335)."""
+    min_v = max(0, v0 - (0.125 * horizon * a_max))
+    max_v = max(min_v + 5.0, v0 + 2)
+    return min_v, max_v
+
+
+def _load_scenario(name: str):
+    return dict(np.load(os.path.join(SCENARIO_DIR, f"scenario_{name}.npz")))
+
+
+def _with_d0(D: np.ndarray, d0: float) -> np.ndarray:
+    """``samples_d.union({x_0_lat[0]})`` (sampling.py:226): the current offset is appended unless present."""
+    return D if np.any(D == d0) else np.append(D, d0)
+
+
+def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired_speed=None, extra_obstacles=0,
+                       flags=0, description="") -> Workload:
+    sc = _load_scenario(scen_name)
+    dt = float(sc["dt"])
+    co = CoordinateSystem(smooth_ref_path(sc["centre"]))
+    x, y, th, v0 = (float(v) for v in sc["init"])
+    # the planner state sits on the rear axle (state.py:52-55)
+    xr, yr = x - VEHICLE2["wb_rear_axle"] * math.cos(th), y - VEHICLE2["wb_rear_axle"] * math.sin(th)
+    low = v0 < low_vel_threshold
+    x0_lon, x0_lat = initial_curvilinear_state(co, xr, yr, th, v0, low_vel_mode=low)
+    vmin, vmax = velocity_range(v0, N * dt)
+    L = np.linspace(vmin, vmax, nL)
+    D = _with_d0(np.linspace(-3.0, 3.0, nD), x0_lat[0])
+    T = np.asarray(T, dtype=np.float64)
+    dyn = sc["dyn_obb"]
+    if extra_obstacles:
+        rng = np.random.default_rng(0)
+        n_steps = max(dyn.shape[1], N + 1)
+        ext = np.full((dyn.shape[0] + extra_obstacles, n_steps, 5), np.nan)
+        ext[:dyn.shape[0], :dyn.shape[1]] = dyn
+        s_max = co.ref_pos[-1]
+        for j in range(extra_obstacles):   # constant-velocity 4.5 x 2.0 m boxes along the route
+            s0, vel, off = rng.uniform(0.0, s_max), rng.uniform(5.0, 15.0), rng.uniform(-1.5, 1.5)
+            lane = rng.choice([-1.0, 1.0]) * 4.0      # neighbouring lanes
+            for k in range(n_steps):
+                s = s0 + vel * dt * k
+                if s >= s_max - 1.0:
+                    break
+                p = co.convert_to_cartesian_coords(s, off + lane)
+                kk = min(int(np.searchsorted(co.ref_pos, s, side="right")) - 1, len(co.ref_pos) - 2)
+                ext[dyn.shape[0] + j, k] = (p[0], p[1], co.ref_theta[kk], 2.25, 1.0)
+        dyn = ext
+    obstacles = ObstacleTables(static_obb=sc["static_obb"], dyn_obb=dyn, dyn_t0=int(sc["dyn_t0"]))
+    params = make_params(dt=dt, N=N, x0_lon=x0_lon, x0_lat=x0_lat, x0_orientation=th, low_vel_mode=low,
+                         time_step0=int(sc["init_time_step"]), flags=flags, **VEHICLE2)
+    cost = make_cost(desired_speed=v0 if desired_speed is None else desired_speed)
+    inp = PlanInputs(params, cost, T, traj_len_of(T, dt), L, D)
+    return Workload(name, description, inp, co, obstacles)
+
+
+def cfg1(level: int = 3) -> Workload:
+    """ZAM_Over-1_1, reference sampling levels (N = 20, t_min 0.2, configurations/ZAM_Over-1_1.yaml)."""
+    dt, N, t_min = 0.1, 20, 0.2
+    step = int((1 / (level + 1)) / dt)
+    T = sorted(set(np.arange(t_min, round(N * dt + dt, 2), step * dt)) - {round(N * dt + dt, 2)})
+    n = 2 ** (level + 1) + 1
+    return _scenario_workload("cfg1", "ZAM_Over-1_1", N, T, n, n, low_vel_threshold=4.0,
+                              description=f"ZAM_Over-1_1, sampling level {level}, N=20")
+
+
+def cfg2(flags: int = 0) -> Workload:
+    """ZAM_Tjunction-1_42_T-1, 15 x 15 x 31 grid, N = 30, 5 dynamic obstacles."""
+    dt, N = 0.1, 30
+    T = [dt * (16 + k) for k in range(15)]
+    return _scenario_workload("cfg2", "ZAM_Tjunction-1_42_T-1", N, T, 31, 15, low_vel_threshold=2.0, flags=flags,
+                              description="ZAM_Tjunction-1_42_T-1, 15(d)x15(T)x31(v) grid, N=30, 5 dynamic obstacles")
+
+
+def cfg3(flags: int = 0) -> Workload:
+    """DEU_Test-1_1_T-1, 31 x 31 x 63 grid, N = 60, 1 static + 1 dynamic + 49 synthetic obstacles."""
+    dt, N = 0.1, 60
+    T = [dt * (30 + k) for k in range(31)]
+    return _scenario_workload("cfg3", "DEU_Test-1_1_T-1", N, T, 63, 31, low_vel_threshold=4.0, extra_obstacles=49,
+                              flags=flags,
+                              description="DEU_Test-1_1_T-1, 31x31x63 grid, N=60, 51 obstacles (49 synthetic, seed 0)")
+
+
+def cfg4(flags: int = 0) -> Workload:
+    """ZAM_Tjunction-1_42_T-1, 63 x 63 x 127 grid, N = 100."""
+    dt, N = 0.1, 100
+    T = [dt * (38 + k) for k in range(63)]
+    return _scenario_workload("cfg4", "ZAM_Tjunction-1_42_T-1", N, T, 127, 63, low_vel_threshold=2.0, flags=flags,
+                              description="ZAM_Tjunction-1_42_T-1, 63x63x127 grid, N=100, 5 dynamic obstacles")
+
+
+def cfg5(flags: int = 0, obstacles: int = 0, scale: int = 1) -> Workload:
+    """Synthetic straight lane, 101(d) x 99(T) x 101(v) = 1 009 899 candidates, N = 100."""
+    dt, N = 0.1, 100
+    ref = np.stack((np.arange(0.0, 401.0, 1.0), np.zeros(401)), axis=1)
+    co = CoordinateSystem(ref)
+    T = np.array([dt * k for k in range(2, 101)])
+    L = np.linspace(12.0, 18.0, 101 * scale)
+    D = np.linspace(-3.0, 3.0, 101)
+    tables = ObstacleTables()
+    if obstacles:
+        rng = np.random.default_rng(0)
+        dyn = np.full((obstacles, N + 1, 5), np.nan)
+        for j in range(obstacles):
+            s0, vel, lane = rng.uniform(30.0, 380.0), rng.uniform(5.0, 15.0), rng.choice([-4.5, 4.5])
+            for k in range(N + 1):
+                dyn[j, k] = (s0 + vel * dt * k, lane + rng.uniform(-0.2, 0.2), 0.0, 2.25, 1.0)
+        tables = ObstacleTables(dyn_obb=dyn, dyn_t0=0)
+    params = make_params(dt=dt, N=N, x0_lon=[20.0, 15.0, 0.0], x0_lat=[0.0, 0.0, 0.0], x0_orientation=0.0,
+                         low_vel_mode=False, flags=flags, **VEHICLE2)
+    inp = PlanInputs(params, make_cost(desired_speed=15.0), T, traj_len_of(T, dt), L, _with_d0(D, 0.0))
+    return Workload("cfg5", "synthetic straight lane, 101x99x101 grid, N=100", inp, co, tables)
+
+
+def replicate_for_ranks(w: Workload, world_size: int) -> Workload:
+    """Weak-scaling variant: the longitudinal grid is densified ``world_size`` times so that every
+    rank evaluates a shard of the original size (BASELINE north star: shard the candidate batch)."""
+    if world_size == 1:
+        return w
+    L = w.inputs.L
+    dense = np.linspace(L.min(), L.max(), len(L) * world_size)
+    inp = PlanInputs(w.inputs.params, w.inputs.cost, w.inputs.T, w.inputs.traj_len, dense, w.inputs.D)
+    return Workload(w.name, w.description + f", L densified x{world_size}", inp, w.coordinate_system, w.obstacles)
+
+
+WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}

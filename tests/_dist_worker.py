@@ -1,0 +1,45 @@
+"""Worker of tests/test_distributed_gloo.py: one rank of a world_size-N gloo group evaluating its
+shard (with the oracle-backed context; no GPU in the CPU test suite) and joining the exchange."""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+for p in (REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from _golden import Golden
+    from _oracle_ctx import OracleContext
+    from commonroad_rp_amd.distributed import shard_range, exchange_winner
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    results = {}
+    for name in sys.argv[2:]:
+        g = Golden(name)
+        ctx = OracleContext()
+        g.setup_context(ctx)
+        lo, hi = shard_range(g.inputs.n_candidates, rank, world)
+        out = ctx.plan(g.inputs, lo, hi)
+        glob = exchange_winner(ctx, out, dist, torch.device("cpu"))
+        results[name] = dict(best_index=glob.best_index, best_cost=glob.best_cost, n_feasible=glob.n_feasible,
+                             n_collision=glob.n_collision, n_before=glob.n_collision_before_best,
+                             n_candidates=glob.n_candidates, reasons=glob.reason_counts.tolist(),
+                             states_sum=None if glob.best_states is None else float(np.sum(glob.best_states)),
+                             lon=glob.best_lon_coeffs.tolist())
+    dist.barrier()
+    with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
+        json.dump(results, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""An object with the interface of ``commonroad_rp_amd._capi.RpContext`` backed by the CPU oracle.
+
+TEST INFRASTRUCTURE: lets the CPU-only test suite exercise the host-side glue (planner mirror,
+multi-rank exchange) that normally sits on top of the HIP library.  Never used by the product."""
+import numpy as np
+
+from commonroad_rp_amd._capi import N_ARRAYS
+from commonroad_rp_amd.collision import ObstacleTables
+from oracle import oracle
+
+
+class OracleContext:
+    def __init__(self, device=0):
+        self._ref = None
+        self._obs = ObstacleTables()
+        self._run = None
+        self._inp = None
+        self._range = (0, 0)
+        self._N = None
+
+    def close(self):
+        pass
+
+    def set_profiling(self, enable):
+        pass
+
+    def set_reference(self, ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit=20.0):
+        self._ref = (ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit)
+
+    def set_coordinate_system(self, co):
+        self.set_reference(co.ref_pos, co.ref_theta, co.ref_curv, co.ref_curv_d, co.reference,
+                           getattr(co, "proj_domain_d_limit", 20.0))
+
+    def set_obstacles(self, tables=None):
+        self._obs = tables if tables is not None else ObstacleTables()
+
+    def _tables(self):
+        return oracle.OracleTables(*self._ref, obstacles=self._obs)
+
+    def plan(self, inp, cand_begin=0, cand_end=-1, want_best_states=True):
+        end = inp.n_candidates if cand_end < 0 else cand_end
+        self._run = oracle.plan(inp, self._tables(), cand_begin, end, want_states=True)
+        self._inp, self._range, self._N = inp, (cand_begin, end), inp.params.N
+        return self._run.out
+
+    def plan_coeffs(self, params, cost, lon_coeffs, lat_coeffs, lon_T, traj_len, want_best_states=True):
+        self._run = oracle.plan_coeffs(params, cost, self._tables(), lon_coeffs, lat_coeffs, traj_len)
+        self._range, self._N = (0, len(traj_len)), params.N
+        return self._run.out
+
+    def fetch_status(self, first=0, count=None):
+        count = len(self._run.status) - first if count is None else count
+        return self._run.status[first:first + count].copy(), self._run.cost[first:first + count].copy()
+
+    def fetch_states(self, first=0, count=None):
+        count = len(self._run.status) - first if count is None else count
+        return self._run.states[first:first + count].copy()
+
+    def eval_one(self, index):
+        i = index - self._range[0]
+        return self._run.states[i].copy(), int(self._run.status[i]), float(self._run.cost[i])
+
+    def count_collisions_before(self, cost, index):
+        return oracle.count_collisions_before(self._run.status, self._run.cost, self._range[0], cost, index)
+
+    def select(self, costs, want_best_states=True):
+        run = self._run
+        lab = run.status & 3
+        cost = np.where((lab == 1) | (lab == 3), np.asarray(costs, dtype=float), run.cost)
+        run.cost = cost
+        ok = np.flatnonzero((lab == 1) & ~np.isnan(cost))
+        out = run.out
+        if len(ok):
+            k = ok[np.lexsort((ok, cost[ok]))[0]]
+            out.best_index, out.best_cost = int(self._range[0] + k), float(cost[k])
+            out.best_states = run.states[k].copy()
+        else:
+            out.best_index, out.best_cost, out.best_states = -1, float("nan"), None
+        out.n_collision_before_best = self.count_collisions_before(out.best_cost, out.best_index)
+        return out

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Extract the *data* of the reference's example scenarios (CommonRoad XML under
+/root/reference/example_scenarios) that BASELINE.json's configs are quoted on into small .npz
+fixtures: route centre line, initial state, static / dynamic obstacle boxes per time step.
+
+Runs ONLY in the build container.  The XML parser of commonroad-io is not installed (and out of
+scope), so the few fields needed are read with ElementTree.  The route
+(sequence of lanelets) is fixed by hand here because commonroad-route-planner is not installed.
+"""
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+SRC = "/root/reference/example_scenarios"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+ROUTES = {
+    # scenario file -> lanelet ids along the route
+    "ZAM_Tjunction-1_42_T-1": ["50195", "50209", "50203"],   # left turn at the junction
+    "DEU_Test-1_1_T-1": ["1", "3"],
+    "ZAM_Over-1_1": ["1000"],
+}
+
+
+def pts(node):
+    return np.array([(float(p.find("x").text), float(p.find("y").text)) for p in node.findall("point")])
+
+
+def first_float(node, tag):
+    el = node.find(tag)
+    if el is None:
+        return 0.0
+    ex = el.find("exact")
+    return float(ex.text) if ex is not None else float(el[0].text)
+
+
+def state(node):
+    pos = node.find("position").find("point")
+    return (float(pos.find("x").text), float(pos.find("y").text), first_float(node, "orientation"),
+            int(first_float(node, "time")), first_float(node, "velocity"))
+
+
+def main():
+    for name, route in ROUTES.items():
+        root = ET.parse(os.path.join(SRC, name + ".xml")).getroot()
+        lanelets = {ll.attrib["id"]: ll for ll in root.findall("lanelet")}
+        centre = []
+        for lid in route:
+            ll = lanelets[lid]
+            left, right = pts(ll.find("leftBound")), pts(ll.find("rightBound"))
+            c = 0.5 * (left + right)
+            centre.append(c if not centre else c[1:])
+        centre = np.concatenate(centre, axis=0)
+        left_b = np.concatenate([pts(lanelets[l].find("leftBound")) for l in route])
+        right_b = np.concatenate([pts(lanelets[l].find("rightBound")) for l in route])
+        dyn_nodes = root.findall("dynamicObstacle")
+        n_steps = 0
+        for ob in dyn_nodes:
+            tr = ob.find("trajectory")
+            n_steps = max(n_steps, 1 + (len(tr.findall("state")) if tr is not None else 0))
+        dyn = np.full((len(dyn_nodes), n_steps, 5), np.nan)
+        for j, ob in enumerate(dyn_nodes):
+            rect = ob.find("shape").find("rectangle")
+            hl, hw = 0.5 * float(rect.find("length").text), 0.5 * float(rect.find("width").text)
+            sts = [state(ob.find("initialState"))] + [state(s) for s in ob.find("trajectory").findall("state")]
+            for (x, y, th, t, _v) in sts:
+                if 0 <= t < n_steps:
+                    dyn[j, t] = (x, y, th, hl, hw)
+        sobb = []
+        static_nodes = root.findall("staticObstacle") + [o for o in root.findall("obstacle")
+                                                         if o.find("role") is not None and o.find("role").text == "static"]
+        for ob in static_nodes:
+            rect = ob.find("shape").find("rectangle")
+            x, y, th, _t, _v = state(ob.find("initialState"))
+            sobb.append((x, y, th, 0.5 * float(rect.find("length").text), 0.5 * float(rect.find("width").text)))
+        ini = root.find("planningProblem").find("initialState")
+        x, y, th, t0, v = state(ini)
+        out = os.path.join(HERE, "scenario_" + name + ".npz")
+        np.savez_compressed(out, centre=centre, left_bound=left_b, right_bound=right_b, dyn_obb=dyn, dyn_t0=0,
+                            static_obb=np.array(sobb).reshape(-1, 5), init=np.array([x, y, th, v]), init_time_step=t0,
+                            dt=float(root.attrib["timeStepSize"]))
+        print(name, "centre", centre.shape, "dyn", dyn.shape, "static", len(sobb), "init", (x, y, th, v),
+              f"{os.path.getsize(out) / 1024:.0f}KB")
+
+
+if __name__ == "__main__":
+    main()
