@@ -11,13 +11,17 @@
 #include <stdint.h>
 
 #include "../../include/rp_amd.h"
+#include "rp_math.h"
 
 #define RP_EPS 1e-5  // _EPS, commonroad_rp/reactive_planner.py:49
 #define RP_PI 3.14159265358979323846
 #define RP_TWO_PI 6.28318530717958647692
 
 // ------------------------------------------------------------------------------------------------
-// group-level cross-lane helpers (all 64 lanes of the wave must execute them)
+// group-level cross-lane helpers (all 64 lanes of the wave must execute them).
+// A group is G = 32 or 64 consecutive lanes = 2 or 4 DPP rows of 16.  Neighbour moves, sums and
+// prefix sums use DPP (plain VALU, no LDS round trip); only broadcasts from a run-time lane use
+// ds_bpermute (__shfl).
 // ------------------------------------------------------------------------------------------------
 template <int G>
 __device__ __forceinline__ uint64_t group_ballot(bool p, int gbase) {
@@ -29,21 +33,45 @@ __device__ __forceinline__ uint64_t group_ballot(bool p, int gbase) {
 template <int G>
 __device__ __forceinline__ double group_bcast(double v, int src) { return __shfl(v, src, G); }
 
+enum : int {
+    DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118,
+    DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128,
+    DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143
+};
+
+// lanes whose source is outside the row / masked off receive 0.0
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// value of the previous lane of the wave (lane 0: 0.0); callers patch the first lane of a group
+__device__ __forceinline__ double lane_prev(double v) { return dpp_f64<DPP_WAVE_SHR1, 0xf>(v); }
+
+// sum over the group, valid in the LAST lane of the group (gl == G - 1)
 template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+__device__ __forceinline__ double group_sum_last(double v) {
+    v += dpp_f64<DPP_ROW_ROR8, 0xf>(v);
+    v += dpp_f64<DPP_ROW_ROR4, 0xf>(v);
+    v += dpp_f64<DPP_ROW_ROR2, 0xf>(v);
+    v += dpp_f64<DPP_ROW_ROR1, 0xf>(v);          // every lane: sum of its row
+    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);       // rows 1, 3 += row 0, 2
+    if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // rows 2, 3 += lane 31 (rows 0 + 1)
     return v;
 }
 
-// inclusive prefix sum over the lanes of a group (Hillis-Steele)
+// inclusive prefix sum over the lanes of a group
 template <int G>
-__device__ __forceinline__ double group_scan(double v, int gl) {
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1) {
-        double u = __shfl_up(v, o, G);
-        if (gl >= o) v += u;
-    }
+__device__ __forceinline__ double group_scan(double v) {
+    v += dpp_f64<DPP_ROW_SHR1, 0xf>(v);
+    v += dpp_f64<DPP_ROW_SHR2, 0xf>(v);
+    v += dpp_f64<DPP_ROW_SHR4, 0xf>(v);
+    v += dpp_f64<DPP_ROW_SHR8, 0xf>(v);          // inclusive scan inside each row of 16
+    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);       // rows 1, 3 += total of row 0, 2
+    if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // rows 2, 3 += total of rows 0 + 1
     return v;
 }
 
@@ -89,10 +117,12 @@ __device__ __forceinline__ Poly quartic_coeffs(double p0, double v0, double a0, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// reference-path tables.  Eight rows of n doubles, contiguous: pos, theta, curv, curv_d, x, y, tx, ty
-// (utils_coordinate_system.py:114-118 + the polyline and its vertex tangents).
+// reference-path tables.  Nine rows of n doubles, contiguous: pos, theta, curv, curv_d, x, y, tx, ty
+// (utils_coordinate_system.py:114-118 + the polyline and its vertex tangents) and invlen[k] =
+// 1 / (pos[k+1] - pos[k]) (last entry: the wrap-around pair 1 / (pos[0] - pos[n-1])), followed by
+// an int32 bucket table for the O(1) segment lookup.
 // ------------------------------------------------------------------------------------------------
-enum { TB_POS = 0, TB_THETA, TB_CURV, TB_CURV_D, TB_X, TB_Y, TB_TX, TB_TY, TB_ROWS };
+enum { TB_POS = 0, TB_THETA, TB_CURV, TB_CURV_D, TB_X, TB_Y, TB_TX, TB_TY, TB_INVLEN, TB_ROWS };
 
 // make_valid_orientation (commonroad-io, used by interpolate_angle, utils_coordinate_system.py:43)
 __device__ __forceinline__ double make_valid_orientation(double a) {
@@ -116,6 +146,23 @@ __device__ __forceinline__ int upper_bound(const double *pos, int n, int iters, 
         hi = left ? mid : hi;
     }
     return lo;
+}
+
+// Same result through a uniform bucket table: bucket[b] = first index with pos > pos[0] + b*h,
+// h <= the shortest segment, so at most one vertex lies inside a bucket; the two forward steps and
+// one backward step absorb the rounding of the bucket index.
+__device__ __forceinline__ int upper_bound_bucket(const double *pos, const int *bucket, int n, int nb, double inv_h,
+                                                  double pos_first, double pos_last, double s) {
+    int ub = (s < pos_first) ? 0 : n;          // NaN -> n, like np.argmax of an all-False mask minus the -1 later
+    if (s >= pos_first && s < pos_last) {
+        int b = (int)((s - pos_first) * inv_h);
+        b = b < nb ? b : nb - 1;
+        ub = bucket[b];
+        ub = (ub > 0 && pos[ub - 1] > s) ? ub - 1 : ub;
+        ub = (ub < n && !(pos[ub] > s)) ? ub + 1 : ub;
+        ub = (ub < n && !(pos[ub] > s)) ? ub + 1 : ub;
+    }
+    return ub;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -206,16 +253,16 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     int k = t - ob.dyn_t0;
     if (k >= 0 && k < ob.n_steps) {
         const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+#pragma unroll 4
         for (int j = 0; j < ob.n_dyn; ++j) {
             const double *o = ob.dyn + (size_t)j * ob.n_steps + k;
-            double cx = o[0];
-            if (cx == cx) {  // not NaN
-                double cy = o[plane], rr = ego_r + o[6 * plane];
-                double dx = cx - ego.cx, dy = cy - ego.cy;
-                if (dx * dx + dy * dy <= rr * rr * 1.000001) {
-                    Obb b = {cx, cy, o[2 * plane], o[3 * plane], o[4 * plane], o[5 * plane]};
-                    hit |= obb_obb(ego, b);
-                }
+            // all seven loads are independent and issue back to back; NaN centre = obstacle absent
+            const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane],
+                         hw = o[5 * plane], rr = ego_r + o[6 * plane];
+            const double dx = cx - ego.cx, dy = cy - ego.cy;
+            if (dx * dx + dy * dy <= rr * rr * 1.000001) {   // false for NaN
+                Obb b = {cx, cy, ux, uy, hl, hw};
+                hit |= obb_obb(ego, b);
             }
         }
     }

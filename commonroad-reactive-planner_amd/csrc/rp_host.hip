@@ -44,11 +44,13 @@ struct rp_ctx {
 
     // reference tables
     double *d_tables = nullptr;
-    int n_ref = 0, search_iters = 0;
+    int n_ref = 0, search_iters = 0, n_buckets = 0, table_words = 0;
+    double bucket_inv_h = 0.0;
     double proj_d_limit = 20.0;
     // obstacles
     double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr;
     ObsTables obs{};
+    ObsTables *d_obs = nullptr;   // device copy of the descriptor
 
     // per-call staging (pinned host + device mirror)
     char *h_stage = nullptr, *d_stage = nullptr;
@@ -64,6 +66,7 @@ struct rp_ctx {
     char *d_result = nullptr, *h_result = nullptr;
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
+    unsigned long long *d_debug = nullptr;   // diagnostic build only
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
@@ -131,13 +134,24 @@ int ensure_stage(rp_ctx *c, size_t need) {
     return RP_OK;
 }
 
+template <int G, bool MAT, bool CIN, bool COLL>
+void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
+    const size_t tbytes = (size_t)ka.table_words * sizeof(double);
+    const bool one = ka.N + 1 <= G;
+    if (tbytes <= kLdsTableLimit) {
+        if (one) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true, COLL, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
+        else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true, COLL, false>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
+    } else {
+        if (one) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false, COLL, true>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+        else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false, COLL, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+    }
+}
+
 template <int G, bool MAT, bool CIN>
 void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
-    const size_t tbytes = (size_t)TB_ROWS * (size_t)ka.n_ref * sizeof(double);
-    if (tbytes <= kLdsTableLimit)
-        hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
-    else
-        hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+    const bool coll = ka.has_obstacles && !(ka.flags & RP_FLAG_SKIP_COLLISION);
+    if (coll) launch_eval_tc<G, MAT, CIN, true>(c, ka, grid);
+    else launch_eval_tc<G, MAT, CIN, false>(c, ka, grid);
 }
 
 // G = 32 packs two candidates into one wavefront when the horizon fits (N + 1 <= 32).
@@ -185,8 +199,13 @@ void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs
         ka.desired_s = ka.has_s ? cost->desired_s : 0.0;
     }
     ka.tables = c->d_tables; ka.n_ref = c->n_ref; ka.search_iters = c->search_iters;
+    ka.n_buckets = c->n_buckets; ka.table_words = c->table_words; ka.bucket_inv_h = c->bucket_inv_h;
+    ka.c_yaw = 1e5 / p->dt;
+    ka.c_kdot = p->dt * p->v_delta_max / p->wheelbase;
     ka.proj_d_limit = c->proj_d_limit;
-    ka.obs = c->obs;
+    ka.obs = c->d_obs;
+    ka.debug = c->d_debug;
+    ka.has_obstacles = (c->obs.n_sobb + c->obs.n_tri + c->obs.n_circ > 0 || (c->obs.n_dyn > 0 && c->obs.n_steps > 0)) ? 1 : 0;
 }
 
 int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result *res) {
@@ -274,6 +293,15 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         if (best_states)
             std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
     }
+#ifdef RP_STAMPS
+    if (std::getenv("RP_AMD_PRINT_STAMPS")) {
+        unsigned long long st[32];
+        HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
+        for (int k = 1; k < 15; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        std::fprintf(stderr, "\n");
+    }
+#endif
     result->kernel_ms = 0.0;
     if (c->profiling && !skip_eval) {
         float ms = 0.f;
@@ -308,6 +336,12 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
+#ifdef RP_STAMPS
+    HIP_TRY(c, hipMalloc((void **)&c->d_debug, 32 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(c->d_debug, 0, 32 * sizeof(unsigned long long)));
+#endif
+    HIP_TRY(c, hipMemset(c->d_obs, 0, sizeof(ObsTables)));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_single, sizeof(int64_t), hipHostMallocDefault));
     return RP_OK;
 }
@@ -317,7 +351,7 @@ void rp_destroy(rp_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
-                   c->d_states, c->d_partials, c->d_result, c->d_single};
+                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -369,9 +403,31 @@ int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *
         double tn = std::sqrt(sx * sx + sy * sy);
         tx[i] = sx / tn; ty[i] = sy / tn;
     }
+    // reciprocal segment lengths; the last slot serves the wrap-around pair (k0 = n-1, k1 = 0)
+    double *inv = &t[(size_t)TB_INVLEN * n];
+    double hmin = ref_pos[1] - ref_pos[0];
+    for (int i = 0; i + 1 < n; ++i) {
+        inv[i] = 1.0 / (ref_pos[i + 1] - ref_pos[i]);
+        hmin = std::min(hmin, ref_pos[i + 1] - ref_pos[i]);
+    }
+    inv[n - 1] = 1.0 / (ref_pos[0] - ref_pos[n - 1]);
+    // uniform bucket table for the O(1) segment lookup (falls back to binary search if too fine)
+    const double span = ref_pos[n - 1] - ref_pos[0];
+    const double nbf = std::floor(span / hmin) + 1.0;
+    int nb = (nbf >= 1.0 && nbf <= 8192.0) ? (int)nbf : 0;
+    if (nb > 0) {
+        t.resize(t.size() + (size_t)(nb + 1) / 2, 0.0);
+        int32_t *bk = reinterpret_cast<int32_t *>(t.data() + (size_t)TB_ROWS * n);
+        for (int b = 0; b < nb; ++b)
+            bk[b] = (int32_t)(std::upper_bound(ref_pos, ref_pos + n, ref_pos[0] + b * hmin) - ref_pos);
+    }
+    if (t.size() & 1) t.push_back(0.0);   // staged with 16-byte loads
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     int rc = upload(c, c->d_tables, t);
     if (rc != RP_OK) return rc;
+    c->n_buckets = nb;
+    c->bucket_inv_h = 1.0 / hmin;
+    c->table_words = (int)t.size();
     c->n_ref = n;
     c->proj_d_limit = proj_domain_d_limit;
     int it = 1;
@@ -428,6 +484,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.sobb = c->d_sobb; c->obs.tri = c->d_tri; c->obs.circ = c->d_circ; c->obs.dyn = c->d_dyn;
     c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
+    HIP_TRY(c, hipMemcpy(c->d_obs, &c->obs, sizeof(ObsTables), hipMemcpyHostToDevice));
     c->have_last = false;
     return RP_OK;
 }

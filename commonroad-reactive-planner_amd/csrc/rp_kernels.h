@@ -8,6 +8,9 @@
 #include "rp_device.h"
 
 #define RP_BLOCK 256  // 4 wavefronts per workgroup
+#ifndef RP_WAVES_PER_SIMD
+#define RP_WAVES_PER_SIMD 4  // register budget of the evaluation kernel: 512 / 4 = 128 VGPRs
+#endif
 
 // Everything the evaluation kernel needs; passed by value (kernarg segment).
 struct KArgs {
@@ -18,6 +21,8 @@ struct KArgs {
     double x0_lon[3], x0_lat[3], x0_orientation;
     double wheelbase, wb_rear_axle, half_length, half_width, ego_radius;
     double a_max, v_switch, v_delta_max, kappa_max;
+    double c_yaw;   // 1e5 / dt
+    double c_kdot;  // dt * v_delta_max / wheelbase
     // cost
     int32_t cost_kind, has_speed, has_s, pad0_;
     double w_a, desired_speed, desired_d, desired_s;
@@ -35,15 +40,18 @@ struct KArgs {
     const int64_t *single_index;  // != nullptr: evaluate exactly this one (global) candidate -> slot 0
     // tables
     const double *tables;  // [TB_ROWS][n_ref]
-    int32_t n_ref, search_iters;
+    int32_t n_ref, search_iters, n_buckets, table_words;
+    double bucket_inv_h;
     double proj_d_limit;
-    ObsTables obs;
+    const ObsTables *obs;  // device copy of the obstacle table descriptor (loaded only by the collision block)
+    int32_t has_obstacles, pad2_;
     // outputs
     uint32_t *status;  // [count]
     double *cost;      // [count]
     double *states;    // [count][14][N+1] (MAT) or nullptr
     double *coeffs;    // [count][13] or nullptr (lon 6, lat 6, lat_T)
     struct BlockPartial *partials;  // [gridDim.x] or nullptr
+    unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
 };
 
 struct BlockPartial {
@@ -58,6 +66,24 @@ struct DevResult {
     // followed in the same allocation by best_states[14][N+1]
 };
 
+// In-kernel stamps (diagnostic build only; see cdna_hip_programming.md section 7).  Values go to a
+// buffer nothing else reads.
+#ifdef RP_STAMPS
+#ifndef RP_STAMP_BLOCK
+#define RP_STAMP_BLOCK 0
+#endif
+#define RP_STAMP(k)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == 0) a.debug[(k)] = t_;                   \
+    } while (0)
+#else
+#define RP_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t bi) {
     return bi < 0 || c < bc || (c == bc && i < bi);
 }
@@ -65,24 +91,74 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 // ------------------------------------------------------------------------------------------------
 // The fused kernel.  G lanes per candidate; MAT: write the 14 state rows; COEFFS_IN: polynomials
 // are given; LDS_TABLES: reference-path tables staged in LDS (else read through L1/L2).
+//
+// Arithmetic notes (all within the 1e-6 state tolerance, typically ~1e-13):
+//   * theta_cl = atan(d') on the moving branch, hence cos(theta_cl) = 1/sqrt(1 + d'^2) and
+//     tan(theta_cl) = d' without a second and third transcendental; only standstill lanes
+//     (reactive_planner.py:864-873) evaluate sin/cos, behind a wave-uniform branch.
+//   * divisions by quantities reused several times (s_dot, 1 - k_r d, segment length) become one
+//     Newton-refined reciprocal each; threshold tests are rearranged to multiplications.
 // ------------------------------------------------------------------------------------------------
-template <int G, bool MAT, bool COEFFS_IN, bool LDS_TABLES>
-__global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
+// raw per-candidate inputs, fetched one iteration ahead of their use (global-memory latency hidden
+// behind the table staging / the previous candidate)
+struct CandIn {
+    double v[12];   // grid mode: T, L sample, D sample;  COEFFS_IN: lon[6], lat[6]
+    int L;
+};
+
+template <bool COEFFS_IN>
+__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) {
+    CandIn ci;
+    if (COEFFS_IN) {
+        const double *pl = a.lon_coeffs + 6 * gidx, *pt = a.lat_coeffs + 6 * gidx;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ci.v[k] = pl[k]; ci.v[6 + k] = pt[k]; }
+        ci.L = a.traj_len_c[gidx];
+    } else {
+        const int64_t nLD = (int64_t)a.nL * a.nD;
+        const int iT = (int)(gidx / nLD);
+        const int rem = (int)(gidx - (int64_t)iT * nLD);
+        const int iL = rem / a.nD, iD = rem - iL * a.nD;
+        ci.v[0] = a.T[iT];
+        ci.v[1] = a.L[iL];
+        ci.v[2] = a.D[iD];
+        ci.L = a.traj_len[iT];
+    }
+    return ci;
+}
+
+// Per-group LDS scratch.  Values that are identical in all lanes of a group and live for the whole
+// candidate (polynomial coefficients, last valid state) are parked here and re-read (broadcast reads)
+// right where they are used, instead of occupying VGPRs across the step loop.
+//   poly[0..14]  longitudinal: c0..c5 | c1, 2c2, 3c3, 4c4, 5c5 | 2c2, 6c3, 12c4, 20c5
+//   poly[15..29] lateral, same layout
+//   last[0..15]  x y theta v a kappa kappa_dot s d theta_cl s_dot s_ddot d_dot d_ddot cos(theta) sin(theta)
+struct GroupScratch {
+    double poly[30];
+    double last[16];
+};
+
+__device__ __forceinline__ void park_poly(double *o, const Poly &c) {
+    o[0] = c.c0; o[1] = c.c1; o[2] = c.c2; o[3] = c.c3; o[4] = c.c4; o[5] = c.c5;
+    o[6] = c.c1; o[7] = 2.0 * c.c2; o[8] = 3.0 * c.c3; o[9] = 4.0 * c.c4; o[10] = 5.0 * c.c5;
+    o[11] = 2.0 * c.c2; o[12] = 6.0 * c.c3; o[13] = 12.0 * c.c4; o[14] = 20.0 * c.c5;
+}
+// PolynomialTrajectory.calc_position / calc_velocity / calc_acceleration (polynomial_trajectory.py:240-271), Horner
+__device__ __forceinline__ double lds_pos(const double *o, double t) {
+    return ((((o[5] * t + o[4]) * t + o[3]) * t + o[2]) * t + o[1]) * t + o[0];
+}
+__device__ __forceinline__ double lds_vel(const double *o, double t) {
+    return (((o[10] * t + o[9]) * t + o[8]) * t + o[7]) * t + o[6];
+}
+__device__ __forceinline__ double lds_acc(const double *o, double t) { return ((o[14] * t + o[13]) * t + o[12]) * t + o[11]; }
+
+// ONE_CHUNK: N + 1 <= G, the step loop disappears together with its carried state.
+template <int G, bool MAT, bool COEFFS_IN, bool LDS_TABLES, bool COLL, bool ONE_CHUNK>
+__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
+    RP_STAMP(0);
     const int n_ref = a.n_ref;
-    const double *tab;
-    if (LDS_TABLES) {
-        for (int k = tid; k < TB_ROWS * n_ref; k += RP_BLOCK) lds[k] = a.tables[k];
-        __syncthreads();
-        tab = lds;
-    } else {
-        tab = a.tables;
-    }
-    const double *t_pos = tab + TB_POS * n_ref, *t_theta = tab + TB_THETA * n_ref, *t_curv = tab + TB_CURV * n_ref,
-                 *t_curv_d = tab + TB_CURV_D * n_ref, *t_x = tab + TB_X * n_ref, *t_y = tab + TB_Y * n_ref,
-                 *t_tx = tab + TB_TX * n_ref, *t_ty = tab + TB_TY * n_ref;
-    const double pos_first = t_pos[0], pos_last = t_pos[n_ref - 1];
 
     const int lane = tid & 63;
     const int gl = lane & (G - 1);        // lane inside the group = time step inside the chunk
@@ -91,28 +167,75 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
     constexpr int GPW = 64 / G;           // groups per wave
     const int wave_in_block = tid >> 6;
     const int group_in_wave = gbase / G;
-
-    const int N = a.N, n = N + 1;
-    const int nchunks = (n + G - 1) / G;
-    const double dt = a.dt;
-    const bool draw = (a.flags & RP_FLAG_DRAW_ALL) != 0;
-    const bool low = a.low_vel_mode != 0;
-    const bool check_coll = (a.flags & RP_FLAG_SKIP_COLLISION) == 0 &&
-                            (a.obs.n_sobb + a.obs.n_tri + a.obs.n_circ > 0 || (a.obs.n_dyn > 0 && a.obs.n_steps > 0));
-    const uint32_t cm = a.constraint_mask;
-    const int mid = n / 2;  // int(len(v) / 2), cost_function.py:59
-
-    // running per-group selection state (identical in all lanes of a group)
-    double best_cost = 0.0;
-    int64_t best_index = -1;
-    int cnt_feasible = 0, cnt_collision = 0;
-    int cnt_reason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int grp = tid / G;              // group inside the block
 
     if (a.single_index && *a.single_index < 0) return;   // no winner to re-evaluate (uniform)
-
     const int64_t total_groups = (int64_t)gridDim.x * GPB;
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave
     const int64_t count = a.single_index ? 1 : a.count;
+
+    // first candidate's inputs: issued before the table staging so both latencies overlap
+    CandIn cin;
+    {
+        const int64_t slot0 = wave_first + group_in_wave;
+        const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
+        cin = fetch_candidate<COEFFS_IN>(a, g0);
+    }
+
+    __shared__ GroupScratch sh_grp[GPB];
+    __shared__ double sh_best_cost[GPB];
+    __shared__ long long sh_best_idx[GPB];
+    __shared__ int sh_cnt[10];
+    if (tid < 10) sh_cnt[tid] = 0;
+    if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
+
+    const double *tab;
+    if (LDS_TABLES) {   // 16-byte loads, four in flight per lane
+        const double2 *src = reinterpret_cast<const double2 *>(a.tables);
+        double2 *dst = reinterpret_cast<double2 *>(lds);
+        const int nw2 = a.table_words >> 1;   // table_words is even
+#pragma unroll 4
+        for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+        tab = lds;
+    } else {
+        tab = a.tables;
+    }
+    __syncthreads();
+    RP_STAMP(1);   // tables staged
+    const double *t_pos = tab + TB_POS * n_ref, *t_theta = tab + TB_THETA * n_ref, *t_curv = tab + TB_CURV * n_ref,
+                 *t_curv_d = tab + TB_CURV_D * n_ref, *t_x = tab + TB_X * n_ref, *t_y = tab + TB_Y * n_ref,
+                 *t_tx = tab + TB_TX * n_ref, *t_ty = tab + TB_TY * n_ref, *t_inv = tab + TB_INVLEN * n_ref;
+    const int *t_bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
+    const double pos_first = t_pos[0], pos_last = t_pos[n_ref - 1];
+
+    const int N = a.N, n = N + 1;
+    const int nchunks = ONE_CHUNK ? 1 : (n + G - 1) / G;
+    const double dt = a.dt;
+    const bool draw = (a.flags & RP_FLAG_DRAW_ALL) != 0;
+    const bool low = a.low_vel_mode != 0;
+    const uint32_t cm = a.constraint_mask;
+    const int mid = n / 2;  // int(len(v) / 2), cost_function.py:59
+    double *const gs_poly = sh_grp[grp].poly;
+    double *const gs_last = sh_grp[grp].last;
+
+    // this lane's share of the cost of one (possibly extended) state, cost_function.py:51-71 / 82-92:
+    // every lane adds its own step, the lanes holding steps N and N/2 also add the terminal terms
+    auto cost_terms = [&](int i, double acc, double v, double s, double d, double th_cl) -> double {
+        double e, cst;
+        e = a.w_a * acc; cst = e * e;
+        e = 0.25 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+        e = 0.25 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+        if (a.has_speed) { e = 5.0 * (v - a.desired_speed); cst = __builtin_fma(e, e, cst); }
+        if (a.has_s) { e = 0.25 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        if (i == N) {
+            e = 20.0 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+            e = 5.0 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+            if (a.has_speed) { e = v - a.desired_speed; cst += 50.0 * (e * e); }
+            if (a.has_s) { e = 20.0 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        }
+        if (i == mid && a.has_speed) { e = v - a.desired_speed; cst += 100.0 * (e * e); }
+        return cst;
+    };
 
     for (int64_t w0 = wave_first; w0 < count; w0 += total_groups) {   // wave-uniform trip count
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
@@ -120,49 +243,50 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
         const int64_t gidx = a.single_index ? *a.single_index : a.cand_begin + (valid ? slot : 0);
 
         // ---- sampling: FixedIntervalSampling.generate_trajectories_at_level, sampling.py:218-241 ----
-        Poly lon, lat;
-        double lat_T;
-        int L;
-        if (COEFFS_IN) {
-            const double *pl = a.lon_coeffs + 6 * gidx, *pt = a.lat_coeffs + 6 * gidx;
-            lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
-            lat = {pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]};
-            lat_T = 0.0;
-            L = a.traj_len_c[gidx];
-        } else {
-            const int64_t nLD = (int64_t)a.nL * a.nD;
-            const int iT = (int)(gidx / nLD);
-            const int rem = (int)(gidx - (int64_t)iT * nLD);
-            const int iL = rem / a.nD, iD = rem - iL * a.nD;
-            const double T = a.T[iT];
-            L = a.traj_len[iT];
-            if (a.lon_mode == RP_LON_STOPPING)
-                lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);  // sampling.py:259-263
-            else
-                lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);             // sampling.py:254-258
-            lat_T = T;
-            if (low) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
-                double sg = lon.pos(T) - a.x0_lon[0];
-                lat_T = sg <= 0.0 ? T : sg;
+        int L = cin.L;
+        {
+            Poly lon, lat;
+            double lat_T;
+            if (COEFFS_IN) {
+                lon = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
+                lat = {cin.v[6], cin.v[7], cin.v[8], cin.v[9], cin.v[10], cin.v[11]};
+                lat_T = 0.0;
+            } else {
+                const double T = cin.v[0];
+                if (a.lon_mode == RP_LON_STOPPING)
+                    lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], cin.v[1], 0.0, 0.0, T);  // sampling.py:259-263
+                else
+                    lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, cin.v[1]);             // sampling.py:254-258
+                lat_T = T;
+                if (low) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
+                    double sg = lon.pos(T) - a.x0_lon[0];
+                    lat_T = sg <= 0.0 ? T : sg;
+                }
+                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[2], 0.0, 0.0, lat_T);  // sampling.py:227
             }
-            lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], a.D[iD], 0.0, 0.0, lat_T);  // sampling.py:227
+            if (gl == 0) {   // park the coefficients (same-wave LDS ordering makes them visible to the group)
+                park_poly(gs_poly, lon);
+                park_poly(gs_poly + 15, lat);
+                if (a.coeffs && valid) {
+                    double *o = a.coeffs + 13 * slot;
+                    o[0] = lon.c0; o[1] = lon.c1; o[2] = lon.c2; o[3] = lon.c3; o[4] = lon.c4; o[5] = lon.c5;
+                    o[6] = lat.c0; o[7] = lat.c1; o[8] = lat.c2; o[9] = lat.c3; o[10] = lat.c4; o[11] = lat.c5;
+                    o[12] = lat_T;
+                }
+            }
         }
         L = L > n ? n : (L < 1 ? 1 : L);
-        if (a.coeffs && valid && gl == 0) {
-            double *o = a.coeffs + 13 * slot;
-            o[0] = lon.c0; o[1] = lon.c1; o[2] = lon.c2; o[3] = lon.c3; o[4] = lon.c4; o[5] = lon.c5;
-            o[6] = lat.c0; o[7] = lat.c1; o[8] = lat.c2; o[9] = lat.c3; o[10] = lat.c4; o[11] = lat.c5;
-            o[12] = lat_T;
-        }
+        RP_STAMP(2);   // polynomials ready
 
         // ---- pre-filter, reactive_planner.py:796-805 (label stays None) ----
         uint32_t pre_reason = RP_REASON_NONE;
         if (!draw) {
             bool bad_a = false, bad_v = false;
+#pragma nounroll
             for (int c = 0; c < nchunks; ++c) {
                 const int i = c * G + gl;
                 const double t = (double)i * dt;
-                double sd = lon.vel(t), sdd = lon.acc(t);
+                double sd = lds_vel(gs_poly, t), sdd = lds_acc(gs_poly, t);
                 if (fabs(sd) < RP_EPS) sd = 0.0;
                 bad_a |= (i < L) && (fabs(sdd) > a.a_max);
                 bad_v |= (i < L) && (sd < -RP_EPS);
@@ -175,17 +299,17 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
         int fail_step = -1, ood_step = -1;
         uint32_t fail_reason = RP_REASON_NONE;
         bool collide = false;
-        double acc_a = 0.0, acc_v = 0.0, acc_s = 0.0, acc_d = 0.0, acc_th = 0.0;
-        double v_end = 0.0, v_mid = 0.0, s_end = 0.0, d_end = 0.0, th_end = 0.0;
+        double cost_acc = 0.0;
 
         bool alive = valid && pre_reason == RP_REASON_NONE;
         if (__ballot(alive) != 0) {   // wave-uniform
             double theta_carry = a.x0_orientation;  // theta_gl[base-1]; at base 0 the i == 0 rule of :866
             double kappa_carry = 0.0;
             double cumx = 0.0, cumy = 0.0;
-            double x_l = 0, y_l = 0, th_l = 0, v_l = 0, a_l = 0, ka_l = 0, kd_l = 0, s_l = 0, d_l = 0, thc_l = 0, sd_l = 0,
-                   sdd_l = 0, dd_l = 0, ddd_l = 0, cth_l = 1, sth_l = 0;
+            const bool store_ok = MAT && valid && pre_reason == RP_REASON_NONE;
+            double *const orow = MAT ? a.states + ((size_t)slot * RP_N_ARRAYS) * (size_t)n : nullptr;
 
+#pragma nounroll
             for (int c = 0; c < nchunks; ++c) {   // wave-uniform
                 const int base = c * G;
                 const int i = base + gl;
@@ -194,181 +318,138 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
 
                 // -- polynomial evaluation, reactive_planner.py:733-777
                 const double t = (double)i * dt;
-                double s = lon.pos(t), sd = lon.vel(t), sdd = lon.acc(t);
-                const double tau = low ? s - lon.c0 : t;   // s[0] == c0 exactly (:762)
-                double d = lat.pos(tau), dd = lat.vel(tau), ddd = lat.acc(tau);
+                double s = lds_pos(gs_poly, t), sd = lds_vel(gs_poly, t), sdd = lds_acc(gs_poly, t);
+                const double tau = low ? s - gs_poly[0] : t;   // s[0] == c0 exactly (:762)
+                double d = lds_pos(gs_poly + 15, tau), dd = lds_vel(gs_poly + 15, tau), ddd = lds_acc(gs_poly + 15, tau);
                 if (fabs(sd) < RP_EPS) sd = 0.0;
                 if (fabs(dd) < RP_EPS) dd = 0.0;
+                if (store_ok && act) {   // curvilinear rows of valid steps are final here
+                    double *o = orow + i;
+                    o[(size_t)RP_S * n] = s;
+                    o[(size_t)RP_S_DOT * n] = sd;
+                    o[(size_t)RP_S_DDOT * n] = sdd;
+                    o[(size_t)RP_D * n] = d;
+                    o[(size_t)RP_D_DOT * n] = dd;
+                    o[(size_t)RP_D_DDOT * n] = ddd;
+                }
+                RP_STAMP(3);   // polynomial evaluation
 
                 // -- d', d'' (:810-832)
                 const bool moving = sd > 0.001;
                 double dp, dpp;
                 if (!low) {
-                    dp = moving ? dd / sd : 0.0;
+                    const double inv_sd = moving ? rp_rcp(sd) : 0.0;
+                    dp = dd * inv_sd;
                     const double ddot = ddd - dp * sdd;
-                    dpp = moving ? ddot / (sd * sd) : 0.0;
+                    dpp = ddot * inv_sd * inv_sd;
                 } else {
                     dp = dd;
                     dpp = ddd;
                 }
 
                 // -- segment lookup + interpolation factors (:835-839); Python's negative index wraps
-                const int ub = upper_bound(t_pos, n_ref, a.search_iters, s);
+                const int ub = a.n_buckets > 0
+                                   ? upper_bound_bucket(t_pos, t_bucket, n_ref, a.n_buckets, a.bucket_inv_h, pos_first, pos_last, s)
+                                   : upper_bound(t_pos, n_ref, a.search_iters, s);
                 const int s_idx = (ub == n_ref) ? -1 : ub - 1;
                 const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
-                const double p0 = t_pos[k0], p1 = t_pos[k1];
-                const double lam = (s - p0) / (p1 - p0);
+                const double p0 = t_pos[k0], inv_len = t_inv[k0];
+                const double ds = s - p0;
+                const double lam = ds * inv_len;
                 const double th0 = t_theta[k0];
-                const double th_ref = make_valid_orientation((t_theta[k1] - th0) * (s - p0) / (p1 - p0) + th0);  // interpolate_angle
+                const double th_ref = make_valid_orientation((t_theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
+                const double c0 = t_curv[k0], cd0 = t_curv_d[k0];
+                const double k_r = (t_curv[k1] - c0) * lam + c0;              // :876-880
+                const double k_r_d = (t_curv_d[k1] - cd0) * lam + cd0;
+                RP_STAMP(4);   // lookup + interpolation
 
                 // -- orientations (:842-873) incl. the standstill carry of :866
                 const bool use_atan = moving || low;
-                const double th_cl_m = atan(dp);          // np.arctan2(dp, 1.0)
-                const double th_gl_m = th_cl_m + th_ref;
-                const uint64_t mv = group_ballot<G>(use_atan && act, gbase);
-                const uint64_t below = mv & ((1ull << gl) - 1ull);
-                const int src = below ? 63 - __clzll(below) : 0;
-                const double th_from = group_bcast<G>(th_gl_m, src);
-                double th_gl = use_atan ? th_gl_m : (below ? th_from : theta_carry);
-                double th_cl = use_atan ? th_cl_m : th_gl - th_ref;
+                double th_cl = rp_atan(dp);          // np.arctan2(dp, 1.0)
+                double th_gl = th_cl + th_ref;
+                // cos / sec / tan of theta_cl: algebraic on the atan branch
+                const double w2 = __builtin_fma(dp, dp, 1.0);
+                double cosT = rp_rsqrt(w2);
+                double secT = w2 * cosT;
+                double tanT = dp;
+                if (__any(act && !use_atan)) {   // standstill lanes: keep the orientation of the last moving step
+                    const uint64_t mv = group_ballot<G>(use_atan && act, gbase);
+                    const uint64_t below = mv & ((1ull << gl) - 1ull);
+                    const int src = below ? 63 - __clzll(below) : 0;
+                    const double th_from = group_bcast<G>(th_gl, src);
+                    if (!use_atan) {
+                        th_gl = below ? th_from : theta_carry;
+                        th_cl = th_gl - th_ref;
+                    }
+                    double sn, cs;
+                    rp_sincos(th_cl, &sn, &cs);
+                    const double sc = rp_rcp(cs);
+                    cosT = use_atan ? cosT : cs;
+                    secT = use_atan ? secT : sc;
+                    tanT = use_atan ? tanT : sn * sc;
+                }
+                RP_STAMP(5);   // atan + carry
 
-                // -- curvature, velocity, acceleration (:876-896)
-                const double c0 = t_curv[k0], cd0 = t_curv_d[k0];
-                const double k_r = (t_curv[k1] - c0) * lam + c0;
-                const double k_r_d = (t_curv_d[k1] - cd0) * lam + cd0;
+                // -- curvature, velocity, acceleration (:883-896)
                 const double oneKrD = 1.0 - k_r * d;
-                const double cosT = cos(th_cl), tanT = tan(th_cl);
-                const double q = cosT / oneKrD;
-                double kappa = (dpp + (k_r * dp + k_r_d * d) * tanT) * cosT * (q * q) + q * k_r;
-                double v = sd * (oneKrD / cosT);
-                double acc = sdd * oneKrD / cosT +
-                             ((sd * sd) / cosT) * (oneKrD * tanT * (kappa * oneKrD / cosT - k_r) - (k_r_d * d + k_r * dp));
+                const double q = cosT * rp_rcp(oneKrD);
+                const double kterm = k_r_d * d + k_r * dp;
+                double kappa = (dpp + kterm * tanT) * cosT * (q * q) + q * k_r;
+                const double f = oneKrD * secT;
+                double v = sd * f;
+                double acc = sdd * f + (sd * sd * secT) * (oneKrD * tanT * (kappa * f - k_r) - kterm);
 
-                // -- previous-step values for the finite differences
-                double th_prev = __shfl_up(th_gl, 1, G), ka_prev = __shfl_up(kappa, 1, G);
+                // -- previous-step values for the finite differences (DPP lane shift)
+                double th_prev = lane_prev(th_gl), ka_prev = lane_prev(kappa);
                 if (gl == 0) { th_prev = theta_carry; ka_prev = kappa_carry; }
+                const double dth = i > 0 ? th_gl - th_prev : 0.0;
+                double kdot = i > 0 ? kappa - ka_prev : 0.0;   // np.append([0], np.diff(kappa_gl)), :923
+                RP_STAMP(6);   // kappa, v, a + prev-step shifts
 
                 // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
                 uint32_t reason = RP_REASON_NONE;
                 if (act) {
-                    const double yaw = i > 0 ? (th_gl - th_prev) / dt : 0.0;
-                    const double kdot_t = i > 0 ? (kappa - ka_prev) / dt : 0.0;
-                    const double sa = atan(a.wheelbase * kappa);
-                    const double cs = cos(sa);
-                    const double kdot_max = a.v_delta_max / (a.wheelbase * (cs * cs));
-                    const double amax = v > a.v_switch ? a.a_max * a.v_switch / v : a.a_max;
+                    const double wk = a.wheelbase * kappa;
+                    // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
+                    const bool bad_yaw = fabs(rint(dth * a.c_yaw)) > a.kappa_max * v * 1e5;
+                    // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
+                    const bool bad_kd = fabs(kdot) > a.c_kdot * __builtin_fma(wk, wk, 1.0);
+                    // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
+                    const bool ok_acc = (-a.a_max <= acc) && (v > a.v_switch ? acc * v <= a.a_max * a.v_switch : acc <= a.a_max);
                     if ((cm & RP_CHECK_VELOCITY) && v < -RP_EPS) reason = RP_REASON_VELOCITY;
                     else if ((cm & RP_CHECK_KAPPA) && fabs(kappa) > a.kappa_max) reason = RP_REASON_KAPPA;
-                    else if ((cm & RP_CHECK_YAW_RATE) && fabs(rint(yaw * 1e5) / 1e5) > a.kappa_max * v) reason = RP_REASON_YAW_RATE;
-                    else if ((cm & RP_CHECK_KAPPA_DOT) && fabs(kdot_t) > kdot_max) reason = RP_REASON_KAPPA_DOT;
-                    else if ((cm & RP_CHECK_ACCELERATION) && !(-a.a_max <= acc && acc <= amax)) reason = RP_REASON_ACCELERATION;
+                    else if ((cm & RP_CHECK_YAW_RATE) && bad_yaw) reason = RP_REASON_YAW_RATE;
+                    else if ((cm & RP_CHECK_KAPPA_DOT) && bad_kd) reason = RP_REASON_KAPPA_DOT;
+                    else if ((cm & RP_CHECK_ACCELERATION) && !ok_acc) reason = RP_REASON_ACCELERATION;
                 }
-                const uint64_t fm = group_ballot<G>(reason != RP_REASON_NONE, gbase);
-                const int fl = fm ? __ffsll((unsigned long long)fm) - 1 : 0;
-                const uint32_t r_first = (uint32_t)__shfl((int)reason, fl, G);
-                if (fm && fail_step < 0) { fail_step = base + fl; fail_reason = r_first; }
-                if (!draw && fail_step >= 0) alive = false;
-                if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wave is decided
+                if (__any(reason != RP_REASON_NONE)) {   // wave-uniform
+                    const uint64_t fm = group_ballot<G>(reason != RP_REASON_NONE, gbase);
+                    const int fl = fm ? __ffsll((unsigned long long)fm) - 1 : 0;
+                    const uint32_t r_first = (uint32_t)__shfl((int)reason, fl, G);
+                    if (fm && fail_step < 0) { fail_step = base + fl; fail_reason = r_first; }
+                    if (!draw && fail_step >= 0) alive = false;
+                    if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wave is decided
+                }
+                RP_STAMP(7);   // constraints + first-failure vote
 
                 // -- (s, d) -> (x, y), reactive_planner.py:908-917
                 const bool in_dom = s >= pos_first && s <= pos_last && fabs(d) <= a.proj_d_limit;
                 int k = ub - 1;
                 k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
-                const double q0 = t_pos[k];
-                const double lam2 = (s - q0) / (t_pos[k + 1] - q0);
+                const double lam2 = (s - t_pos[k]) * t_inv[k];
                 const double bx = t_x[k], by = t_y[k], ux0 = t_tx[k], uy0 = t_ty[k];
                 const double px = bx + lam2 * (t_x[k + 1] - bx), py = by + lam2 * (t_y[k + 1] - by);
                 const double ax = ux0 + lam2 * (t_tx[k + 1] - ux0), ay = uy0 + lam2 * (t_ty[k + 1] - uy0);
-                const double tn = sqrt(ax * ax + ay * ay);
-                double x = px - d * (ay / tn), y = py + d * (ax / tn);
-                const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
-                if (om && ood_step < 0) ood_step = base + __ffsll((unsigned long long)om) - 1;
-                if (ood_step >= 0 && i >= ood_step) { x = 0.0; y = 0.0; }   // x, y stay np.zeros past the break
-
-                double kdot = i > 0 ? kappa - ka_prev : 0.0;   // np.append([0], np.diff(kappa_gl)), :923
-
-                // -- last valid state -> horizon extension (trajectories.py:168-197, 302-332)
-                const int ll = L - 1 - base;
-                {   // unconditional shuffles (all lanes), values only kept when this chunk holds step L-1
-                    const int sl = (ll >= 0 && ll < G) ? ll : 0;
-                    const bool take = (ll >= 0 && ll < G);
-                    double t0;
-                    t0 = group_bcast<G>(x, sl); x_l = take ? t0 : x_l;
-                    t0 = group_bcast<G>(y, sl); y_l = take ? t0 : y_l;
-                    t0 = group_bcast<G>(th_gl, sl); th_l = take ? t0 : th_l;
-                    t0 = group_bcast<G>(v, sl); v_l = take ? t0 : v_l;
-                    t0 = group_bcast<G>(acc, sl); a_l = take ? t0 : a_l;
-                    t0 = group_bcast<G>(kappa, sl); ka_l = take ? t0 : ka_l;
-                    t0 = group_bcast<G>(kdot, sl); kd_l = take ? t0 : kd_l;
-                    t0 = group_bcast<G>(s, sl); s_l = take ? t0 : s_l;
-                    t0 = group_bcast<G>(d, sl); d_l = take ? t0 : d_l;
-                    t0 = group_bcast<G>(th_cl, sl); thc_l = take ? t0 : thc_l;
-                    t0 = group_bcast<G>(sd, sl); sd_l = take ? t0 : sd_l;
-                    t0 = group_bcast<G>(sdd, sl); sdd_l = take ? t0 : sdd_l;
-                    t0 = group_bcast<G>(dd, sl); dd_l = take ? t0 : dd_l;
-                    t0 = group_bcast<G>(ddd, sl); ddd_l = take ? t0 : ddd_l;
-                    if (take) { cth_l = cos(th_l); sth_l = sin(th_l); }
+                const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
+                double x = px - d * (ay * inv_tn), y = py + d * (ax * inv_tn);
+                if (__any(act && !in_dom) || ood_step >= 0) {   // wave-uniform ("ood_step" alone is group-uniform: harmless)
+                    const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
+                    if (om && ood_step < 0) ood_step = base + __ffsll((unsigned long long)om) - 1;
+                    if (ood_step >= 0 && i >= ood_step) { x = 0.0; y = 0.0; }   // x, y stay np.zeros past the break
                 }
-                double termx = 0.0, termy = 0.0;
-                if (!act) {   // i >= L: extended state
-                    const double tk = (double)(i - L + 1) * dt;   // np.arange(1, steps + 1) * dt
-                    acc = a_l;                                     // :179
-                    double vt = v_l + tk * a_l;                    // :182 (a[-1] already holds a[last])
-                    vt = vt * (vt >= 0.0 ? 1.0 : 0.0);             // :184
-                    v = vt;
-                    th_gl = th_l; kappa = ka_l; kdot = kd_l;       // :188-192
-                    termx = dt * vt * cth_l;                       // :195-196
-                    termy = dt * vt * sth_l;
-                    double sv = sd_l + tk * 0.0;                   // :313, s_ddot[-1] is the zero padding
-                    sd = sv * (sv >= 0.0 ? 1.0 : 0.0);             // :315
-                    dd = dd_l + tk * 0.0;                          // :319
-                    sdd = sdd_l; ddd = ddd_l; th_cl = thc_l;       // :323-327
-                    s = s_l + tk * sd_l;                           // :330
-                    d = d_l + tk * dd_l;                           // :331
-                }
-                const double scx = group_scan<G>(termx, gl) + cumx, scy = group_scan<G>(termy, gl) + cumy;   // np.cumsum
-                if (!act) { x = x_l + scx; y = y_l + scy; }
-                cumx = group_bcast<G>(scx, G - 1);
-                cumy = group_bcast<G>(scy, G - 1);
-                theta_carry = group_bcast<G>(th_gl, G - 1);
-                kappa_carry = group_bcast<G>(kappa, G - 1);
-
-                // -- cost terms over the extended arrays, cost_function.py:51-71 / 82-92
-                if (live) {
-                    double e;
-                    e = a.w_a * acc; acc_a += e * e;
-                    e = 5.0 * (v - a.desired_speed); acc_v += e * e;
-                    e = 0.25 * (a.desired_s - s); acc_s += e * e;
-                    e = 0.25 * (a.desired_d - d); acc_d += e * e;
-                    e = 0.25 * fabs(th_cl); acc_th += e * e;
-                }
-                {
-                    const int le = N - base, lm = mid - base;
-                    const bool he = le >= 0 && le < G, hm = lm >= 0 && lm < G;
-                    double t0;
-                    t0 = group_bcast<G>(v, he ? le : 0); v_end = he ? t0 : v_end;
-                    t0 = group_bcast<G>(s, he ? le : 0); s_end = he ? t0 : s_end;
-                    t0 = group_bcast<G>(d, he ? le : 0); d_end = he ? t0 : d_end;
-                    t0 = group_bcast<G>(th_cl, he ? le : 0); th_end = he ? t0 : th_end;
-                    t0 = group_bcast<G>(v, hm ? lm : 0); v_mid = hm ? t0 : v_mid;
-                }
-
-                // -- eager collision query for every pose, reactive_planner.py:1033-1046
-                if (check_coll) {
-                    bool hit = false;
-                    if (live && alive && fail_step < 0 && ood_step < 0) {
-                        double sn, cn;
-                        sincos(th_gl, &sn, &cn);
-                        const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
-                        hit = pose_collides(a.obs, ego, a.ego_radius, a.time_step0 + i * a.factor);
-                    }
-                    collide |= group_ballot<G>(hit, gbase) != 0;
-                }
-
-                // -- state block (coalesced along the time axis)
-                if (MAT) {
-                    if (live && valid && pre_reason == RP_REASON_NONE) {
-                        double *o = a.states + ((size_t)slot * RP_N_ARRAYS) * (size_t)n + (size_t)i;
+                if (act) {   // Cartesian rows of valid steps are final here
+                    if (store_ok) {
+                        double *o = orow + i;
                         o[(size_t)RP_X * n] = x;
                         o[(size_t)RP_Y * n] = y;
                         o[(size_t)RP_THETA * n] = th_gl;
@@ -376,25 +457,107 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
                         o[(size_t)RP_A * n] = acc;
                         o[(size_t)RP_KAPPA * n] = kappa;
                         o[(size_t)RP_KAPPA_DOT * n] = kdot;
-                        o[(size_t)RP_S * n] = s;
-                        o[(size_t)RP_D * n] = d;
                         o[(size_t)RP_THETA_CL * n] = th_cl;
-                        o[(size_t)RP_S_DOT * n] = sd;
-                        o[(size_t)RP_S_DDOT * n] = sdd;
-                        o[(size_t)RP_D_DOT * n] = dd;
-                        o[(size_t)RP_D_DDOT * n] = ddd;
+                    }
+                    cost_acc += cost_terms(i, acc, v, s, d, th_cl);
+                }
+                RP_STAMP(8);   // x, y + stores of valid steps
+
+                // -- horizon extension (trajectories.py:168-197, 302-332); only chunks that hold states >= L
+                const int ll = L - 1 - base;
+                const bool take = (ll >= 0 && ll < G);     // this chunk holds the last valid state
+                if (__any(take && L < n)) {                // wave-uniform: park the last valid state in LDS
+                    double sn, cs;
+                    rp_sincos(th_gl, &sn, &cs);
+                    if (take && gl == ll) {
+                        double *o = gs_last;
+                        o[0] = x; o[1] = y; o[2] = th_gl; o[3] = v; o[4] = acc; o[5] = kappa; o[6] = kdot;
+                        o[7] = s; o[8] = d; o[9] = th_cl; o[10] = sd; o[11] = sdd; o[12] = dd; o[13] = ddd;
+                        o[14] = cs; o[15] = sn;
                     }
                 }
+                if (!ONE_CHUNK && c + 1 < nchunks) {
+                    theta_carry = group_bcast<G>(th_gl, G - 1);
+                    kappa_carry = group_bcast<G>(kappa, G - 1);
+                }
+                if (__any(live && !act)) {                 // wave-uniform: this chunk holds extended states
+                    double termx = 0.0, termy = 0.0;
+                    const double *o = gs_last;             // same-wave LDS write above is ordered before these reads
+                    const double tk = (double)(i - L + 1) * dt;   // np.arange(1, steps + 1) * dt
+                    double vt = 0.0;
+                    if (!act) {   // i >= L: extended state
+                        vt = o[3] + tk * o[4];                         // :182 (a[-1] already holds a[last])
+                        vt = vt * (vt >= 0.0 ? 1.0 : 0.0);             // :184
+                        termx = dt * vt * o[14];                       // :195-196
+                        termy = dt * vt * o[15];
+                    }
+                    const double scx = group_scan<G>(termx) + cumx, scy = group_scan<G>(termy) + cumy;   // np.cumsum
+                    if (!act) {
+                        x = o[0] + scx;
+                        y = o[1] + scy;
+                        th_gl = o[2];                                  // :188
+                        const double sv = o[10] + tk * 0.0;            // :313, s_ddot[-1] is the zero padding
+                        const double e_sd = sv * (sv >= 0.0 ? 1.0 : 0.0);   // :315
+                        const double e_dd = o[12] + tk * 0.0;          // :319
+                        const double e_s = o[7] + tk * o[10];          // :330
+                        const double e_d = o[8] + tk * o[12];          // :331
+                        if (live) {
+                            if (store_ok) {
+                                double *w = orow + i;
+                                w[(size_t)RP_X * n] = x;
+                                w[(size_t)RP_Y * n] = y;
+                                w[(size_t)RP_THETA * n] = th_gl;
+                                w[(size_t)RP_V * n] = vt;
+                                w[(size_t)RP_A * n] = o[4];            // :179
+                                w[(size_t)RP_KAPPA * n] = o[5];        // :190
+                                w[(size_t)RP_KAPPA_DOT * n] = o[6];    // :192
+                                w[(size_t)RP_S * n] = e_s;
+                                w[(size_t)RP_D * n] = e_d;
+                                w[(size_t)RP_THETA_CL * n] = o[9];     // :327
+                                w[(size_t)RP_S_DOT * n] = e_sd;
+                                w[(size_t)RP_S_DDOT * n] = o[11];      // :323
+                                w[(size_t)RP_D_DOT * n] = e_dd;
+                                w[(size_t)RP_D_DDOT * n] = o[13];      // :324
+                            }
+                            cost_acc += cost_terms(i, o[4], vt, e_s, e_d, o[9]);
+                        }
+                    }
+                    if (!ONE_CHUNK && c + 1 < nchunks) {
+                        cumx = group_bcast<G>(scx, G - 1);
+                        cumy = group_bcast<G>(scy, G - 1);
+                        theta_carry = group_bcast<G>(th_gl, G - 1);   // only matters for valid steps; keep consistent
+                    }
+                }
+                RP_STAMP(9);   // extension + scans + stores of extended steps
+
+                // -- eager collision query for every pose, reactive_planner.py:1033-1046
+                if (COLL) {
+                    const bool want = live && alive && fail_step < 0 && ood_step < 0;
+                    bool hit = false;
+                    if (__any(want)) {
+                        double sn, cn;
+                        rp_sincos(th_gl, &sn, &cn);
+                        if (want) {
+                            const ObsTables ob = *a.obs;
+                            const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
+                            hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor);
+                        }
+                    }
+                    collide |= group_ballot<G>(hit, gbase) != 0;
+                }
+                RP_STAMP(11);  // collision
             }
         }
+        // next candidate's inputs (software pipelining; consumed at the top of the next iteration)
+        if (w0 + total_groups < count) {
+            const int64_t nslot = slot + total_groups;
+            cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0));
+        }
+        RP_STAMP(12);  // state stores issued, chunk loop done
 
-        // ---- cost reduction (all lanes take part) ----
-        const double sum_a = group_sum<G>(acc_a), sum_v = group_sum<G>(acc_v), sum_s = group_sum<G>(acc_s),
-                     sum_d = group_sum<G>(acc_d), sum_th = group_sum<G>(acc_th);
-
-        // ---- label, reason, cost ----
+        // ---- label, reason, cost (the group's LAST lane holds the reduced cost and does the bookkeeping) ----
         uint32_t status;
-        double cost = __builtin_nan("");
+        const bool decided_bad = pre_reason != RP_REASON_NONE || fail_step >= 0 || ood_step >= 0;
         if (pre_reason != RP_REASON_NONE) {
             status = RP_LABEL_NONE | (pre_reason << 4);
         } else if (fail_step >= 0) {   // :902 INFEASIBLE_KINEMATIC
@@ -403,73 +566,46 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_eval_kernel(const KArgs a) {
             status = (draw ? RP_LABEL_INFEASIBLE_KINEMATIC : RP_LABEL_NONE) | (RP_REASON_OUT_OF_DOMAIN << 4) |
                      ((uint32_t)ood_step << 8);
         } else {
-            double e;
-            if (a.cost_kind == RP_COST_FAILSAFE) {   // cost_function.py:82-92 (w_a == 1, desired_d == 0 set by the host)
-                cost = sum_a;
-                e = 20.0 * d_end; cost += sum_d + e * e;
-                e = 5.0 * fabs(th_end); cost += sum_th + e * e;
-            } else {                                 // cost_function.py:51-71
-                cost = 0.0 + sum_a;
-                if (a.has_speed) {
-                    const double e1 = v_end - a.desired_speed, e2 = v_mid - a.desired_speed;
-                    cost += sum_v + (50.0 * (e1 * e1)) + (100.0 * (e2 * e2));
-                }
-                if (a.has_s) { e = 20.0 * (a.desired_s - s_end); cost += sum_s + e * e; }
-                e = 20.0 * (a.desired_d - d_end); cost += sum_d + e * e;
-                e = 5.0 * fabs(th_end); cost += sum_th + e * e;
-            }
             status = collide ? RP_LABEL_INFEASIBLE_COLLISION : RP_LABEL_FEASIBLE;
         }
-        if (valid) {
-            if (gl == 0) {
-                a.status[slot] = status;
-                a.cost[slot] = cost;
-            }
+        double cost = group_sum_last<G>(cost_acc);
+        if (decided_bad) cost = __builtin_nan("");
+        if (valid && gl == G - 1) {
+            a.status[slot] = status;
+            a.cost[slot] = cost;
             const uint32_t lab = RP_STATUS_LABEL(status), rs = RP_STATUS_REASON(status);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) cnt_reason[r] += (rs == (uint32_t)r);   // no runtime-indexed register array
-            cnt_feasible += (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION);
-            cnt_collision += (lab == RP_LABEL_INFEASIBLE_COLLISION);
-            if (lab == RP_LABEL_FEASIBLE && cost == cost && better(cost, gidx, best_cost, best_index)) {
-                best_cost = cost;
-                best_index = gidx;
+            if (rs) atomicAdd(&sh_cnt[2 + rs], 1);
+            if (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION) atomicAdd(&sh_cnt[0], 1);
+            if (lab == RP_LABEL_INFEASIBLE_COLLISION) atomicAdd(&sh_cnt[1], 1);
+            if (lab == RP_LABEL_FEASIBLE && cost == cost &&
+                better(cost, gidx, sh_best_cost[grp], (int64_t)sh_best_idx[grp])) {   // slot owned by this group
+                sh_best_cost[grp] = cost;
+                sh_best_idx[grp] = gidx;
             }
         }
     }
+    RP_STAMP(13);  // cost reduction + status written
 
     // ---- block partial: lexicographic (cost, index) min + counters ----
     if (a.partials) {
-        __shared__ double sh_cost[GPB];
-        __shared__ int64_t sh_idx[GPB];
-        __shared__ int sh_cnt[GPB][10];
-        const int g = tid / G;
-        __syncthreads();
-        if (gl == 0) {
-            sh_cost[g] = best_cost;
-            sh_idx[g] = best_index;
-            sh_cnt[g][0] = cnt_feasible;
-            sh_cnt[g][1] = cnt_collision;
-            for (int r = 0; r < 8; ++r) sh_cnt[g][2 + r] = cnt_reason[r];
-        }
         __syncthreads();
         if (tid == 0) {
             BlockPartial bp;
             bp.best_cost = 0.0;
             bp.best_index = -1;
-            bp.n_feasible = bp.n_collision = 0;
-            for (int r = 0; r < 8; ++r) bp.reasons[r] = 0;
             for (int k = 0; k < GPB; ++k) {
-                if (sh_idx[k] >= 0 && better(sh_cost[k], sh_idx[k], bp.best_cost, bp.best_index)) {
-                    bp.best_cost = sh_cost[k];
-                    bp.best_index = sh_idx[k];
+                if (sh_best_idx[k] >= 0 && better(sh_best_cost[k], (int64_t)sh_best_idx[k], bp.best_cost, bp.best_index)) {
+                    bp.best_cost = sh_best_cost[k];
+                    bp.best_index = (int64_t)sh_best_idx[k];
                 }
-                bp.n_feasible += sh_cnt[k][0];
-                bp.n_collision += sh_cnt[k][1];
-                for (int r = 0; r < 8; ++r) bp.reasons[r] += sh_cnt[k][2 + r];
             }
+            bp.n_feasible = sh_cnt[0];
+            bp.n_collision = sh_cnt[1];
+            for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
             a.partials[blockIdx.x] = bp;
         }
     }
+    RP_STAMP(14);
 }
 
 // ------------------------------------------------------------------------------------------------
