@@ -23,14 +23,7 @@ namespace {
 constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
 
-struct ResultBlock {       // device -> host in one copy
-    rp_result r;
-    unsigned long long n_before;
-    uint32_t w_status, pad_;
-    double w_cost;
-    double w_coeffs[13];
-    // followed by best_states[14][n]
-};
+using ResultBlock = FinalizeOut;   // device -> host result block (rp_kernels.h)
 
 }  // namespace
 
@@ -55,6 +48,7 @@ struct rp_ctx {
     // per-call staging (pinned host + device mirror)
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t cap_stage = 0;
+    std::vector<char> staged;   // bytes currently resident in d_stage (skip the copy when unchanged)
     // work buffers
     uint32_t *d_status = nullptr;
     double *d_cost = nullptr, *d_user = nullptr;
@@ -63,7 +57,7 @@ struct rp_ctx {
     size_t cap_states = 0;
     BlockPartial *d_partials = nullptr;
     int cap_partials = 0;
-    char *d_result = nullptr, *h_result = nullptr;
+    char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
     unsigned long long *d_debug = nullptr;   // diagnostic build only
@@ -116,7 +110,8 @@ int ensure_result(rp_ctx *c, int n) {
     c->d_result = c->h_result = nullptr;
     c->cap_result = 0;
     HIP_TRY(c, hipMalloc((void **)&c->d_result, need));
-    HIP_TRY(c, hipHostMalloc((void **)&c->h_result, need, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&c->h_result, need, hipHostMallocMapped));
+    HIP_TRY(c, hipHostGetDevicePointer((void **)&c->h_result_dev, c->h_result, 0));
     c->cap_result = need;
     return RP_OK;
 }
@@ -131,6 +126,7 @@ int ensure_stage(rp_ctx *c, size_t need) {
     HIP_TRY(c, hipMalloc((void **)&c->d_stage, want));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, want, hipHostMallocDefault));
     c->cap_stage = want;
+    c->staged.clear();
     return RP_OK;
 }
 
@@ -221,13 +217,14 @@ int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result
     return RP_OK;
 }
 
-// eval -> reduce -> count -> winner -> read back.  ka.status/cost/partials etc. already set.
+// eval -> finalize (-> count for huge batches) (-> winner re-evaluation when nothing was materialised).
+// The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
 int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
     const int n = ka.N + 1;
     int rc;
     if ((rc = ensure_result(c, n)) != RP_OK) return rc;
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
-    double *d_best = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
+    ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
     const int64_t count = ka.count;
     const int grid = eval_grid(c, count, ka.N);
     if (grid > c->cap_partials) {
@@ -241,7 +238,6 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ka.partials = c->d_partials;
     int n_partials = grid;
 
-    HIP_TRY(c, hipMemsetAsync(&drb->n_before, 0, sizeof(unsigned long long), c->stream));
     if (!skip_eval) {
         if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) launch_eval(c, ka, grid, mat, cin);
@@ -255,44 +251,37 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         else
             n_partials = 0;
     }
-    hipLaunchKernelGGL(rp_reduce_kernel, dim3(1), dim3(RP_BLOCK), 0, c->stream, c->d_partials, n_partials, count, &drb->r);
-    if (count > 0) {
+    const bool small = count <= RP_FINALIZE_MAX;
+    const bool copy_states = mat && best_states != nullptr && count > 0;
+    hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, c->d_partials, n_partials,
+                       small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev);
+    if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
         const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
         hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
                            ka.cand_begin, &drb->r, 0.0, (int64_t)0, 0, &drb->n_before);
-        // winner: re-evaluate that one candidate with the state block written out
+        HIP_TRY(c, hipMemcpyAsync(&reinterpret_cast<ResultBlock *>(c->h_result)->n_before, &drb->n_before,
+                                  sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (!mat && best_states != nullptr && count > 0) {
+        // nothing was materialised: re-evaluate the winner with its state block written to the host mirror
         KArgs kw = ka;
         kw.single_index = &drb->r.best_index;
         kw.count = 1;
         kw.status = &drb->w_status;
         kw.cost = &drb->w_cost;
-        kw.states = d_best;
-        kw.coeffs = cin ? nullptr : drb->w_coeffs;
+        kw.states = reinterpret_cast<double *>(hrb_dev + 1);
+        kw.coeffs = nullptr;
         kw.partials = nullptr;
         launch_eval(c, kw, 1, true, cin);
     }
-    const size_t bytes = sizeof(ResultBlock) + (best_states ? sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n : 0);
-    HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
 
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
     *result = hrb->r;
     result->n_collision_before_best = (int64_t)hrb->n_before;
-    result->best_lat_T = NAN;
-    for (int k = 0; k < 6; ++k) result->best_lon_coeffs[k] = result->best_lat_coeffs[k] = NAN;
-    if (result->best_index >= 0) {
-        if (!cin) {
-            std::memcpy(result->best_lon_coeffs, hrb->w_coeffs, 6 * sizeof(double));
-            std::memcpy(result->best_lat_coeffs, hrb->w_coeffs + 6, 6 * sizeof(double));
-            result->best_lat_T = hrb->w_coeffs[12];
-        } else if ((size_t)result->best_index * 6 + 6 <= c->last_lon.size()) {
-            std::memcpy(result->best_lon_coeffs, c->last_lon.data() + 6 * result->best_index, 6 * sizeof(double));
-            std::memcpy(result->best_lat_coeffs, c->last_lat.data() + 6 * result->best_index, 6 * sizeof(double));
-        }
-        if (best_states)
-            std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
-    }
+    if (result->best_index >= 0 && best_states)
+        std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
 #ifdef RP_STAMPS
     if (std::getenv("RP_AMD_PRINT_STAMPS")) {
         unsigned long long st[32];
@@ -514,7 +503,10 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     std::memcpy(hs + g->nT, g->L, sizeof(double) * g->nL);
     std::memcpy(hs + g->nT + g->nL, g->D, sizeof(double) * g->nD);
     std::memcpy(hs + nd, g->traj_len, sizeof(int32_t) * g->nT);
-    if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+    if (sbytes && (c->staged.size() != sbytes || std::memcmp(c->staged.data(), c->h_stage, sbytes) != 0)) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+        c->staged.assign(c->h_stage, c->h_stage + sbytes);
+    }
 
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)count)) != RP_OK) return rc;
@@ -554,6 +546,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     std::memcpy(hs + 6 * C, lat_coeffs, sizeof(double) * 6 * C);
     std::memcpy(hs + 12 * C, traj_len, sizeof(int32_t) * C);
     if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+    c->staged.clear();
     c->last_lon.assign(lon_coeffs, lon_coeffs + 6 * C);
     c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;

@@ -152,6 +152,17 @@ __device__ __forceinline__ double lds_vel(const double *o, double t) {
 }
 __device__ __forceinline__ double lds_acc(const double *o, double t) { return ((o[14] * t + o[13]) * t + o[12]) * t + o[11]; }
 
+#ifndef RP_POLY_LDS
+#define RP_POLY_LDS 1   // 1: coefficients parked in LDS and re-read per step block; 0: kept in VGPRs
+#endif
+#if RP_POLY_LDS
+#define POLY_LON gs_poly
+#define POLY_LAT (gs_poly + 15)
+#else
+#define POLY_LON rg_lon
+#define POLY_LAT rg_lat
+#endif
+
 // ONE_CHUNK: N + 1 <= G, the step loop disappears together with its carried state.
 template <int G, bool MAT, bool COEFFS_IN, bool LDS_TABLES, bool COLL, bool ONE_CHUNK>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
@@ -244,6 +255,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
 
         // ---- sampling: FixedIntervalSampling.generate_trajectories_at_level, sampling.py:218-241 ----
         int L = cin.L;
+#if !RP_POLY_LDS
+        double rg_lon[15], rg_lat[15];
+#endif
         {
             Poly lon, lat;
             double lat_T;
@@ -264,9 +278,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 }
                 lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[2], 0.0, 0.0, lat_T);  // sampling.py:227
             }
+#if !RP_POLY_LDS
+            park_poly(rg_lon, lon);
+            park_poly(rg_lat, lat);
+#endif
             if (gl == 0) {   // park the coefficients (same-wave LDS ordering makes them visible to the group)
+#if RP_POLY_LDS
                 park_poly(gs_poly, lon);
                 park_poly(gs_poly + 15, lat);
+#endif
                 if (a.coeffs && valid) {
                     double *o = a.coeffs + 13 * slot;
                     o[0] = lon.c0; o[1] = lon.c1; o[2] = lon.c2; o[3] = lon.c3; o[4] = lon.c4; o[5] = lon.c5;
@@ -286,7 +306,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             for (int c = 0; c < nchunks; ++c) {
                 const int i = c * G + gl;
                 const double t = (double)i * dt;
-                double sd = lds_vel(gs_poly, t), sdd = lds_acc(gs_poly, t);
+                double sd = lds_vel(POLY_LON, t), sdd = lds_acc(POLY_LON, t);
                 if (fabs(sd) < RP_EPS) sd = 0.0;
                 bad_a |= (i < L) && (fabs(sdd) > a.a_max);
                 bad_v |= (i < L) && (sd < -RP_EPS);
@@ -318,9 +338,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
 
                 // -- polynomial evaluation, reactive_planner.py:733-777
                 const double t = (double)i * dt;
-                double s = lds_pos(gs_poly, t), sd = lds_vel(gs_poly, t), sdd = lds_acc(gs_poly, t);
-                const double tau = low ? s - gs_poly[0] : t;   // s[0] == c0 exactly (:762)
-                double d = lds_pos(gs_poly + 15, tau), dd = lds_vel(gs_poly + 15, tau), ddd = lds_acc(gs_poly + 15, tau);
+                double s = lds_pos(POLY_LON, t), sd = lds_vel(POLY_LON, t), sdd = lds_acc(POLY_LON, t);
+                const double tau = low ? s - POLY_LON[0] : t;   // s[0] == c0 exactly (:762)
+                double d = lds_pos(POLY_LAT, tau), dd = lds_vel(POLY_LAT, tau), ddd = lds_acc(POLY_LAT, tau);
                 if (fabs(sd) < RP_EPS) sd = 0.0;
                 if (fabs(dd) < RP_EPS) dd = 0.0;
                 if (store_ok && act) {   // curvilinear rows of valid steps are final here
@@ -726,5 +746,134 @@ __global__ void rp_apply_costs_kernel(const double *user, double *cost, const ui
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t lab = RP_STATUS_LABEL(status[i]);
         if (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION) cost[i] = user[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One-launch epilogue for batches up to RP_FINALIZE_MAX candidates: reduce the block partials,
+// count the colliding samples that precede the winner (lazy semantics of _check_collisions),
+// fetch the winner's state block from the materialised states (if any) and its polynomial
+// coefficients, and write the whole result block to device memory AND to the pinned host mirror
+// (no separate memset / count / copy operations on the stream).
+// ------------------------------------------------------------------------------------------------
+#define RP_FIN_THREADS 1024
+#define RP_FINALIZE_MAX (1 << 17)
+
+struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
+    rp_result r;
+    unsigned long long n_before;
+    uint32_t w_status, pad_;
+    double w_cost;
+    double w_coeffs[13];
+    // followed by best_states[14][n]
+};
+
+__global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
+                                                                      int count_inline, int copy_states, FinalizeOut *dev_out,
+                                                                      FinalizeOut *host_out) {
+    __shared__ double sh_cost[RP_FIN_THREADS];
+    __shared__ long long sh_idx[RP_FIN_THREADS];
+    __shared__ unsigned long long sh_cnt[10];
+    __shared__ unsigned long long sh_before;
+    const int tid = threadIdx.x;
+    double bc = 0.0;
+    int64_t bi = -1;
+    if (tid < 10) sh_cnt[tid] = 0;
+    if (tid == 0) sh_before = 0;
+    __syncthreads();
+    for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
+        const BlockPartial p = partials[k];
+        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, bi)) { bc = p.best_cost; bi = p.best_index; }
+        if (p.n_feasible) atomicAdd(&sh_cnt[0], (unsigned long long)p.n_feasible);
+        if (p.n_collision) atomicAdd(&sh_cnt[1], (unsigned long long)p.n_collision);
+        for (int r = 0; r < 8; ++r)
+            if (p.reasons[r]) atomicAdd(&sh_cnt[2 + r], (unsigned long long)p.reasons[r]);
+    }
+    sh_cost[tid] = bc;
+    sh_idx[tid] = bi;
+    __syncthreads();
+    for (int off = RP_FIN_THREADS / 2; off > 0; off >>= 1) {   // lexicographic (cost, index) min, tree
+        if (tid < off) {
+            const long long oi = sh_idx[tid + off];
+            if (oi >= 0 && better(sh_cost[tid + off], (int64_t)oi, sh_cost[tid], (int64_t)sh_idx[tid])) {
+                sh_cost[tid] = sh_cost[tid + off];
+                sh_idx[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t widx = (int64_t)sh_idx[0];
+    const double wcost = sh_cost[0];
+    const unsigned long long n_coll = sh_cnt[1];
+    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
+    if (count_inline && n_coll > 0) {
+        int nloc = 0;
+        for (int64_t i = tid; i < a.count; i += RP_FIN_THREADS) {
+            if (RP_STATUS_LABEL(a.status[i]) == RP_LABEL_INFEASIBLE_COLLISION) {
+                const double c = a.cost[i];
+                nloc += (widx < 0 || c < wcost || (c == wcost && a.cand_begin + i < widx));
+            }
+        }
+        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
+    }
+    __syncthreads();
+    const int n = a.N + 1;
+    if (tid == 0) {
+        FinalizeOut o;
+        o.r.best_index = widx;
+        o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
+        o.r.n_candidates = a.count;
+        o.r.n_feasible = (int64_t)sh_cnt[0];
+        o.r.n_collision = (int64_t)n_coll;
+        o.r.n_collision_before_best = (int64_t)sh_before;
+        for (int r = 0; r < 8; ++r) o.r.reason_counts[r] = (int64_t)sh_cnt[2 + r];
+        o.r.kernel_ms = 0.0;
+        o.r.best_lat_T = __builtin_nan("");
+        for (int k = 0; k < 6; ++k) o.r.best_lon_coeffs[k] = o.r.best_lat_coeffs[k] = __builtin_nan("");
+        o.n_before = sh_before;
+        o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
+        for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
+        if (widx >= 0) {
+            // the winner's polynomials, recomputed with the evaluation kernel's own formulas
+            Poly lon, lat;
+            double lat_T = 0.0;
+            if (a.lon_coeffs) {
+                const double *pl = a.lon_coeffs + 6 * widx, *pt = a.lat_coeffs + 6 * widx;
+                lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
+                lat = {pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]};
+            } else {
+                const int64_t nLD = (int64_t)a.nL * a.nD;
+                const int iT = (int)(widx / nLD);
+                const int rem = (int)(widx - (int64_t)iT * nLD);
+                const int iL = rem / a.nD, iD = rem - iL * a.nD;
+                const double T = a.T[iT];
+                if (a.lon_mode == RP_LON_STOPPING) lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);
+                else lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);
+                lat_T = T;
+                if (a.low_vel_mode) {
+                    const double sg = lon.pos(T) - a.x0_lon[0];
+                    lat_T = sg <= 0.0 ? T : sg;
+                }
+                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], a.D[iD], 0.0, 0.0, lat_T);
+            }
+            o.w_coeffs[0] = lon.c0; o.w_coeffs[1] = lon.c1; o.w_coeffs[2] = lon.c2; o.w_coeffs[3] = lon.c3;
+            o.w_coeffs[4] = lon.c4; o.w_coeffs[5] = lon.c5;
+            o.w_coeffs[6] = lat.c0; o.w_coeffs[7] = lat.c1; o.w_coeffs[8] = lat.c2; o.w_coeffs[9] = lat.c3;
+            o.w_coeffs[10] = lat.c4; o.w_coeffs[11] = lat.c5; o.w_coeffs[12] = lat_T;
+            for (int k = 0; k < 6; ++k) { o.r.best_lon_coeffs[k] = o.w_coeffs[k]; o.r.best_lat_coeffs[k] = o.w_coeffs[6 + k]; }
+            o.r.best_lat_T = a.lon_coeffs ? __builtin_nan("") : lat_T;
+            o.w_status = a.status[widx - a.cand_begin];
+        }
+        *dev_out = o;
+        *host_out = o;
+    }
+    if (copy_states && widx >= 0) {   // winner's state block straight from the materialised states
+        const double *src = a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n;
+        double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
+        for (int k = tid; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
+            const double v = src[k];
+            d1[k] = v;
+            d2[k] = v;
+        }
     }
 }
