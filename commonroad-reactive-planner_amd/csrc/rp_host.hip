@@ -55,6 +55,10 @@ struct rp_ctx {
     size_t cap_status = 0, cap_cost = 0, cap_user = 0;
     double *d_states = nullptr;
     size_t cap_states = 0;
+    double *d_profile = nullptr, *d_profile_one = nullptr;   // longitudinal profiles (batch / rp_eval_one scratch)
+    size_t cap_profile = 0, cap_profile_one = 0;
+    PairHdr *d_pair_hdr = nullptr, *d_pair_hdr_one = nullptr;
+    size_t cap_pair_hdr = 0;
     BlockPartial *d_partials = nullptr;
     int cap_partials = 0;
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
@@ -132,15 +136,8 @@ int ensure_stage(rp_ctx *c, size_t need) {
 
 template <int G, bool MAT, bool CIN, bool COLL>
 void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
-    const size_t tbytes = (size_t)ka.table_words * sizeof(double);
-    const bool one = ka.N + 1 <= G;
-    if (tbytes <= kLdsTableLimit) {
-        if (one) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true, COLL, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
-        else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, true, COLL, false>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
-    } else {
-        if (one) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false, COLL, true>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
-        else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, false, COLL, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
-    }
+    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
 }
 
 template <int G, bool MAT, bool CIN>
@@ -160,6 +157,25 @@ void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin) {
         if (mat) { if (cin) launch_eval_t<64, true, true>(c, ka, grid); else launch_eval_t<64, true, false>(c, ka, grid); }
         else     { if (cin) launch_eval_t<64, false, true>(c, ka, grid); else launch_eval_t<64, false, false>(c, ka, grid); }
     }
+}
+
+template <int G, bool CIN>
+void launch_lon_t(rp_ctx *c, const KArgs &ka, int grid) {
+    const size_t tbytes = (size_t)ka.table_words * sizeof(double);
+    if (tbytes <= kLdsTableLimit)
+        hipLaunchKernelGGL((rp_lon_kernel<G, CIN, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
+    else
+        hipLaunchKernelGGL((rp_lon_kernel<G, CIN, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+}
+
+// longitudinal profiles of the pairs [ka.pair_begin, ka.pair_begin + ka.pair_count)
+void launch_lon(rp_ctx *c, const KArgs &ka, bool cin) {
+    if (ka.pair_count <= 0) return;
+    const int G = (ka.N + 1 <= 32) ? 32 : 64;
+    const int gpb = RP_BLOCK / G;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((ka.pair_count + gpb - 1) / gpb, (int64_t)c->num_cus * kBlocksPerCU));
+    if (G == 32) { if (cin) launch_lon_t<32, true>(c, ka, grid); else launch_lon_t<32, false>(c, ka, grid); }
+    else         { if (cin) launch_lon_t<64, true>(c, ka, grid); else launch_lon_t<64, false>(c, ka, grid); }
 }
 
 int eval_grid(const rp_ctx *c, int64_t count, int N) {
@@ -239,6 +255,19 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     int n_partials = grid;
 
     if (!skip_eval) {
+        // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
+        if (count > 0) {
+            if (cin) { ka.pair_begin = 0; ka.pair_count = count; }
+            else {
+                ka.pair_begin = ka.cand_begin / ka.nD;
+                ka.pair_count = (ka.cand_begin + count - 1) / ka.nD + 1 - ka.pair_begin;
+            }
+            if ((rc = grow(c, c->d_profile, c->cap_profile, (size_t)ka.pair_count * PF_FIELDS * (size_t)n)) != RP_OK) return rc;
+            if ((rc = grow(c, c->d_pair_hdr, c->cap_pair_hdr, (size_t)ka.pair_count)) != RP_OK) return rc;
+            ka.profile = c->d_profile;
+            ka.pair_hdr = c->d_pair_hdr;
+            launch_lon(c, ka, cin);
+        }
         if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) launch_eval(c, ka, grid, mat, cin);
         if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -326,6 +355,7 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipEventCreate(&c->ev1));
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
 #ifdef RP_STAMPS
     HIP_TRY(c, hipMalloc((void **)&c->d_debug, 32 * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(c->d_debug, 0, 32 * sizeof(unsigned long long)));
@@ -340,7 +370,8 @@ void rp_destroy(rp_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
-                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs};
+                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs, c->d_profile, c->d_profile_one,
+                   c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -610,6 +641,13 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
     kw.coeffs = nullptr;
     kw.partials = nullptr;
+    // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own
+    if ((rc = grow(c, c->d_profile_one, c->cap_profile_one, (size_t)PF_FIELDS * (size_t)n)) != RP_OK) return rc;
+    kw.pair_begin = c->last_coeffs ? index : index / l.nD;
+    kw.pair_count = 1;
+    kw.profile = c->d_profile_one;
+    kw.pair_hdr = c->d_pair_hdr_one;
+    launch_lon(c, kw, c->last_coeffs);
     launch_eval(c, kw, 1, true, c->last_coeffs);
     const size_t bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));

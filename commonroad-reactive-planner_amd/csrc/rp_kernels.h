@@ -1,8 +1,16 @@
-// rp_kernels.h -- the fused sample -> convert -> check -> cost -> collide kernel and the small
-// selection kernels around it.  Replaces, per candidate, the loop body of
+// rp_kernels.h -- the kernels of one replanning step.  Per candidate they replace the loop body of
 // ReactivePlanner._check_kinematics (commonroad_rp/reactive_planner.py:731-960) together with
 // sampling (sampling.py:218-241), cost (cost_function.py:51-71) and the collision query
 // (reactive_planner.py:1031-1046); citations inline.
+//
+//   rp_lon_kernel       one group of lanes per (T, longitudinal sample) PAIR: everything of a step that
+//                       does not depend on the lateral sample d -- s, s_dot, s_ddot, the reference-path
+//                       segment lookup and the quantities interpolated on it (theta_ref, k_r, k_r',
+//                       foot point, unit normal) -- written once as a "longitudinal profile" and shared
+//                       by the nD candidates of the pair (the reference recomputes it nD times).
+//   rp_eval_kernel      one group of lanes per CANDIDATE: lateral polynomial, Frenet -> Cartesian,
+//                       constraints, horizon extension, cost, collision, state rows, block partial.
+//   rp_finalize_kernel  selection epilogue.
 #pragma once
 
 #include "rp_device.h"
@@ -45,6 +53,10 @@ struct KArgs {
     double proj_d_limit;
     const ObsTables *obs;  // device copy of the obstacle table descriptor (loaded only by the collision block)
     int32_t has_obstacles, pad2_;
+    // longitudinal profiles (rp_lon_kernel -> rp_eval_kernel): pairs [pair_begin, pair_begin + pair_count)
+    double *profile;            // [pair_count][PF_FIELDS][N+1]
+    struct PairHdr *pair_hdr;   // [pair_count]
+    int64_t pair_begin, pair_count;
     // outputs
     uint32_t *status;  // [count]
     double *cost;      // [count]
@@ -52,6 +64,16 @@ struct KArgs {
     double *coeffs;    // [count][13] or nullptr (lon 6, lat 6, lat_T)
     struct BlockPartial *partials;  // [gridDim.x] or nullptr
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
+};
+
+// fields of one step of a longitudinal profile
+enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_FIELDS };
+
+struct PairHdr {
+    double lat_T;        // delta_tau of the lateral polynomials of this pair (sampling.py:229-237)
+    double s0;           // s at t = 0 (low-velocity mode samples the lateral motion over s - s0)
+    int32_t pre_reason;  // pre-filter verdict of reactive_planner.py:796-805 (RP_REASON_* or 0)
+    int32_t L;           // number of valid steps (traj_len), clamped to [1, N+1]
 };
 
 struct BlockPartial {
@@ -99,42 +121,12 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 //   * divisions by quantities reused several times (s_dot, 1 - k_r d, segment length) become one
 //     Newton-refined reciprocal each; threshold tests are rearranged to multiplications.
 // ------------------------------------------------------------------------------------------------
-// raw per-candidate inputs, fetched one iteration ahead of their use (global-memory latency hidden
-// behind the table staging / the previous candidate)
-struct CandIn {
-    double v[12];   // grid mode: T, L sample, D sample;  COEFFS_IN: lon[6], lat[6]
-    int L;
-};
-
-template <bool COEFFS_IN>
-__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) {
-    CandIn ci;
-    if (COEFFS_IN) {
-        const double *pl = a.lon_coeffs + 6 * gidx, *pt = a.lat_coeffs + 6 * gidx;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { ci.v[k] = pl[k]; ci.v[6 + k] = pt[k]; }
-        ci.L = a.traj_len_c[gidx];
-    } else {
-        const int64_t nLD = (int64_t)a.nL * a.nD;
-        const int iT = (int)(gidx / nLD);
-        const int rem = (int)(gidx - (int64_t)iT * nLD);
-        const int iL = rem / a.nD, iD = rem - iL * a.nD;
-        ci.v[0] = a.T[iT];
-        ci.v[1] = a.L[iL];
-        ci.v[2] = a.D[iD];
-        ci.L = a.traj_len[iT];
-    }
-    return ci;
-}
-
-// Per-group LDS scratch.  Values that are identical in all lanes of a group and live for the whole
-// candidate (polynomial coefficients, last valid state) are parked here and re-read (broadcast reads)
-// right where they are used, instead of occupying VGPRs across the step loop.
-//   poly[0..14]  longitudinal: c0..c5 | c1, 2c2, 3c3, 4c4, 5c5 | 2c2, 6c3, 12c4, 20c5
-//   poly[15..29] lateral, same layout
+// Per-group LDS scratch of the evaluation kernel.  Values that are identical in all lanes of a group
+// and live for the whole candidate are parked here and re-read (broadcast reads) where they are used.
+//   poly[0..14]  lateral polynomial: c0..c5 | c1, 2c2, 3c3, 4c4, 5c5 | 2c2, 6c3, 12c4, 20c5
 //   last[0..15]  x y theta v a kappa kappa_dot s d theta_cl s_dot s_ddot d_dot d_ddot cos(theta) sin(theta)
 struct GroupScratch {
-    double poly[30];
+    double poly[16];
     double last[16];
 };
 
@@ -144,33 +136,186 @@ __device__ __forceinline__ void park_poly(double *o, const Poly &c) {
     o[11] = 2.0 * c.c2; o[12] = 6.0 * c.c3; o[13] = 12.0 * c.c4; o[14] = 20.0 * c.c5;
 }
 // PolynomialTrajectory.calc_position / calc_velocity / calc_acceleration (polynomial_trajectory.py:240-271), Horner
-__device__ __forceinline__ double lds_pos(const double *o, double t) {
+__device__ __forceinline__ double poly_pos(const double *o, double t) {
     return ((((o[5] * t + o[4]) * t + o[3]) * t + o[2]) * t + o[1]) * t + o[0];
 }
-__device__ __forceinline__ double lds_vel(const double *o, double t) {
+__device__ __forceinline__ double poly_vel(const double *o, double t) {
     return (((o[10] * t + o[9]) * t + o[8]) * t + o[7]) * t + o[6];
 }
-__device__ __forceinline__ double lds_acc(const double *o, double t) { return ((o[14] * t + o[13]) * t + o[12]) * t + o[11]; }
+__device__ __forceinline__ double poly_acc(const double *o, double t) { return ((o[14] * t + o[13]) * t + o[12]) * t + o[11]; }
 
-#ifndef RP_POLY_LDS
-#define RP_POLY_LDS 1   // 1: coefficients parked in LDS and re-read per step block; 0: kept in VGPRs
-#endif
-#if RP_POLY_LDS
-#define POLY_LON gs_poly
-#define POLY_LAT (gs_poly + 15)
-#else
-#define POLY_LON rg_lon
-#define POLY_LAT rg_lat
-#endif
-
-// ONE_CHUNK: N + 1 <= G, the step loop disappears together with its carried state.
-template <int G, bool MAT, bool COEFFS_IN, bool LDS_TABLES, bool COLL, bool ONE_CHUNK>
-__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
+// ------------------------------------------------------------------------------------------------
+// Longitudinal profiles: one group of G lanes per (T, longitudinal sample) pair, lane = time step.
+// ------------------------------------------------------------------------------------------------
+template <int G, bool COEFFS_IN, bool LDS_TABLES>
+__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
-    RP_STAMP(0);
     const int n_ref = a.n_ref;
+    const double *tab;
+    if (LDS_TABLES) {   // 16-byte loads, four in flight per lane
+        const double2 *src = reinterpret_cast<const double2 *>(a.tables);
+        double2 *dst = reinterpret_cast<double2 *>(lds);
+        const int nw2 = a.table_words >> 1;   // table_words is even
+#pragma unroll 4
+        for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+        tab = lds;
+        __syncthreads();
+    } else {
+        tab = a.tables;
+    }
+    const double *t_pos = tab + TB_POS * n_ref, *t_theta = tab + TB_THETA * n_ref, *t_curv = tab + TB_CURV * n_ref,
+                 *t_curv_d = tab + TB_CURV_D * n_ref, *t_x = tab + TB_X * n_ref, *t_y = tab + TB_Y * n_ref,
+                 *t_tx = tab + TB_TX * n_ref, *t_ty = tab + TB_TY * n_ref, *t_inv = tab + TB_INVLEN * n_ref;
+    const int *t_bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
+    const double pos_first = t_pos[0], pos_last = t_pos[n_ref - 1];
 
+    const int lane = tid & 63;
+    const int gl = lane & (G - 1);
+    const int gbase = lane & ~(G - 1);
+    constexpr int GPB = RP_BLOCK / G;
+    const int N = a.N, n = N + 1;
+    const int nchunks = (n + G - 1) / G;
+    const double dt = a.dt;
+    const bool draw = (a.flags & RP_FLAG_DRAW_ALL) != 0;
+    const bool low = a.low_vel_mode != 0;
+
+    for (int64_t slot = (int64_t)blockIdx.x * GPB + tid / G; slot < a.pair_count; slot += (int64_t)gridDim.x * GPB) {
+        // all lanes of a group share the slot; groups of one wave may leave the loop at different trip counts,
+        // which is fine here: the body uses only group-level ballots on lanes that are all still active.
+        const int64_t pair = a.pair_begin + slot;
+        // ---- longitudinal polynomial: sampling.py:253-266
+        Poly lon;
+        double lat_T = 0.0;
+        int L;
+        if (COEFFS_IN) {
+            const double *pl = a.lon_coeffs + 6 * pair;
+            lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
+            L = a.traj_len_c[pair];
+        } else {
+            const int iT = (int)(pair / a.nL), iL = (int)(pair - (int64_t)iT * a.nL);
+            const double T = a.T[iT];
+            L = a.traj_len[iT];
+            if (a.lon_mode == RP_LON_STOPPING)
+                lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);  // sampling.py:259-263
+            else
+                lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);             // sampling.py:254-258
+            lat_T = T;
+            if (low) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
+                const double sg = lon.pos(T) - a.x0_lon[0];
+                lat_T = sg <= 0.0 ? T : sg;
+            }
+        }
+        L = L > n ? n : (L < 1 ? 1 : L);
+        double *const prow = a.profile + ((size_t)slot * PF_FIELDS) * (size_t)n;
+        bool bad_a = false, bad_v = false;
+#pragma nounroll
+        for (int c = 0; c < nchunks; ++c) {
+            const int i = c * G + gl;
+            const double t = (double)i * dt;
+            // -- polynomial evaluation, reactive_planner.py:751-753,776
+            const double s = lon.pos(t), sdd = lon.acc(t);
+            double sd = lon.vel(t);
+            if (fabs(sd) < RP_EPS) sd = 0.0;
+            bad_a |= (i < L) && (fabs(sdd) > a.a_max);   // pre-filter, :798
+            bad_v |= (i < L) && (sd < -RP_EPS);          // pre-filter, :802
+            const bool moving = sd > 0.001;              // :811,:822,:842
+            const double inv_sd = moving ? rp_rcp(sd) : 0.0;
+            // -- segment lookup + interpolation factors (:835-839); Python's negative index wraps
+            const int ub = a.n_buckets > 0
+                               ? upper_bound_bucket(t_pos, t_bucket, n_ref, a.n_buckets, a.bucket_inv_h, pos_first, pos_last, s)
+                               : upper_bound(t_pos, n_ref, a.search_iters, s);
+            const int s_idx = (ub == n_ref) ? -1 : ub - 1;
+            const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
+            const double p0 = t_pos[k0], inv_len = t_inv[k0];
+            const double ds = s - p0;
+            const double lam = ds * inv_len;
+            const double th0 = t_theta[k0];
+            const double th_ref = make_valid_orientation((t_theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
+            const double c0 = t_curv[k0], cd0 = t_curv_d[k0];
+            const double k_r = (t_curv[k1] - c0) * lam + c0;              // :876-880
+            const double k_r_d = (t_curv_d[k1] - cd0) * lam + cd0;
+            // -- foot point and unit normal of (s, d) -> (x, y) = foot + d * normal, :908-917
+            int k = ub - 1;
+            k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
+            const double lam2 = (s - t_pos[k]) * t_inv[k];
+            const double bx = t_x[k], by = t_y[k], ux0 = t_tx[k], uy0 = t_ty[k];
+            const double px = bx + lam2 * (t_x[k + 1] - bx), py = by + lam2 * (t_y[k + 1] - by);
+            const double ax = ux0 + lam2 * (t_tx[k + 1] - ux0), ay = uy0 + lam2 * (t_ty[k + 1] - uy0);
+            const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
+            if (i <= N) {
+                double *o = prow + i;
+                o[(size_t)PF_S * n] = s;
+                o[(size_t)PF_SD * n] = sd;
+                o[(size_t)PF_SDD * n] = sdd;
+                o[(size_t)PF_INV_SD * n] = inv_sd;
+                o[(size_t)PF_TH_REF * n] = th_ref;
+                o[(size_t)PF_KR * n] = k_r;
+                o[(size_t)PF_KRD * n] = k_r_d;
+                o[(size_t)PF_PX * n] = px;
+                o[(size_t)PF_PY * n] = py;
+                o[(size_t)PF_NX * n] = -(ay * inv_tn);
+                o[(size_t)PF_NY * n] = ax * inv_tn;
+                o[(size_t)PF_INDOM * n] = (s >= pos_first && s <= pos_last) ? 1.0 : 0.0;
+            }
+        }
+        const bool any_a = group_ballot<G>(bad_a, gbase) != 0, any_v = group_ballot<G>(bad_v, gbase) != 0;
+        if (gl == 0) {
+            PairHdr h;
+            h.lat_T = lat_T;
+            h.s0 = lon.c0;   // s[0] == c0 exactly (:762)
+            h.pre_reason = draw ? RP_REASON_NONE : (any_a ? RP_REASON_ACCELERATION : (any_v ? RP_REASON_VELOCITY : RP_REASON_NONE));
+            h.L = L;
+            a.pair_hdr[slot] = h;
+        }
+    }
+}
+
+// raw per-candidate inputs of the evaluation kernel, fetched one iteration ahead of their use
+struct CandIn {
+    double v[6];   // grid mode: v[0] = lateral sample d;  COEFFS_IN: lateral coefficients
+    double lat_T, s0;
+    int pre_reason, L;
+    int64_t pair_slot;
+};
+
+template <bool COEFFS_IN>
+__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) {
+    CandIn ci;
+    int64_t pair;
+    if (COEFFS_IN) {
+        const double *pt = a.lat_coeffs + 6 * gidx;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ci.v[k] = pt[k];
+        pair = gidx;
+    } else {
+        pair = gidx / a.nD;
+        ci.v[0] = a.D[(int)(gidx - pair * a.nD)];
+    }
+    ci.pair_slot = pair - a.pair_begin;
+    const PairHdr h = a.pair_hdr[ci.pair_slot];
+    ci.lat_T = h.lat_T;
+    ci.s0 = h.s0;
+    ci.pre_reason = h.pre_reason;
+    ci.L = h.L;
+    return ci;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Candidate evaluation: one group of G lanes per candidate, lane = time step.
+// ONE_CHUNK: N + 1 <= G, the step loop disappears together with its carried state.
+//
+// Arithmetic notes (all within the 1e-6 state tolerance, typically ~1e-13):
+//   * theta_cl = atan(d') on the moving branch, hence cos(theta_cl) = 1/sqrt(1 + d'^2) and
+//     tan(theta_cl) = d' without a second and third transcendental; only standstill lanes
+//     (reactive_planner.py:864-873) evaluate sin/cos, behind a wave-uniform branch.
+//   * divisions by quantities reused several times (s_dot, 1 - k_r d, segment length) become one
+//     Newton-refined reciprocal each; threshold tests are rearranged to multiplications.
+// ------------------------------------------------------------------------------------------------
+template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK>
+__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
+    const int tid = threadIdx.x;
+    RP_STAMP(0);
     const int lane = tid & 63;
     const int gl = lane & (G - 1);        // lane inside the group = time step inside the chunk
     const int gbase = lane & ~(G - 1);    // first lane of the group inside the wave
@@ -185,7 +330,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave
     const int64_t count = a.single_index ? 1 : a.count;
 
-    // first candidate's inputs: issued before the table staging so both latencies overlap
     CandIn cin;
     {
         const int64_t slot0 = wave_first + group_in_wave;
@@ -199,25 +343,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     __shared__ int sh_cnt[10];
     if (tid < 10) sh_cnt[tid] = 0;
     if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
-
-    const double *tab;
-    if (LDS_TABLES) {   // 16-byte loads, four in flight per lane
-        const double2 *src = reinterpret_cast<const double2 *>(a.tables);
-        double2 *dst = reinterpret_cast<double2 *>(lds);
-        const int nw2 = a.table_words >> 1;   // table_words is even
-#pragma unroll 4
-        for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
-        tab = lds;
-    } else {
-        tab = a.tables;
-    }
     __syncthreads();
-    RP_STAMP(1);   // tables staged
-    const double *t_pos = tab + TB_POS * n_ref, *t_theta = tab + TB_THETA * n_ref, *t_curv = tab + TB_CURV * n_ref,
-                 *t_curv_d = tab + TB_CURV_D * n_ref, *t_x = tab + TB_X * n_ref, *t_y = tab + TB_Y * n_ref,
-                 *t_tx = tab + TB_TX * n_ref, *t_ty = tab + TB_TY * n_ref, *t_inv = tab + TB_INVLEN * n_ref;
-    const int *t_bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
-    const double pos_first = t_pos[0], pos_last = t_pos[n_ref - 1];
+    RP_STAMP(1);
 
     const int N = a.N, n = N + 1;
     const int nchunks = ONE_CHUNK ? 1 : (n + G - 1) / G;
@@ -253,67 +380,18 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const bool valid = slot < count;
         const int64_t gidx = a.single_index ? *a.single_index : a.cand_begin + (valid ? slot : 0);
 
-        // ---- sampling: FixedIntervalSampling.generate_trajectories_at_level, sampling.py:218-241 ----
-        int L = cin.L;
-#if !RP_POLY_LDS
-        double rg_lon[15], rg_lat[15];
-#endif
+        // ---- lateral polynomial: sampling.py:226-238, 268-270
+        const int L = cin.L;
+        const double s0 = cin.s0;
+        const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
+        const double *const prow = a.profile + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n;
         {
-            Poly lon, lat;
-            double lat_T;
-            if (COEFFS_IN) {
-                lon = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
-                lat = {cin.v[6], cin.v[7], cin.v[8], cin.v[9], cin.v[10], cin.v[11]};
-                lat_T = 0.0;
-            } else {
-                const double T = cin.v[0];
-                if (a.lon_mode == RP_LON_STOPPING)
-                    lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], cin.v[1], 0.0, 0.0, T);  // sampling.py:259-263
-                else
-                    lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, cin.v[1]);             // sampling.py:254-258
-                lat_T = T;
-                if (low) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
-                    double sg = lon.pos(T) - a.x0_lon[0];
-                    lat_T = sg <= 0.0 ? T : sg;
-                }
-                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[2], 0.0, 0.0, lat_T);  // sampling.py:227
-            }
-#if !RP_POLY_LDS
-            park_poly(rg_lon, lon);
-            park_poly(rg_lat, lat);
-#endif
-            if (gl == 0) {   // park the coefficients (same-wave LDS ordering makes them visible to the group)
-#if RP_POLY_LDS
-                park_poly(gs_poly, lon);
-                park_poly(gs_poly + 15, lat);
-#endif
-                if (a.coeffs && valid) {
-                    double *o = a.coeffs + 13 * slot;
-                    o[0] = lon.c0; o[1] = lon.c1; o[2] = lon.c2; o[3] = lon.c3; o[4] = lon.c4; o[5] = lon.c5;
-                    o[6] = lat.c0; o[7] = lat.c1; o[8] = lat.c2; o[9] = lat.c3; o[10] = lat.c4; o[11] = lat.c5;
-                    o[12] = lat_T;
-                }
-            }
+            Poly lat;
+            if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
+            else lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
+            if (gl == 0) park_poly(gs_poly, lat);   // same-wave LDS ordering makes it visible to the group
         }
-        L = L > n ? n : (L < 1 ? 1 : L);
-        RP_STAMP(2);   // polynomials ready
-
-        // ---- pre-filter, reactive_planner.py:796-805 (label stays None) ----
-        uint32_t pre_reason = RP_REASON_NONE;
-        if (!draw) {
-            bool bad_a = false, bad_v = false;
-#pragma nounroll
-            for (int c = 0; c < nchunks; ++c) {
-                const int i = c * G + gl;
-                const double t = (double)i * dt;
-                double sd = lds_vel(POLY_LON, t), sdd = lds_acc(POLY_LON, t);
-                if (fabs(sd) < RP_EPS) sd = 0.0;
-                bad_a |= (i < L) && (fabs(sdd) > a.a_max);
-                bad_v |= (i < L) && (sd < -RP_EPS);
-            }
-            const bool any_a = group_ballot<G>(bad_a, gbase) != 0, any_v = group_ballot<G>(bad_v, gbase) != 0;
-            pre_reason = any_a ? RP_REASON_ACCELERATION : (any_v ? RP_REASON_VELOCITY : RP_REASON_NONE);
-        }
+        RP_STAMP(2);   // polynomial ready
 
         // per-candidate carried state
         int fail_step = -1, ood_step = -1;
@@ -335,13 +413,21 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int i = base + gl;
                 const bool live = i <= N;
                 const bool act = i < L;
+                const int il = live ? i : N;   // clamp dead lanes into the profile rows
 
-                // -- polynomial evaluation, reactive_planner.py:733-777
+                // -- this step of the pair's longitudinal profile (coalesced: lanes = consecutive steps)
+                const double *pr = prow + il;
+                double s = pr[(size_t)PF_S * n], sd = pr[(size_t)PF_SD * n], sdd = pr[(size_t)PF_SDD * n];
+                const double inv_sd = pr[(size_t)PF_INV_SD * n], th_ref = pr[(size_t)PF_TH_REF * n];
+                const double k_r = pr[(size_t)PF_KR * n], k_r_d = pr[(size_t)PF_KRD * n];
+                const double px = pr[(size_t)PF_PX * n], py = pr[(size_t)PF_PY * n];
+                const double nx = pr[(size_t)PF_NX * n], ny = pr[(size_t)PF_NY * n];
+                const bool s_in_dom = pr[(size_t)PF_INDOM * n] != 0.0;
+
+                // -- lateral polynomial, reactive_planner.py:756-777
                 const double t = (double)i * dt;
-                double s = lds_pos(POLY_LON, t), sd = lds_vel(POLY_LON, t), sdd = lds_acc(POLY_LON, t);
-                const double tau = low ? s - POLY_LON[0] : t;   // s[0] == c0 exactly (:762)
-                double d = lds_pos(POLY_LAT, tau), dd = lds_vel(POLY_LAT, tau), ddd = lds_acc(POLY_LAT, tau);
-                if (fabs(sd) < RP_EPS) sd = 0.0;
+                const double tau = low ? s - s0 : t;
+                double d = poly_pos(gs_poly, tau), dd = poly_vel(gs_poly, tau), ddd = poly_acc(gs_poly, tau);
                 if (fabs(dd) < RP_EPS) dd = 0.0;
                 if (store_ok && act) {   // curvilinear rows of valid steps are final here
                     double *o = orow + i;
@@ -352,13 +438,12 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     o[(size_t)RP_D_DOT * n] = dd;
                     o[(size_t)RP_D_DDOT * n] = ddd;
                 }
-                RP_STAMP(3);   // polynomial evaluation
+                RP_STAMP(3);   // profile loads + polynomial evaluation
 
                 // -- d', d'' (:810-832)
-                const bool moving = sd > 0.001;
+                const bool moving = inv_sd > 0.0;
                 double dp, dpp;
                 if (!low) {
-                    const double inv_sd = moving ? rp_rcp(sd) : 0.0;
                     dp = dd * inv_sd;
                     const double ddot = ddd - dp * sdd;
                     dpp = ddot * inv_sd * inv_sd;
@@ -366,22 +451,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     dp = dd;
                     dpp = ddd;
                 }
-
-                // -- segment lookup + interpolation factors (:835-839); Python's negative index wraps
-                const int ub = a.n_buckets > 0
-                                   ? upper_bound_bucket(t_pos, t_bucket, n_ref, a.n_buckets, a.bucket_inv_h, pos_first, pos_last, s)
-                                   : upper_bound(t_pos, n_ref, a.search_iters, s);
-                const int s_idx = (ub == n_ref) ? -1 : ub - 1;
-                const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
-                const double p0 = t_pos[k0], inv_len = t_inv[k0];
-                const double ds = s - p0;
-                const double lam = ds * inv_len;
-                const double th0 = t_theta[k0];
-                const double th_ref = make_valid_orientation((t_theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
-                const double c0 = t_curv[k0], cd0 = t_curv_d[k0];
-                const double k_r = (t_curv[k1] - c0) * lam + c0;              // :876-880
-                const double k_r_d = (t_curv_d[k1] - cd0) * lam + cd0;
-                RP_STAMP(4);   // lookup + interpolation
 
                 // -- orientations (:842-873) incl. the standstill carry of :866
                 const bool use_atan = moving || low;
@@ -452,16 +521,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 }
                 RP_STAMP(7);   // constraints + first-failure vote
 
-                // -- (s, d) -> (x, y), reactive_planner.py:908-917
-                const bool in_dom = s >= pos_first && s <= pos_last && fabs(d) <= a.proj_d_limit;
-                int k = ub - 1;
-                k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
-                const double lam2 = (s - t_pos[k]) * t_inv[k];
-                const double bx = t_x[k], by = t_y[k], ux0 = t_tx[k], uy0 = t_ty[k];
-                const double px = bx + lam2 * (t_x[k + 1] - bx), py = by + lam2 * (t_y[k + 1] - by);
-                const double ax = ux0 + lam2 * (t_tx[k + 1] - ux0), ay = uy0 + lam2 * (t_ty[k + 1] - uy0);
-                const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
-                double x = px - d * (ay * inv_tn), y = py + d * (ax * inv_tn);
+                // -- (s, d) -> (x, y) = foot point + d * unit normal, reactive_planner.py:908-917
+                const bool in_dom = s_in_dom && fabs(d) <= a.proj_d_limit;
+                double x = px + d * nx, y = py + d * ny;
                 if (__any(act && !in_dom) || ood_step >= 0) {   // wave-uniform ("ood_step" alone is group-uniform: harmless)
                     const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
                     if (om && ood_step < 0) ood_step = base + __ffsll((unsigned long long)om) - 1;
@@ -545,7 +607,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     if (!ONE_CHUNK && c + 1 < nchunks) {
                         cumx = group_bcast<G>(scx, G - 1);
                         cumy = group_bcast<G>(scy, G - 1);
-                        theta_carry = group_bcast<G>(th_gl, G - 1);   // only matters for valid steps; keep consistent
                     }
                 }
                 RP_STAMP(9);   // extension + scans + stores of extended steps
