@@ -19,7 +19,7 @@
 
 // ------------------------------------------------------------------------------------------------
 // group-level cross-lane helpers (all 64 lanes of the wave must execute them).
-// A group is G = 32 or 64 consecutive lanes = 2 or 4 DPP rows of 16.  Neighbour moves, sums and
+// A group is G = 16, 32 or 64 consecutive lanes = 1, 2 or 4 DPP rows of 16.  Neighbour moves, sums and
 // prefix sums use DPP (plain VALU, no LDS round trip); only broadcasts from a run-time lane use
 // ds_bpermute (__shfl).
 // ------------------------------------------------------------------------------------------------
@@ -58,7 +58,7 @@ __device__ __forceinline__ double group_sum_last(double v) {
     v += dpp_f64<DPP_ROW_ROR4, 0xf>(v);
     v += dpp_f64<DPP_ROW_ROR2, 0xf>(v);
     v += dpp_f64<DPP_ROW_ROR1, 0xf>(v);          // every lane: sum of its row
-    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);       // rows 1, 3 += row 0, 2
+    if (G >= 32) v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);   // rows 1, 3 += row 0, 2
     if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // rows 2, 3 += lane 31 (rows 0 + 1)
     return v;
 }
@@ -70,7 +70,7 @@ __device__ __forceinline__ double group_scan(double v) {
     v += dpp_f64<DPP_ROW_SHR2, 0xf>(v);
     v += dpp_f64<DPP_ROW_SHR4, 0xf>(v);
     v += dpp_f64<DPP_ROW_SHR8, 0xf>(v);          // inclusive scan inside each row of 16
-    v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);       // rows 1, 3 += total of row 0, 2
+    if (G >= 32) v += dpp_f64<DPP_ROW_BCAST15, 0xa>(v);   // rows 1, 3 += total of row 0, 2
     if (G == 64) v += dpp_f64<DPP_ROW_BCAST31, 0xc>(v);   // rows 2, 3 += total of rows 0 + 1
     return v;
 }

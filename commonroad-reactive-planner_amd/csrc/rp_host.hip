@@ -147,16 +147,28 @@ void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
     else launch_eval_tc<G, MAT, CIN, false>(c, ka, grid);
 }
 
-// G = 32 packs two candidates into one wavefront when the horizon fits (N + 1 <= 32).
-void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin) {
-    const bool g32 = ka.N + 1 <= 32;
-    if (g32) {
-        if (mat) { if (cin) launch_eval_t<32, true, true>(c, ka, grid); else launch_eval_t<32, true, false>(c, ka, grid); }
-        else     { if (cin) launch_eval_t<32, false, true>(c, ka, grid); else launch_eval_t<32, false, false>(c, ka, grid); }
-    } else {
-        if (mat) { if (cin) launch_eval_t<64, true, true>(c, ka, grid); else launch_eval_t<64, true, false>(c, ka, grid); }
-        else     { if (cin) launch_eval_t<64, false, true>(c, ka, grid); else launch_eval_t<64, false, false>(c, ka, grid); }
+// Lanes per candidate.  The time axis is cut into step blocks of G lanes; fewer lanes per candidate
+// mean more candidates per wavefront (fewer wavefronts for a batch that would otherwise need more
+// than one residency round) at the price of a longer dependent chain per wavefront.
+int lanes_per_candidate(const rp_ctx *c, int N, int64_t count) {
+    if (const char *e = std::getenv("RP_AMD_G")) {
+        int g = std::atoi(e);
+        if (g == 16 || g == 32 || g == 64) return g;
     }
+    (void)c; (void)count;
+    return (N + 1 <= 32) ? 32 : 64;
+}
+
+template <int G>
+void launch_eval_g(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin) {
+    if (mat) { if (cin) launch_eval_t<G, true, true>(c, ka, grid); else launch_eval_t<G, true, false>(c, ka, grid); }
+    else     { if (cin) launch_eval_t<G, false, true>(c, ka, grid); else launch_eval_t<G, false, false>(c, ka, grid); }
+}
+
+void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int G) {
+    if (G == 16) launch_eval_g<16>(c, ka, grid, mat, cin);
+    else if (G == 32) launch_eval_g<32>(c, ka, grid, mat, cin);
+    else launch_eval_g<64>(c, ka, grid, mat, cin);
 }
 
 template <int G, bool CIN>
@@ -178,8 +190,7 @@ void launch_lon(rp_ctx *c, const KArgs &ka, bool cin) {
     else         { if (cin) launch_lon_t<64, true>(c, ka, grid); else launch_lon_t<64, false>(c, ka, grid); }
 }
 
-int eval_grid(const rp_ctx *c, int64_t count, int N) {
-    const int G = (N + 1 <= 32) ? 32 : 64;
+int eval_grid(const rp_ctx *c, int64_t count, int G) {
     const int gpb = RP_BLOCK / G;
     int64_t blocks = (count + gpb - 1) / gpb;
     int64_t cap = (int64_t)c->num_cus * kBlocksPerCU;
@@ -242,7 +253,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
     ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
     const int64_t count = ka.count;
-    const int grid = eval_grid(c, count, ka.N);
+    const int G = lanes_per_candidate(c, ka.N, count);
+    const int grid = eval_grid(c, count, G);
     if (grid > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
@@ -269,7 +281,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             launch_lon(c, ka, cin);
         }
         if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (count > 0) launch_eval(c, ka, grid, mat, cin);
+        if (count > 0) launch_eval(c, ka, grid, mat, cin, G);
         if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         if (count == 0) n_partials = 0;
     } else {
@@ -301,7 +313,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.coeffs = nullptr;
         kw.partials = nullptr;
-        launch_eval(c, kw, 1, true, cin);
+        launch_eval(c, kw, 1, true, cin, G);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
@@ -317,6 +329,18 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
         for (int k = 1; k < 15; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        std::fprintf(stderr, "\n");
+    }
+#endif
+#ifdef RP_TIMELINE
+    if (std::getenv("RP_AMD_PRINT_STAMPS")) {
+        std::vector<unsigned long long> tl(2 * 4096);
+        HIP_TRY(c, hipMemcpy(tl.data(), c->d_debug + 32, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < grid && b < 4096; ++b) { t0 = std::min(t0, tl[2 * b]); t1 = std::max(t1, tl[2 * b + 1]); }
+        std::fprintf(stderr, "timeline: %d blocks, span %llu cycles; per block (start,dur):", grid, t1 - t0);
+        for (int b = 0; b < grid && b < 4096; b += std::max(1, grid / 24))
+            std::fprintf(stderr, " b%d(%llu,%llu)", b, tl[2 * b] - t0, tl[2 * b + 1] - tl[2 * b]);
         std::fprintf(stderr, "\n");
     }
 #endif
@@ -356,9 +380,9 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
-#ifdef RP_STAMPS
-    HIP_TRY(c, hipMalloc((void **)&c->d_debug, 32 * sizeof(unsigned long long)));
-    HIP_TRY(c, hipMemset(c->d_debug, 0, 32 * sizeof(unsigned long long)));
+#if defined(RP_STAMPS) || defined(RP_TIMELINE)
+    HIP_TRY(c, hipMalloc((void **)&c->d_debug, (32 + 2 * 4096) * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
 #endif
     HIP_TRY(c, hipMemset(c->d_obs, 0, sizeof(ObsTables)));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_single, sizeof(int64_t), hipHostMallocDefault));
@@ -648,7 +672,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
     launch_lon(c, kw, c->last_coeffs);
-    launch_eval(c, kw, 1, true, c->last_coeffs);
+    launch_eval(c, kw, 1, true, c->last_coeffs, lanes_per_candidate(c, kw.N, 1));
     const size_t bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -105,6 +105,19 @@ struct DevResult {
 #else
 #define RP_STAMP(k) do { } while (0)
 #endif
+// Per-block timeline (diagnostic build -DRP_TIMELINE): start / end s_memtime of every workgroup.
+#ifdef RP_TIMELINE
+#define RP_TL(slot)                                                                               \
+    do {                                                                                          \
+        if (a.debug && !a.single_index && threadIdx.x == 0) {                                     \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            a.debug[32 + 2 * blockIdx.x + (slot)] = t_;                                           \
+        }                                                                                         \
+    } while (0)
+#else
+#define RP_TL(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t bi) {
     return bi < 0 || c < bc || (c == bc && i < bi);
@@ -271,6 +284,17 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     }
 }
 
+// one step of a longitudinal profile in registers
+struct ProfStep { double f[PF_FIELDS]; };
+
+__device__ __forceinline__ ProfStep load_profile(const double *prow, int n, int il) {
+    const double *pr = prow + il;
+    ProfStep p;
+#pragma unroll
+    for (int k = 0; k < PF_FIELDS; ++k) p.f[k] = pr[(size_t)k * n];
+    return p;
+}
+
 // raw per-candidate inputs of the evaluation kernel, fetched one iteration ahead of their use
 struct CandIn {
     double v[6];   // grid mode: v[0] = lateral sample d;  COEFFS_IN: lateral coefficients
@@ -316,6 +340,7 @@ template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
     const int tid = threadIdx.x;
     RP_STAMP(0);
+    RP_TL(0);
     const int lane = tid & 63;
     const int gl = lane & (G - 1);        // lane inside the group = time step inside the chunk
     const int gbase = lane & ~(G - 1);    // first lane of the group inside the wave
@@ -384,7 +409,11 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int L = cin.L;
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
-        const double *const prow = a.profile + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n;
+        // profile rows are addressed arithmetically (no dependence on the header load just issued)
+        const int64_t pair_slot_ = (COEFFS_IN ? gidx : gidx / a.nD) - a.pair_begin;
+        const double *const prow = a.profile + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
+        // first step block of the profile: requested before the header-dependent polynomial set-up
+        ProfStep pf = load_profile(prow, n, gl <= N ? gl : N);
         {
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
@@ -413,16 +442,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int i = base + gl;
                 const bool live = i <= N;
                 const bool act = i < L;
-                const int il = live ? i : N;   // clamp dead lanes into the profile rows
 
                 // -- this step of the pair's longitudinal profile (coalesced: lanes = consecutive steps)
-                const double *pr = prow + il;
-                double s = pr[(size_t)PF_S * n], sd = pr[(size_t)PF_SD * n], sdd = pr[(size_t)PF_SDD * n];
-                const double inv_sd = pr[(size_t)PF_INV_SD * n], th_ref = pr[(size_t)PF_TH_REF * n];
-                const double k_r = pr[(size_t)PF_KR * n], k_r_d = pr[(size_t)PF_KRD * n];
-                const double px = pr[(size_t)PF_PX * n], py = pr[(size_t)PF_PY * n];
-                const double nx = pr[(size_t)PF_NX * n], ny = pr[(size_t)PF_NY * n];
-                const bool s_in_dom = pr[(size_t)PF_INDOM * n] != 0.0;
+                if (!ONE_CHUNK && c > 0) pf = load_profile(prow, n, live ? i : N);   // dead lanes clamp into the rows
+                double s = pf.f[PF_S], sd = pf.f[PF_SD], sdd = pf.f[PF_SDD];
+                const double inv_sd = pf.f[PF_INV_SD], th_ref = pf.f[PF_TH_REF];
+                const double k_r = pf.f[PF_KR], k_r_d = pf.f[PF_KRD];
+                const double px = pf.f[PF_PX], py = pf.f[PF_PY], nx = pf.f[PF_NX], ny = pf.f[PF_NY];
+                const bool s_in_dom = pf.f[PF_INDOM] != 0.0;
 
                 // -- lateral polynomial, reactive_planner.py:756-777
                 const double t = (double)i * dt;
@@ -687,6 +714,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         }
     }
     RP_STAMP(14);
+    RP_TL(1);
 }
 
 // ------------------------------------------------------------------------------------------------
