@@ -134,10 +134,20 @@ int ensure_stage(rp_ctx *c, size_t need) {
     return RP_OK;
 }
 
+constexpr size_t kStageOutLimit = 65536;   // LDS bytes per workgroup up to which state rows are staged for linear copy-out
+
+template <int G, bool MAT, bool CIN, bool COLL, bool STAGE>
+void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+}
+
 template <int G, bool MAT, bool CIN, bool COLL>
 void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
-    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
-    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+    const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
+    const bool stage = MAT && !ka.single_index && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
+    if (MAT && stage) launch_eval_tcs<G, MAT, CIN, COLL, true>(c, ka, grid, tile);
+    else launch_eval_tcs<G, MAT, CIN, COLL, false>(c, ka, grid, 0);
 }
 
 template <int G, bool MAT, bool CIN>
@@ -150,13 +160,16 @@ void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
 // Lanes per candidate.  The time axis is cut into step blocks of G lanes; fewer lanes per candidate
 // mean more candidates per wavefront (fewer wavefronts for a batch that would otherwise need more
 // than one residency round) at the price of a longer dependent chain per wavefront.
-int lanes_per_candidate(const rp_ctx *c, int N, int64_t count) {
+int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
     if (const char *e = std::getenv("RP_AMD_G")) {
         int g = std::atoi(e);
         if (g == 16 || g == 32 || g == 64) return g;
     }
     (void)c; (void)count;
-    return (N + 1 <= 32) ? 32 : 64;
+    // measured on MI355X (profiles/r01_lanes_per_candidate.txt): without state rows 16 lanes per candidate
+    // win at every horizon; with state rows long horizons want whole-wavefront rows (512-byte runs)
+    if (!mat) return 16;
+    return (N + 1 <= 32) ? 16 : 64;
 }
 
 template <int G>
@@ -253,7 +266,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
     ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
     const int64_t count = ka.count;
-    const int G = lanes_per_candidate(c, ka.N, count);
+    const int G = lanes_per_candidate(c, ka.N, count, mat);
     const int grid = eval_grid(c, count, G);
     if (grid > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
@@ -672,7 +685,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
     launch_lon(c, kw, c->last_coeffs);
-    launch_eval(c, kw, 1, true, c->last_coeffs, lanes_per_candidate(c, kw.N, 1));
+    launch_eval(c, kw, 1, true, c->last_coeffs, lanes_per_candidate(c, kw.N, 1, true));
     const size_t bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

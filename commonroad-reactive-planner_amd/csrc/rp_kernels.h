@@ -17,7 +17,8 @@
 
 #define RP_BLOCK 256  // 4 wavefronts per workgroup
 #ifndef RP_WAVES_PER_SIMD
-#define RP_WAVES_PER_SIMD 4  // register budget of the evaluation kernel: 512 / 4 = 128 VGPRs
+#define RP_WAVES_PER_SIMD 2  // register budget of the evaluation kernel: 512 / 2 = 256 VGPRs (no scratch spills;
+                             // measured faster than 3 or 4 waves with spills, profiles/r01_occupancy_ab.txt)
 #endif
 
 // Everything the evaluation kernel needs; passed by value (kernarg segment).
@@ -336,8 +337,13 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) 
 //   * divisions by quantities reused several times (s_dot, 1 - k_r d, segment length) become one
 //     Newton-refined reciprocal each; threshold tests are rearranged to multiplications.
 // ------------------------------------------------------------------------------------------------
-template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK>
+// STAGE_OUT (with MAT): the state rows of the candidates of a wavefront are collected in LDS and leave
+// as ONE linear, 16-byte-per-lane stream -- the [14][N+1] blocks of consecutive candidates are
+// contiguous in memory and 112 (N+1) bytes long, i.e. always 16-byte aligned.  Half the store
+// instructions of row-wise 8-byte stores, every one of them a full 1 KiB.
+template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE_OUT>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
+    extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1]
     const int tid = threadIdx.x;
     RP_STAMP(0);
     RP_TL(0);
@@ -434,7 +440,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             double kappa_carry = 0.0;
             double cumx = 0.0, cumy = 0.0;
             const bool store_ok = MAT && valid && pre_reason == RP_REASON_NONE;
-            double *const orow = MAT ? a.states + ((size_t)slot * RP_N_ARRAYS) * (size_t)n : nullptr;
+            double *const orow = !MAT ? nullptr
+                                 : (STAGE_OUT ? lds_out + (size_t)grp * RP_N_ARRAYS * (size_t)n
+                                              : a.states + ((size_t)slot * RP_N_ARRAYS) * (size_t)n);
 
 #pragma nounroll
             for (int c = 0; c < nchunks; ++c) {   // wave-uniform
@@ -662,6 +670,20 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0));
         }
         RP_STAMP(12);  // state stores issued, chunk loop done
+        if (MAT && STAGE_OUT) {   // linear copy-out of this wavefront's candidates (wave-uniform)
+            // blocks are written for every candidate that passed the pre-filter; failed candidates keep
+            // whatever steps were computed (same contract as direct stores)
+            const uint64_t okmask = __ballot(valid && pre_reason == RP_REASON_NONE);
+            if (okmask) {
+                const int blk2 = (RP_N_ARRAYS * n) >> 1;             // double2 pieces per candidate (14 n is even)
+                const double2 *src = reinterpret_cast<const double2 *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n);
+                double2 *dst = reinterpret_cast<double2 *>(a.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n);
+                for (int k = lane; k < GPW * blk2; k += 64) {
+                    const int cand = k / blk2;
+                    if ((okmask >> (cand * G)) & 1ull) dst[k] = src[k];
+                }
+            }
+        }
 
         // ---- label, reason, cost (the group's LAST lane holds the reduced cost and does the bookkeeping) ----
         uint32_t status;
