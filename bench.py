@@ -150,6 +150,21 @@ def main():
             el = time.perf_counter() - t1
             result["fused_mode"] = {"value": C_total * len(kk) / el, "unit": "candidates/s",
                                     "ms_per_step": el / len(kk) * 1e3, "kernel_ms": float(np.mean(kk))}
+        # second half of BASELINE.json's metric: p50 latency of a whole planner.plan() call, Python boundary and
+        # output packing included (production mode), >= 200 replans after 20 warm-ups
+        if base.n_candidates <= 100000:
+            rp = W.make_planner(base, device=local_rank)
+            for _ in range(20):
+                rp.plan()
+            lat = []
+            for _ in range(200):
+                t1 = time.perf_counter()
+                res = rp.plan()
+                lat.append(time.perf_counter() - t1)
+            rp.close()
+            result["plan_latency_ms"] = {"p50": float(np.percentile(lat, 50) * 1e3), "p90": float(np.percentile(lat, 90) * 1e3),
+                                         "n": len(lat), "planned": res is not None,
+                                         "what": "ReactivePlanner.plan() wall time, one sampling level, fused mode"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w, inp, args.cpu_seconds)
     ctx.close()

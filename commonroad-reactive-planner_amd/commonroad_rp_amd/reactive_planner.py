@@ -1,0 +1,546 @@
+"""The planner behind the reference's ``ReactivePlanner`` interface, with the hot path on the GPU.
+
+Two pieces:
+
+``GpuBackendMixin``
+    Overrides exactly the two methods ``plan()`` calls per sampling level
+    (reference: commonroad_rp/reactive_planner.py:620 ``_create_trajectory_bundle`` and :624
+    ``_get_optimal_trajectory``) and routes them through ``librp_amd.so``.  It reads only attributes
+    the reference planner already has (``config, dt, N, horizon, vehicle_params, x_0, _co,
+    sampling_space, cost_function, _low_vel_mode, _draw_traj_set, ...``), so it can be mixed into the
+    reference class itself: ``class Planner(GpuBackendMixin, commonroad_rp.reactive_planner.ReactivePlanner)``
+    (exercised against the real reference class in tests/test_planner_dropin.py).
+
+``ReactivePlanner``
+    A stand-alone planner with the reference's public surface (``reset, set_reference_path,
+    set_collision_checker, set_desired_velocity, set_desired_lon_position, set_cost_function,
+    set_sampling_space, set_*_sampling_parameters, plan, record_state_and_input, ...``) that does not
+    need commonroad-io / commonroad-drivability-checker.  Everything outside the two overridden methods
+    follows the reference's control flow (levels loop :616-636, standstill :638-653, output packing
+    :514-568).
+
+There is no CPU fallback: without the HIP library ``plan()`` raises ``RpLibraryMissing``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import (CHECK_BITS, COST_DEFAULT, COST_EXTERNAL, COST_FAILSAFE, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL,
+                    LON_STOPPING, LON_VELOCITY_KEEPING, PlanInputs, PlanOutput, RpContext, make_cost, make_params)
+from .collision import ObstacleTables
+from .config import ReactivePlannerConfiguration
+from .coordinate_system import CoordinateSystem, interpolate_angle
+from .cost_function import CostFunction, DefaultCostFunction, DefaultCostFunctionFailSafe
+from .polynomial_trajectory import QuarticTrajectory, QuinticTrajectory
+from .sampling import (FixedIntervalSampling, PositionSampling, SamplingSpace, TimeSampling, VelocitySampling,
+                       sampling_space_factory)
+from .state import CustomState, ReactivePlannerState, Trajectory
+from .trajectories import FeasibilityStatus, TrajectorySample, bind_states, label_from_status
+
+logger = logging.getLogger("RP_LOGGER")
+
+
+class _CostView:
+    def __init__(self, cost):
+        self.cost = cost
+
+
+class GpuTrajectoryBundle:
+    """What ``_create_trajectory_bundle`` hands to ``_get_optimal_trajectory`` on the GPU path: the
+    sample grids (or, for foreign sampling spaces, explicit polynomials) instead of one Python object
+    per candidate.  ``trajectories`` materialises the objects on demand for code that wants them."""
+
+    def __init__(self, planner, level: int, x_0_lon, x_0_lat, grids=None, samples: Optional[List[TrajectorySample]] = None):
+        self._planner = planner
+        self.level = level
+        self.x_0_lon, self.x_0_lat = list(x_0_lon), list(x_0_lat)
+        self.grids = grids            # (T, traj_len, L, D) or None
+        self._samples = samples       # foreign sampling space: list of TrajectorySample
+        self._is_sorted = False
+        self.costs: Optional[np.ndarray] = None   # per-candidate costs after _get_optimal_trajectory
+
+    @property
+    def n_candidates(self) -> int:
+        if self.grids is not None:
+            T, _, L, D = self.grids
+            return len(T) * len(L) * len(D)
+        return len(self._samples)
+
+    @property
+    def trajectories(self) -> List[TrajectorySample]:
+        if self._samples is None:
+            p = self._planner
+            self._samples = p.sampling_space.generate_trajectories_at_level(
+                self.level, self.x_0_lon, self.x_0_lat, p.config.sampling.longitudinal_mode, p._low_vel_mode)
+            if p.config.sampling.longitudinal_mode == "stopping":
+                self._samples = [t for t in self._samples if t.trajectory_long.x_0[0] < t.trajectory_long.x_d[0]]
+        return self._samples
+
+    @property
+    def empty(self) -> bool:
+        return self.n_candidates == 0
+
+    def min_costs(self):
+        c = self.costs
+        return _CostView(np.float64(np.nanmin(c))) if c is not None and np.any(~np.isnan(c)) else None
+
+    def max_costs(self):
+        c = self.costs
+        return _CostView(np.float64(np.nanmax(c))) if c is not None and np.any(~np.isnan(c)) else None
+
+
+class GpuBackendMixin:
+    """Routes the per-level hot path of ``plan()`` through the HIP library."""
+
+    #: factory ``device -> context`` with the interface of ``_capi.RpContext``
+    backend_factory = RpContext
+    gpu_device = 0
+
+    # ---- context and tables -----------------------------------------------------------------------
+    def _gpu_ctx(self):
+        ctx = getattr(self, "_rp_ctx", None)
+        if ctx is None:
+            ctx = self._rp_ctx = self.backend_factory(self.gpu_device)
+            self._rp_ref_id = None
+            self._rp_obs_id = None
+        co = self._co
+        if self._rp_ref_id is not co:
+            ctx.set_coordinate_system(co)
+            self._rp_ref_id = co
+        tables = getattr(self, "_obstacle_tables", None)
+        if self._rp_obs_id is not tables or tables is None:
+            if tables is None:
+                tables = self._obstacle_tables = ObstacleTables()
+            ctx.set_obstacles(tables)
+            self._rp_obs_id = tables
+        return ctx
+
+    def set_collision_checker(self, scenario=None, collision_checker=None, road_boundary_obstacle=None):
+        """When mixed into the reference class: keep its pycrcc checker (other code may use it) and, in
+        addition, extract the obstacle tables the GPU check needs from the same scenario."""
+        parent = getattr(super(), "set_collision_checker", None)
+        if parent is not None:
+            parent(scenario=scenario, collision_checker=collision_checker, road_boundary_obstacle=road_boundary_obstacle)
+        if scenario is not None:
+            self.set_obstacle_tables(ObstacleTables.from_scenario(scenario))
+
+    def set_obstacle_tables(self, tables: Optional[ObstacleTables]):
+        """Obstacle content for the GPU collision check (what the reference keeps inside the opaque
+        pycrcc checker, reactive_planner.py:234-251)."""
+        self._obstacle_tables = tables if tables is not None else ObstacleTables()
+
+    def close(self):
+        ctx = getattr(self, "_rp_ctx", None)
+        if ctx is not None:
+            ctx.close()
+            self._rp_ctx = None
+
+    # ---- per-call inputs ---------------------------------------------------------------------------
+    def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
+        cfg, vp = self.config, self.vehicle_params
+        mask = 0
+        for c in cfg.planning.constraints_to_check:
+            mask |= CHECK_BITS[c]
+        return make_params(dt=self.dt, N=self.N, factor=cfg.planning.factor, time_step0=int(self.x_0.time_step),
+                           low_vel_mode=self._low_vel_mode,
+                           lon_mode=LON_STOPPING if cfg.sampling.longitudinal_mode == "stopping" else LON_VELOCITY_KEEPING,
+                           constraint_mask=mask, flags=flags, x0_lon=x_0_lon, x0_lat=x_0_lat,
+                           x0_orientation=self.x_0.orientation, wheelbase=vp.wheelbase, wb_rear_axle=vp.wb_rear_axle,
+                           length=vp.length, width=vp.width, a_max=vp.a_max, v_switch=vp.v_switch,
+                           delta_max=vp.delta_max, v_delta_max=vp.v_delta_max)
+
+    def _gpu_cost(self):
+        """Cost parameters for the fused path, or ``None`` for a plug-in cost function."""
+        cf = self.cost_function
+        if type(cf) is DefaultCostFunction or type(cf).__name__ == "DefaultCostFunction" and \
+                type(cf).evaluate.__qualname__ == "DefaultCostFunction.evaluate":
+            return make_cost(COST_DEFAULT, w_a=cf.w_a, desired_speed=cf.desired_speed, desired_d=cf.desired_d,
+                             desired_s=cf.desired_s)
+        if type(cf) is DefaultCostFunctionFailSafe or type(cf).__name__ == "DefaultCostFunctionFailSafe" and \
+                type(cf).evaluate.__qualname__ == "DefaultCostFunctionFailSafe.evaluate":
+            return make_cost(COST_FAILSAFE)
+        return None
+
+    # ---- the two overridden methods ----------------------------------------------------------------
+    def _create_trajectory_bundle(self, x_0_lon, x_0_lat, samp_level: int) -> GpuTrajectoryBundle:
+        logger.info("===== Sampling trajectories ... =====")
+        logger.info(f"Sampling density {samp_level + 1} of {self.sampling_level}")
+        sp = self.sampling_space
+        if hasattr(sp, "grids_at_level"):
+            grids = sp.grids_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode)
+            bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, grids=grids)
+        else:   # foreign sampling space: its own objects, polynomials handed to the device explicitly
+            samples = sp.generate_trajectories_at_level(samp_level, x_0_lon, x_0_lat,
+                                                        self.config.sampling.longitudinal_mode, self._low_vel_mode)
+            if self.config.sampling.longitudinal_mode == "stopping":
+                samples = [t for t in samples if t.trajectory_long.x_0[0] < t.trajectory_long.x_d[0]]
+            bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, samples=samples)
+        logger.info(f"Number of trajectory samples: {bundle.n_candidates}")
+        return bundle
+
+    def _get_optimal_trajectory(self, bundle: GpuTrajectoryBundle) -> Optional[TrajectorySample]:
+        logger.info("===== Checking trajectories ... =====")
+        self._reset_statistics()
+        ctx = self._gpu_ctx()
+        t0 = time.time()
+        cost = self._gpu_cost()
+        external = cost is None
+        flags = 0
+        if self._draw_traj_set:
+            flags |= FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL
+        if external:
+            flags |= FLAG_MATERIALIZE_ALL
+            cost = make_cost(COST_EXTERNAL)
+        params = self._gpu_params(bundle.x_0_lon, bundle.x_0_lat, flags)
+
+        if bundle.grids is not None:
+            T, traj_len, L, D = bundle.grids
+            if len(T) * len(L) * len(D) == 0:
+                self._infeasible_count_kinematics = 0
+                return None
+            out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D))
+        else:
+            samples = bundle.trajectories
+            if not samples:
+                self._infeasible_count_kinematics = 0
+                return None
+            lon = np.array([t.trajectory_long.coeffs for t in samples])
+            lat = np.array([t.trajectory_lat.coeffs for t in samples])
+            lon_T = np.array([t.trajectory_long.delta_tau for t in samples], dtype=float)
+            tl = np.array([len(np.arange(0, np.round(tt + self.dt, 5), self.dt)) for tt in lon_T], dtype=np.int32)
+            out = ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl)
+        logger.info(f"Kinematic checks took:  \t{time.time() - t0:.7f}s")
+
+        if external:   # plug-in CostFunction: states from the device, evaluate() in Python, argmin on the device
+            out = self._gpu_external_costs(ctx, bundle, out)
+
+        # statistics the reference keeps (reactive_planner.py:127-145, 1119)
+        self._infeasible_count_kinematics = out.n_infeasible_kinematics
+        self._infeasible_count_collision = out.n_collision_before_best
+        for i, name in enumerate(_capi.REASON_NAMES[1:6], start=1):
+            if name in self._infeasible_reason_dict:
+                self._infeasible_reason_dict[name] = int(out.reason_counts[i])
+        status, costs = ctx.fetch_status() if (self._draw_traj_set or bundle.grids is None or self._wants_costs()) else (None, None)
+        bundle.costs = costs
+        if self._draw_traj_set:
+            self.stored_trajectories = self._gpu_stored_trajectories(ctx, bundle, status, costs)
+        if out.best_index < 0:
+            return None
+        return self._gpu_winner_sample(bundle, out)
+
+    def _wants_costs(self) -> bool:
+        # plan()'s standstill branch reads bundle.min_costs()/max_costs() (reactive_planner.py:650-651)
+        return getattr(self.x_0, "velocity", 1.0) <= 0.05
+
+    # ---- helpers ----------------------------------------------------------------------------------
+    def _gpu_candidate_sample(self, bundle: GpuTrajectoryBundle, index: int, lon_coeffs=None, lat_coeffs=None,
+                              lat_T=None) -> TrajectorySample:
+        if bundle.grids is None:
+            return bundle.trajectories[index]
+        T, _, L, D = bundle.grids
+        nLD = len(L) * len(D)
+        iT, r = divmod(index, nLD)
+        iL, iD = divmod(r, len(D))
+        x0_lon, x0_lat = np.asarray(bundle.x_0_lon, dtype=float), np.asarray(bundle.x_0_lat, dtype=float)
+        if self.config.sampling.longitudinal_mode == "stopping":
+            lon = QuinticTrajectory(tau_0=0, delta_tau=T[iT], x_0=x0_lon, x_d=np.array([L[iL], 0.0, 0.0]), coeffs=lon_coeffs)
+        else:
+            lon = QuarticTrajectory(tau_0=0, delta_tau=T[iT], x_0=x0_lon, x_d=np.array([L[iL], 0.0]), coeffs=lon_coeffs)
+        tau = T[iT]
+        if lat_T is not None and not np.isnan(lat_T):
+            tau = lat_T
+        elif self._low_vel_mode:
+            s_goal = lon.evaluate_state_at_tau(T[iT])[0] - x0_lon[0]
+            tau = T[iT] if s_goal <= 0 else s_goal
+        lat = QuinticTrajectory(tau_0=0, delta_tau=tau, x_0=x0_lat, x_d=np.array([D[iD], 0.0, 0.0]), coeffs=lat_coeffs)
+        return TrajectorySample(self.horizon, self.dt, lon, lat)
+
+    def _gpu_winner_sample(self, bundle, out: PlanOutput) -> TrajectorySample:
+        s = self._gpu_candidate_sample(bundle, out.best_index, out.best_lon_coeffs, out.best_lat_coeffs, out.best_lat_T)
+        bind_states(s, out.best_states, 1, out.best_cost)
+        s._cost_function = self.cost_function
+        return s
+
+    def _gpu_external_costs(self, ctx, bundle, out: PlanOutput) -> PlanOutput:
+        status, _ = ctx.fetch_status()
+        states = ctx.fetch_states()
+        costs = np.full(len(status), np.nan)
+        for i in np.flatnonzero(((status & 3) == 1) | ((status & 3) == 3)):
+            s = self._gpu_candidate_sample(bundle, int(i))
+            bind_states(s, states[i], int(status[i]))
+            costs[i] = float(self.cost_function.evaluate(s))
+        return ctx.select(costs)
+
+    def _gpu_stored_trajectories(self, ctx, bundle, status, costs) -> List[TrajectorySample]:
+        """``stored_trajectories = feasible + infeasible`` of draw_traj_set (reactive_planner.py:1122-1123)."""
+        states = ctx.fetch_states()
+        feas, infeas = [], []
+        for i in range(len(status)):
+            lab = int(status[i]) & 3
+            s = self._gpu_candidate_sample(bundle, i)
+            c = None if np.isnan(costs[i]) else float(costs[i])
+            bind_states(s, states[i], int(status[i]), c)
+            (feas if lab in (1, 3) else infeas).append(s)
+        return feas + infeas
+
+
+class ReactivePlanner(GpuBackendMixin):
+    """Stand-alone planner with the reference's public interface (reactive_planner.py:52-1159)."""
+
+    def __init__(self, config: ReactivePlannerConfiguration, backend_factory=None, device: int = 0):
+        if backend_factory is not None:
+            self.backend_factory = backend_factory
+        self.gpu_device = device
+        self.dt: float = config.planning.dt
+        self.N: int = config.planning.time_steps_computation
+        self.horizon: float = config.planning.dt * config.planning.time_steps_computation
+        self.vehicle_params = config.vehicle
+        self.x_0: Optional[ReactivePlannerState] = None
+        self.x_0_cl: Optional[Tuple[List, List]] = None
+        self._co: Optional[CoordinateSystem] = None
+        self._obstacle_tables: Optional[ObstacleTables] = None
+        self._infeasible_count_collision = 0
+        self._infeasible_count_kinematics = 0
+        self._infeasible_reason_dict: Dict = dict()
+        self._optimal_cost = 0.0
+        self._planning_times_list: List = list()
+        self._record_state_list: List[ReactivePlannerState] = list()
+        self._record_input_list: List = list()
+        self.stored_trajectories: Optional[List[TrajectorySample]] = None
+        self._desired_speed: Optional[float] = None
+        self._desired_lon_position: Optional[float] = None
+        self._low_vel_mode = False
+        self._draw_traj_set = config.debug.draw_traj_set and (config.debug.show_plots or config.debug.save_plots)
+        self.config: Optional[ReactivePlannerConfiguration] = None
+        self.reset(config)
+        self.sampling_space: Optional[SamplingSpace] = None
+        self.set_sampling_space()
+        self.sampling_level = config.sampling.num_sampling_levels
+        self.cost_function: Optional[CostFunction] = None
+        self.set_cost_function()
+        self._standstill_lookahead = config.planning.standstill_lookahead
+
+    # ---- read-only views (reactive_planner.py:115-160) ---------------------------------------------
+    coordinate_system = property(lambda self: self._co)
+    reference_path = property(lambda self: self._co.reference)
+    infeasible_count_collision = property(lambda self: self._infeasible_count_collision)
+    infeasible_count_kinematics = property(lambda self: self._infeasible_count_kinematics)
+    infeasible_reason_dict = property(lambda self: self._infeasible_reason_dict)
+    optimal_cost = property(lambda self: self._optimal_cost)
+    planning_times = property(lambda self: self._planning_times_list)
+    record_state_list = property(lambda self: self._record_state_list)
+    record_input_list = property(lambda self: self._record_input_list)
+    collision_checker = property(lambda self: self._obstacle_tables)
+
+    def goal_reached(self) -> bool:
+        x0 = self.x_0.shift_positions_to_center(self.vehicle_params.wb_rear_axle)
+        return bool(self.config.planning_problem.goal.is_reached(x0))
+
+    # ---- set-up (reactive_planner.py:172-389) ------------------------------------------------------
+    def reset(self, config=None, initial_state_cart=None, initial_state_curv=None, collision_checker=None,
+              coordinate_system=None):
+        if config is not None:
+            self.config = config
+        else:
+            assert self.config is not None, "<ReactivePlanner.reset(). No Configuration object provided>"
+        self._reset_statistics()
+        if collision_checker is None:
+            self.set_collision_checker(scenario=self.config.scenario)
+        else:
+            self.set_collision_checker(collision_checker=collision_checker)
+        if coordinate_system is not None:
+            self.set_reference_path(coordinate_system=coordinate_system)
+        if self.x_0 is None and initial_state_cart is None:
+            pp = self.config.planning_problem
+            self.x_0 = ReactivePlannerState.create_from_initial_state(
+                pp.initial_state, self.vehicle_params.wheelbase, self.vehicle_params.wb_rear_axle) if pp else None
+        else:
+            self.x_0 = initial_state_cart if initial_state_cart is not None else self.x_0
+        self.x_0_cl = initial_state_curv if initial_state_curv is not None else self._compute_initial_states(self.x_0)
+
+    def set_collision_checker(self, scenario=None, collision_checker=None, road_boundary_obstacle=None):
+        """``collision_checker`` is an ``ObstacleTables`` here (the GPU path cannot read an opaque pycrcc
+        checker); from a scenario the tables are extracted as ``set_collision_checker`` feeds pycrcc
+        (reactive_planner.py:234-251); ``road_boundary_obstacle``: (n, 6) triangles."""
+        if collision_checker is None:
+            tables = ObstacleTables.from_scenario(scenario, road_boundary_obstacle) if scenario is not None else ObstacleTables()
+        else:
+            assert isinstance(collision_checker, ObstacleTables), "pass commonroad_rp_amd.collision.ObstacleTables"
+            tables = collision_checker
+        self.set_obstacle_tables(tables)
+
+    def set_reference_path(self, reference_path: np.ndarray = None, coordinate_system: CoordinateSystem = None):
+        if coordinate_system is None:
+            assert reference_path is not None, "<set reference path>: Please provide a reference path OR a CoordinateSystem object to the planner."
+            from .workloads import smooth_ref_path
+            self._co = CoordinateSystem(smooth_ref_path(reference_path))
+        else:
+            assert reference_path is None, "<set reference path>: Please provide a reference path OR a CoordinateSystem object to the planner."
+            self._co = coordinate_system
+
+    def set_t_sampling_parameters(self, t_min):
+        self.sampling_space.samples_t = TimeSampling(t_min, self.horizon, self.sampling_level, self.dt)
+
+    def set_d_sampling_parameters(self, delta_d_min, delta_d_max):
+        self.sampling_space.samples_d = PositionSampling(delta_d_min, delta_d_max, self.sampling_level)
+
+    def set_v_sampling_parameters(self, v_min, v_max):
+        self.sampling_space.samples_v = VelocitySampling(v_min, v_max, self.sampling_level)
+
+    def set_s_sampling_parameters(self, s_min, s_max):
+        self.sampling_space.samples_s = PositionSampling(s_min, s_max, self.sampling_level)
+
+    def set_desired_velocity(self, desired_velocity: float = None, current_speed: float = None, stopping: bool = False):
+        self._desired_lon_position = None
+        if desired_velocity is None and self._desired_speed is None:
+            self._desired_speed = float(self.x_0.velocity)
+        else:
+            self._desired_speed = desired_velocity if desired_velocity is not None else self._desired_speed
+        assert self._desired_speed >= 0.0, f"<ReactivePlanner.set_desired_velocity(): desired speed has to be positive. Provided speed{self._desired_speed}>"
+        if not stopping:
+            ref = current_speed if current_speed is not None else self._desired_speed
+            min_v = max(0, ref - (0.125 * self.horizon * self.vehicle_params.a_max))
+            max_v = max(min_v + 5.0, ref + 2)
+            self.set_v_sampling_parameters(min_v, max_v)
+        else:
+            self.set_v_sampling_parameters(v_min=self._desired_speed, v_max=self._desired_speed)
+        cf = self.cost_function
+        if hasattr(cf, "desired_speed"):
+            cf.desired_speed = self._desired_speed
+        if hasattr(cf, "w_a"):
+            cf.w_a = 5
+        if hasattr(cf, "desired_s"):
+            cf.desired_s = self._desired_lon_position
+
+    def set_desired_lon_position(self, lon_position: float, delta_s_min: Optional[float] = None,
+                                 delta_s_max: Optional[float] = None):
+        self._desired_lon_position = lon_position
+        self._desired_speed = 0.0
+        if delta_s_min is None and delta_s_max is None:
+            delta_s_min, delta_s_max = self.config.sampling.s_min, self.config.sampling.s_max
+        self.set_s_sampling_parameters(s_min=lon_position + delta_s_min, s_max=lon_position + delta_s_max)
+        cf = self.cost_function
+        if hasattr(cf, "desired_s"):
+            cf.desired_s = self._desired_lon_position
+        if hasattr(cf, "desired_speed"):
+            cf.desired_speed = self._desired_speed
+        if hasattr(cf, "w_a"):
+            cf.w_a = 1
+
+    def set_cost_function(self, cost_function: CostFunction = None):
+        self.cost_function = cost_function if cost_function else DefaultCostFunction(
+            self._desired_speed, desired_d=0.0, desired_s=self._desired_lon_position)
+
+    def set_sampling_space(self, sampling_space: SamplingSpace = None):
+        self.sampling_space = sampling_space if sampling_space else sampling_space_factory(self.config)
+
+    def record_state_and_input(self, state: ReactivePlannerState):
+        self._record_state_list.append(state)
+        rate = (state.steering_angle - self._record_state_list[-2].steering_angle) / self.dt \
+            if len(self._record_state_list) > 1 else 0.0
+        self._record_input_list.append(dict(time_step=state.time_step, acceleration=state.acceleration,
+                                            steering_angle_speed=rate))
+
+    def _reset_statistics(self):
+        self._optimal_cost = 0
+        self._infeasible_count_kinematics = 0
+        self._infeasible_count_collision = 0
+        for constraint in self.config.planning.constraints_to_check:
+            self._infeasible_reason_dict[constraint] = 0
+
+    # ---- initial state in the curvilinear frame (reactive_planner.py:446-512) ----------------------
+    def _compute_initial_states(self, x_0: ReactivePlannerState):
+        if not self._co or x_0 is None:
+            return None
+        from .workloads import initial_curvilinear_state
+        try:
+            return initial_curvilinear_state(self._co, x_0.position[0], x_0.position[1], x_0.orientation, x_0.velocity,
+                                             acceleration=x_0.acceleration or 0.0, steering_angle=x_0.steering_angle or 0.0,
+                                             low_vel_mode=self._low_vel_mode, wheelbase=self.vehicle_params.wheelbase)
+        except ValueError:
+            logger.critical("Initial state could not be transformed.")
+            raise ValueError("Initial state could not be transformed.")
+
+    # ---- one replanning cycle (reactive_planner.py:570-665) ----------------------------------------
+    def plan(self, current_sampling_level: int = None) -> Optional[tuple]:
+        start = time.time()
+        assert self.x_0 is not None, "<ReactivePlanner.plan(): Planner Cartesian initial state is empty!>"
+        assert self._co is not None, "<ReactivePlanner.plan(): No coordinate system given. Call set_reference_path()>"
+        if not self.x_0_cl:
+            self.x_0_cl = self._compute_initial_states(self.x_0)
+        assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
+        x_0_lon, x_0_lat = self.x_0_cl
+        self._low_vel_mode = bool(self.x_0.velocity < self.config.planning.low_vel_mode_threshold)
+
+        optimal, bundle = None, None
+        i = 1 if current_sampling_level is None else current_sampling_level
+        while optimal is None and i < self.sampling_level:
+            bundle = self._create_trajectory_bundle(x_0_lon, x_0_lat, samp_level=i)
+            optimal = self._get_optimal_trajectory(bundle)
+            if current_sampling_level is not None:
+                break
+            i += 1
+
+        if (optimal is None or optimal.cartesian.v[self._standstill_lookahead] <= 0.05) and self.x_0.velocity <= 0.05:
+            optimal = self._compute_standstill_trajectory()
+            self._optimal_cost = optimal.cost
+
+        result = self._compute_trajectory_pair(optimal) if optimal is not None else None
+        self._planning_times_list.append(time.time() - start)
+        if result is None:
+            logger.warning("Planner failed to find an optimal trajectory with given sampling configuration!")
+        return result
+
+    def _compute_standstill_trajectory(self) -> TrajectorySample:
+        """reactive_planner.py:667-713 (arrays of length N, not N + 1, as in the reference)."""
+        from .trajectories import CartesianSample, CurviLinearSample
+        x_0 = self.x_0
+        x_0_lon, x_0_lat = self.x_0_cl
+        lon = QuarticTrajectory(tau_0=0, delta_tau=self.horizon, x_0=np.asarray(x_0_lon), x_d=np.array([0, 0]))
+        lat = QuinticTrajectory(tau_0=0, delta_tau=self.horizon, x_0=np.asarray(x_0_lat), x_d=np.array([x_0_lat[0], 0, 0]))
+        kappa_0 = np.tan(x_0.steering_angle) / self.vehicle_params.wheelbase
+        p = TrajectorySample(self.horizon, self.dt, lon, lat)
+        a = np.repeat(0.0, self.N)
+        a[1] = -self.x_0.velocity / self.dt
+        rep = lambda v: np.repeat(v, self.N)   # noqa: E731
+        p.cartesian = CartesianSample(rep(x_0.position[0]), rep(x_0.position[1]), rep(x_0.orientation), rep(0.0), a,
+                                      rep(kappa_0), rep(0.0), current_time_step=self.N)
+        ref_pos = self._co.ref_pos
+        s_idx = int(np.argmax(ref_pos > x_0_lon[0])) - 1
+        ref_theta = np.unwrap(self._co.ref_theta)
+        theta_cl = x_0.orientation - interpolate_angle(x_0_lon[0], ref_pos[s_idx], ref_pos[s_idx + 1], ref_theta[s_idx],
+                                                       ref_theta[s_idx + 1])
+        p.curvilinear = CurviLinearSample(rep(x_0_lon[0]), rep(x_0_lat[0]), rep(theta_cl), dd=rep(x_0_lat[1]),
+                                          ddd=rep(x_0_lat[2]), ss=rep(x_0_lon[1]), sss=rep(x_0_lon[2]),
+                                          current_time_step=self.N)
+        return p
+
+    def _compute_trajectory_pair(self, trajectory: TrajectorySample):
+        """Output packing, reactive_planner.py:514-568."""
+        cart_list, cl_list, lon_list, lat_list = [], [], [], []
+        ca, cu = trajectory.cartesian, trajectory.curvilinear
+        factor = self.config.planning.factor
+        for i in range(len(ca.x)):
+            yaw = (ca.theta[i] - ca.theta[i - 1]) / self.dt if i > 0 else self.x_0.yaw_rate
+            cart_list.append(ReactivePlannerState(
+                time_step=self.x_0.time_step + factor * i, position=np.array([ca.x[i], ca.y[i]]), orientation=ca.theta[i],
+                velocity=ca.v[i], acceleration=ca.a[i], yaw_rate=yaw,
+                steering_angle=np.arctan2(self.vehicle_params.wheelbase * ca.kappa[i], 1.0)))
+            cl_list.append(CustomState(time_step=self.x_0.time_step + factor * i, position=np.array([cu.s[i], cu.d[i]]),
+                                       velocity=ca.v[i], acceleration=ca.a[i], orientation=ca.theta[i], yaw_rate=ca.kappa[i]))
+            lon_list.append([cu.s[i], cu.s_dot[i], cu.s_ddot[i]])
+            lat_list.append([cu.d[i], cu.d_dot[i], cu.d_ddot[i]])
+        cart = Trajectory(self.x_0.time_step, cart_list)
+        lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
+        for st in cart.state_list:   # shift_orientation, utility/general.py:49-55
+            while st.orientation < lo:
+                st.orientation += 2 * np.pi
+            while st.orientation > hi:
+                st.orientation -= 2 * np.pi
+        return cart, Trajectory(self.x_0.time_step, cl_list), lon_list, lat_list

@@ -221,4 +221,38 @@ def replicate_for_ranks(w: Workload, world_size: int) -> Workload:
     return Workload(w.name, w.description + f", L densified x{world_size}", inp, w.coordinate_system, w.obstacles)
 
 
+def make_planner(w: Workload, backend_factory=None, device: int = 0, draw: bool = False):
+    """A ``ReactivePlanner`` set up for a workload: same reference path, obstacles, initial state, cost
+    parameters and -- through explicit sample sets at level 1 -- the same (T, L, D) grids, so that
+    ``planner.plan()`` evaluates exactly the workload's candidate batch (used for the p50 plan() latency)."""
+    from .config import ReactivePlannerConfiguration
+    from .reactive_planner import ReactivePlanner
+    from .state import ReactivePlannerState
+    p = w.inputs.params
+    cfg = ReactivePlannerConfiguration.from_dict(dict(
+        planning=dict(dt=p.dt, time_steps_computation=p.N, factor=p.factor,
+                      low_vel_mode_threshold=1e9 if p.low_vel_mode else 0.0),
+        sampling=dict(longitudinal_mode="stopping" if p.lon_mode else "velocity_keeping", num_sampling_levels=2,
+                      t_min=float(max(2 * p.dt, min(w.inputs.T)))),
+        debug=dict(draw_traj_set=draw, show_plots=draw)))
+    rp = ReactivePlanner(cfg, backend_factory=backend_factory, device=device)
+    rp.set_reference_path(coordinate_system=w.coordinate_system)
+    rp.set_collision_checker(collision_checker=w.obstacles)
+    co = w.coordinate_system
+    pos = co.convert_to_cartesian_coords(p.x0_lon[0], p.x0_lat[0])
+    x0 = ReactivePlannerState(time_step=p.time_step0, position=pos, orientation=p.x0_orientation,
+                              velocity=max(p.x0_lon[1], 0.1), steering_angle=0.0, acceleration=0.0, yaw_rate=0.0)
+    rp.reset(initial_state_cart=x0, initial_state_curv=(list(p.x0_lon), list(p.x0_lat)),
+             collision_checker=rp.collision_checker, coordinate_system=co)
+    c = w.inputs.cost
+    rp.set_desired_velocity(desired_velocity=None if math.isnan(c.desired_speed) else c.desired_speed,
+                            current_speed=p.x0_lon[1])
+    sp = rp.sampling_space
+    sp.samples_t._dict_level_to_sample_set[1] = set(float(t) for t in w.inputs.T)
+    sp.samples_v._dict_level_to_sample_set[1] = set(float(v) for v in w.inputs.L)
+    sp.samples_s._dict_level_to_sample_set[1] = set(float(v) for v in w.inputs.L)
+    sp.samples_d._dict_level_to_sample_set[1] = set(float(d) for d in w.inputs.D)
+    return rp
+
+
 WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}

@@ -396,11 +396,75 @@ def obstacles_long():
     return ObstacleTables(static_obb=[[q[0], q[1], 0.6, 2.0, 0.8]], dyn_obb=dyn, dyn_t0=0)
 
 
+def plan_cases():
+    """End-to-end plan() runs of the reference (levels loop, standstill branch, output packing)."""
+    arc, scurve = path_arc(), path_scurve()
+    base = dict(dt=0.1, N=20, t_min=0.4)
+    return [
+        dict(base, name="plan_arc_hv_obs", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
+             x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3, obstacles=obstacles_arc()),
+        dict(base, name="plan_scurve_lv", ref_path=scurve, level=1, x0_lon=[8.0, 1.5, 0.4], x0_lat=[-0.3, 0.05, 0.0],
+             x0_orientation=0.55, x0_velocity=1.5, desired_speed=4.0),
+        dict(base, name="plan_arc_stop", ref_path=arc, level=1, lon_mode="stopping", x0_lon=[12.0, 6.0, 0.0],
+             x0_lat=[0.2, 0.0, 0.0], x0_orientation=0.12, x0_velocity=6.0, desired_s=22.0, delta_s_min=-12.0,
+             delta_s_max=4.0),
+        dict(base, name="plan_standstill", ref_path=arc, level=1, x0_lon=[12.0, 0.0, 0.0], x0_lat=[0.1, 0.0, 0.0],
+             x0_orientation=0.12, x0_velocity=0.0, desired_speed=0.0, v_range=(0.0, 0.0)),
+        dict(base, name="plan_all_collide", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
+             x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0,
+             obstacles=ObstacleTables(static_circ=[[20.0, 2.0, 30.0]])),
+    ]
+
+
+def run_plan_case(case):
+    rp = make_planner(case)
+    res = rp.plan()
+    out = dict(case_inputs(rp, case), planned=int(res is not None),
+               n_infeasible_kinematics=rp._infeasible_count_kinematics, n_infeasible_collision=rp._infeasible_count_collision,
+               reason_counts=np.array([rp._infeasible_reason_dict.get(k, 0) for k in REASONS], dtype=np.int64),
+               optimal_cost=float(rp._optimal_cost))
+    if res is not None:
+        cart, cvln, lon_list, lat_list = res
+        out.update(
+            cart=np.array([[st.time_step, st.position[0], st.position[1], st.orientation, st.velocity, st.acceleration,
+                            st.yaw_rate, st.steering_angle] for st in cart.state_list], dtype=float),
+            cvln=np.array([[st.time_step, st.position[0], st.position[1], st.orientation, st.velocity, st.acceleration,
+                            st.yaw_rate] for st in cvln.state_list], dtype=float),
+            lon_list=np.array(lon_list, dtype=float), lat_list=np.array(lat_list, dtype=float))
+    return out
+
+
+def case_inputs(rp, case):
+    tb = case.get("obstacles") or ObstacleTables()
+    return dict(ref_path=rp._co.reference, proj_d_limit=rp._co.proj_domain_d_limit, dt=rp.dt, N=rp.N,
+                factor=rp.config.planning.factor, time_step0=rp.x_0.time_step,
+                low_vel_mode_threshold=rp.config.planning.low_vel_mode_threshold,
+                lon_mode=int(rp.config.sampling.longitudinal_mode == "stopping"), t_min=case.get("t_min", 0.4),
+                x0_lon=np.array(rp.x_0_cl[0], dtype=float), x0_lat=np.array(rp.x_0_cl[1], dtype=float),
+                x0_orientation=rp.x_0.orientation, x0_velocity=rp.x_0.velocity, x0_position=np.asarray(rp.x_0.position),
+                desired_speed=np.nan if case.get("desired_speed") is None else case["desired_speed"],
+                desired_s=np.nan if case.get("desired_s") is None else case["desired_s"],
+                delta_s=np.array([case.get("delta_s_min", -5.0), case.get("delta_s_max", 5.0)]),
+                v_range=np.array(case.get("v_range", (np.nan, np.nan)), dtype=float),
+                static_obb=tb.static_obb, static_tri=tb.static_tri, static_circ=tb.static_circ, dyn_obb=tb.dyn_obb,
+                dyn_t0=tb.dyn_t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
+    for case in plan_cases():
+        if args.list:
+            print(case["name"])
+            continue
+        if args.only and case["name"] != args.only:
+            continue
+        out = run_plan_case(case)
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out)
+        print(f"{case['name']:34s} planned={out['planned']} kin={out['n_infeasible_kinematics']} "
+              f"coll={out['n_infeasible_collision']} reasons={out['reason_counts'].tolist()}")
     for case in cases():
         if args.list:
             print(case["name"])

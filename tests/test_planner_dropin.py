@@ -1,0 +1,102 @@
+"""Drop-in check against the REAL reference class: ``GpuBackendMixin`` mixed into
+``commonroad_rp.reactive_planner.ReactivePlanner`` (imported read-only from /root/reference under the
+third-party stand-ins of tests/golden/_ref_shims.py), with everything else of the reference -- plan(),
+its own FixedIntervalSampling / DefaultCostFunction objects, _compute_trajectory_pair -- untouched.
+Compared with the unmodified reference planner on the same inputs.
+
+Only runs where the reference is mounted (the build container); skipped on the GPU box.
+The mixin's backend here is the oracle-backed context (CPU).  Two plug-in paths are exercised:
+  * the reference's FixedIntervalSampling has no ``grids_at_level`` -> "foreign sampling space" path
+    (explicit polynomials, rp_plan_coeffs);
+  * a user CostFunction subclass -> plug-in cost path (materialise, evaluate in Python, rp_select).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if not os.path.isdir("/root/reference/commonroad_rp"):
+    pytest.skip("reference not mounted", allow_module_level=True)
+
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402  (installs the stand-ins and imports the reference)
+
+from commonroad_rp.reactive_planner import ReactivePlanner as RefPlanner  # noqa: E402
+from commonroad_rp.cost_function import DefaultCostFunction as RefDefaultCost  # noqa: E402
+from commonroad_rp_amd.reactive_planner import GpuBackendMixin  # noqa: E402
+from _oracle_ctx import OracleContext  # noqa: E402
+
+
+class DropInPlanner(GpuBackendMixin, RefPlanner):
+    backend_factory = OracleContext
+
+
+def _planner(case, cls):
+    rp = mg.make_planner(dict(case))
+    if cls is not RefPlanner:
+        rp.__class__ = cls       # same attributes, methods of the mixin in front of the reference's
+        rp.set_obstacle_tables(case.get("obstacles"))
+    return rp
+
+
+def _states(res):
+    cart, cvln, lon_list, lat_list = res
+    c = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration, s.yaw_rate,
+                   s.steering_angle] for s in cart.state_list], dtype=float)
+    return c, np.array(lon_list, dtype=float), np.array(lat_list, dtype=float)
+
+
+CASES = {c["name"]: c for c in mg.plan_cases()}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_mixin_on_reference_class_matches_reference(name):
+    ref = _planner(CASES[name], RefPlanner)
+    gpu = _planner(CASES[name], DropInPlanner)
+    r0, r1 = ref.plan(), gpu.plan()
+    assert (r0 is None) == (r1 is None)
+    assert gpu.infeasible_count_kinematics == ref.infeasible_count_kinematics
+    assert gpu.infeasible_count_collision == ref.infeasible_count_collision
+    assert gpu.infeasible_reason_dict == ref.infeasible_reason_dict
+    if r0 is not None:
+        for a, b in zip(_states(r0), _states(r1)):
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-9)
+
+
+class BiasedCost(RefDefaultCost):
+    """user plug-in: default cost plus a penalty on driving left of the reference path"""
+
+    def evaluate(self, trajectory):
+        return super().evaluate(trajectory) + 40.0 * float(np.sum(np.maximum(trajectory.curvilinear.d, 0.0)))
+
+
+def test_plugin_cost_function_path():
+    case = CASES["plan_arc_hv_obs"]
+    ref, gpu = _planner(case, RefPlanner), _planner(case, DropInPlanner)
+    for p in (ref, gpu):
+        cf = BiasedCost(p.cost_function.desired_speed, desired_d=0.0, desired_s=None)
+        p.set_cost_function(cf)
+    r0, r1 = ref.plan(), gpu.plan()
+    assert r0 is not None and r1 is not None
+    for a, b in zip(_states(r0), _states(r1)):
+        np.testing.assert_allclose(b, a, rtol=0, atol=1e-9)
+    assert gpu.infeasible_count_collision == ref.infeasible_count_collision
+
+
+def test_draw_traj_set_stores_every_trajectory():
+    case = dict(CASES["plan_arc_hv_obs"], draw=True)
+    ref, gpu = _planner(case, RefPlanner), _planner(case, DropInPlanner)
+    ref.plan(), gpu.plan()
+    assert len(gpu.stored_trajectories) == len(ref.stored_trajectories)
+    key = lambda t: (t.trajectory_long.delta_tau, t.trajectory_long.x_d[0], t.trajectory_lat.x_d[0])   # noqa: E731
+    mine = {key(t): t for t in gpu.stored_trajectories}
+    for t in ref.stored_trajectories:
+        m = mine[key(t)]
+        np.testing.assert_allclose(m.cartesian.x, t.cartesian.x, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(m.cartesian.kappa_dot, t.cartesian.kappa_dot, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(m.curvilinear.s, t.curvilinear.s, rtol=0, atol=1e-9)
+        kin_ref = t.feasibility_label is not None and t.feasibility_label.value == "infeasible_kinematic"
+        kin_me = m.feasibility_label is not None and m.feasibility_label.value == "infeasible_kinematic"
+        assert kin_ref == kin_me

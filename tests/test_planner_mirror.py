@@ -1,0 +1,53 @@
+"""The host-side mirror of the reference planner interface (commonroad_rp_amd.reactive_planner)
+reproduces the reference's plan() output -- levels loop, standstill branch, output packing -- on the
+golden plan_* fixtures.  CPU run: oracle-backed context (test infrastructure); GPU run: the HIP library."""
+import numpy as np
+import pytest
+
+from _golden import build_planner_from_plan_golden, compare_plan_result, plan_case_names
+
+NAMES = plan_case_names()
+
+
+def test_plan_fixture_inventory():
+    assert len(NAMES) >= 5
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_plan_matches_reference_cpu_glue(name):
+    from _oracle_ctx import OracleContext
+    rp, z = build_planner_from_plan_golden(name, OracleContext)
+    res = rp.plan()
+    compare_plan_result(res, rp, z, atol=1e-9)
+    assert len(rp.planning_times) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_plan_matches_reference_gpu(name):
+    from commonroad_rp_amd._capi import RpContext
+    rp, z = build_planner_from_plan_golden(name, RpContext)
+    res = rp.plan()
+    compare_plan_result(res, rp, z, atol=1e-6)
+    rp.close()
+
+
+def test_sampling_grids_follow_reference_set_order():
+    """grids_at_level reproduces the candidate order stored in the fixtures (Python set iteration order)."""
+    from _golden import Golden
+    from commonroad_rp_amd.config import ReactivePlannerConfiguration
+    from commonroad_rp_amd.sampling import FixedIntervalSampling, VelocitySampling
+    for name, level, t_min in (("arc_hv_l1", 1, 0.4), ("arc_hv_l2_obs", 2, 0.4), ("scurve_hv_l3", 3, 0.2)):
+        g = Golden(name)
+        cfg = ReactivePlannerConfiguration.from_dict(dict(planning=dict(dt=0.1, time_steps_computation=20),
+                                                          sampling=dict(t_min=t_min)))
+        sp = FixedIntervalSampling(cfg)
+        h = 2.0
+        v0, vd = float(g["x0_velocity"]), float(g["desired_speed"])
+        min_v = max(0, v0 - (0.125 * h * 11.5))
+        sp.samples_v = VelocitySampling(min_v, max(min_v + 5.0, v0 + 2), 4)
+        T, tl, L, D = sp.grids_at_level(level, g["x0_lon"], g["x0_lat"], "velocity_keeping")
+        np.testing.assert_array_equal(T, g["T"])
+        np.testing.assert_array_equal(tl, g["traj_len"])
+        np.testing.assert_array_equal(L, g["L"])
+        np.testing.assert_array_equal(D, g["D"])
