@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,8 @@ struct rp_ctx {
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
     unsigned long long *d_debug = nullptr;   // diagnostic build only
+    unsigned long long seq = 0;              // completion tickets handed to the kernels
+    bool spin_wait = true;                   // wait for the ticket in the pinned result block instead of hipStreamSynchronize
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
@@ -307,16 +310,20 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     }
     const bool small = count <= RP_FINALIZE_MAX;
     const bool copy_states = mat && best_states != nullptr && count > 0;
+    const bool winner_pass = !mat && best_states != nullptr && count > 0;
+    const bool ticket = c->spin_wait && small;
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    const unsigned long long seq = ++c->seq;
+    if (ticket) hrb_host->seq = 0;
     hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, c->d_partials, n_partials,
-                       small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev);
+                       small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, (ticket && !winner_pass) ? seq : 0ull);
     if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
         const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
         hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
                            ka.cand_begin, &drb->r, 0.0, (int64_t)0, 0, &drb->n_before);
-        HIP_TRY(c, hipMemcpyAsync(&reinterpret_cast<ResultBlock *>(c->h_result)->n_before, &drb->n_before,
-                                  sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&hrb_host->n_before, &drb->n_before, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     }
-    if (!mat && best_states != nullptr && count > 0) {
+    if (winner_pass) {
         // nothing was materialised: re-evaluate the winner with its state block written to the host mirror
         KArgs kw = ka;
         kw.single_index = &drb->r.best_index;
@@ -326,10 +333,23 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.coeffs = nullptr;
         kw.partials = nullptr;
+        kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
+        kw.seq_value = seq;
         launch_eval(c, kw, 1, true, cin, G);
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    bool done = false;
+    if (ticket) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
+        const volatile unsigned long long *flag = &hrb_host->seq;
+        const auto t_start = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
+            if ((spins & 0x3FF) == 0x3FF &&
+                std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;   // fall back
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
 
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
     *result = hrb->r;
@@ -360,7 +380,12 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     result->kernel_ms = 0.0;
     if (c->profiling && !skip_eval) {
         float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        hipError_t e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        if (e == hipErrorNotReady) {   // ticket arrived ahead of the driver's bookkeeping
+            HIP_TRY(c, hipEventSynchronize(c->ev1));
+            e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        }
+        HIP_TRY(c, e);
         result->kernel_ms = ms;
     }
     return RP_OK;

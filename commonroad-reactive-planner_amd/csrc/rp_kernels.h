@@ -65,6 +65,8 @@ struct KArgs {
     double *coeffs;    // [count][13] or nullptr (lon 6, lat 6, lat_T)
     struct BlockPartial *partials;  // [gridDim.x] or nullptr
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
+    unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
+    unsigned long long seq_value;
 };
 
 // fields of one step of a longitudinal profile
@@ -737,6 +739,11 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     }
     RP_STAMP(14);
     RP_TL(1);
+    if (a.single_index && a.host_seq) {   // winner re-evaluation (one workgroup): ticket after the state rows
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -867,7 +874,7 @@ __global__ void rp_apply_costs_kernel(const double *user, double *cost, const ui
 // coefficients, and write the whole result block to device memory AND to the pinned host mirror
 // (no separate memset / count / copy operations on the stream).
 // ------------------------------------------------------------------------------------------------
-#define RP_FIN_THREADS 1024
+#define RP_FIN_THREADS 256
 #define RP_FINALIZE_MAX (1 << 17)
 
 struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
@@ -876,45 +883,63 @@ struct FinalizeOut {          // layout shared with the host (rp_host.hip: Resul
     uint32_t w_status, pad_;
     double w_cost;
     double w_coeffs[13];
+    unsigned long long seq;   // completion ticket: written to the host mirror after everything else
     // followed by best_states[14][n]
 };
 
+// lexicographic (cost, index) minimum over a wavefront, result in every lane
+__device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(c, o, 64);
+        const long long oi = __shfl_xor(i, o, 64);
+        if (oi >= 0 && better(oc, (int64_t)oi, c, (int64_t)i)) { c = oc; i = oi; }
+    }
+}
+
 __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
                                                                       int count_inline, int copy_states, FinalizeOut *dev_out,
-                                                                      FinalizeOut *host_out) {
-    __shared__ double sh_cost[RP_FIN_THREADS];
-    __shared__ long long sh_idx[RP_FIN_THREADS];
+                                                                      FinalizeOut *host_out, unsigned long long seq) {
+    __shared__ double sh_cost[RP_FIN_THREADS / 64];
+    __shared__ long long sh_idx[RP_FIN_THREADS / 64];
     __shared__ unsigned long long sh_cnt[10];
     __shared__ unsigned long long sh_before;
+    __shared__ FinalizeOut sh_out;
     const int tid = threadIdx.x;
     double bc = 0.0;
-    int64_t bi = -1;
-    if (tid < 10) sh_cnt[tid] = 0;
+    long long bi = -1;
+    unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tid == 0) sh_before = 0;
-    __syncthreads();
     for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
         const BlockPartial p = partials[k];
-        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, bi)) { bc = p.best_cost; bi = p.best_index; }
-        if (p.n_feasible) atomicAdd(&sh_cnt[0], (unsigned long long)p.n_feasible);
-        if (p.n_collision) atomicAdd(&sh_cnt[1], (unsigned long long)p.n_collision);
-        for (int r = 0; r < 8; ++r)
-            if (p.reasons[r]) atomicAdd(&sh_cnt[2 + r], (unsigned long long)p.reasons[r]);
+        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
+        cnt[0] += (unsigned long long)p.n_feasible;
+        cnt[1] += (unsigned long long)p.n_collision;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned long long)p.reasons[r];
     }
-    sh_cost[tid] = bc;
-    sh_idx[tid] = bi;
+    wave_min_pair(bc, bi);
+    // counters: wavefront sums through DPP (exact in double: counts are far below 2^53), one LDS add per wave
+    __shared__ double sh_wcnt[RP_FIN_THREADS / 64][10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const double t = group_sum_last<64>((double)cnt[r]);
+        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = t;
+    }
+    if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
     __syncthreads();
-    for (int off = RP_FIN_THREADS / 2; off > 0; off >>= 1) {   // lexicographic (cost, index) min, tree
-        if (tid < off) {
-            const long long oi = sh_idx[tid + off];
-            if (oi >= 0 && better(sh_cost[tid + off], (int64_t)oi, sh_cost[tid], (int64_t)sh_idx[tid])) {
-                sh_cost[tid] = sh_cost[tid + off];
-                sh_idx[tid] = oi;
-            }
-        }
-        __syncthreads();
+    if (tid < 10) {
+        double t = 0.0;
+        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
+        sh_cnt[tid] = (unsigned long long)t;
     }
-    const int64_t widx = (int64_t)sh_idx[0];
-    const double wcost = sh_cost[0];
+    __syncthreads();
+    double wcost = sh_cost[0];
+    long long widx_ = sh_idx[0];
+#pragma unroll
+    for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
+        if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
+    const int64_t widx = (int64_t)widx_;
     const unsigned long long n_coll = sh_cnt[1];
     // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
     if (count_inline && n_coll > 0) {
@@ -930,7 +955,7 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs
     __syncthreads();
     const int n = a.N + 1;
     if (tid == 0) {
-        FinalizeOut o;
+        FinalizeOut &o = sh_out;
         o.r.best_index = widx;
         o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
         o.r.n_candidates = a.count;
@@ -944,6 +969,7 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs
         o.n_before = sh_before;
         o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
         for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
+        o.seq = 0;
         if (widx >= 0) {
             // the winner's polynomials, recomputed with the evaluation kernel's own formulas
             Poly lon, lat;
@@ -975,8 +1001,13 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs
             o.r.best_lat_T = a.lon_coeffs ? __builtin_nan("") : lat_T;
             o.w_status = a.status[widx - a.cand_begin];
         }
-        *dev_out = o;
-        *host_out = o;
+    }
+    __syncthreads();
+    {   // result header: cooperative copy (8-byte words), everything except the ticket
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
+        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
+        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
     }
     if (copy_states && widx >= 0) {   // winner's state block straight from the materialised states
         const double *src = a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n;
@@ -985,6 +1016,13 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs
             const double v = src[k];
             d1[k] = v;
             d2[k] = v;
+        }
+    }
+    if (seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
