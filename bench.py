@@ -35,6 +35,22 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 
 def main():
+    # Only the JSON line may reach stdout: native libraries (RCCL prints a version banner) write to fd 1
+    # directly, so fd 1 is pointed at stderr for the duration of the run and restored for the final print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        line = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if line is not None:
+        print(line, flush=True)
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -55,9 +71,11 @@ def main():
 
     import torch
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("RP_BENCH_FORCE_DIST") == "1"   # rehearse the N > 1 code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -82,13 +100,13 @@ def main():
 
     def step():
         out = ctx.plan(inp, lo, hi)
-        if world > 1:
+        if dist is not None:
             return exchange_winner(ctx, out, dist, torch.device("cuda", local_rank)), out
         return out, out
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     kernel_ms = []
@@ -99,10 +117,10 @@ def main():
         kernel_ms.append(loc.kernel_ms)
         n_feasible = loc.n_feasible
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -168,10 +186,9 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(w, inp, args.cpu_seconds)
     ctx.close()
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
+    return json.dumps(result) if rank == 0 else None
 
 
 def cpu_baseline(w, inp, budget_s: float):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from _golden import Golden
-from commonroad_rp_amd.distributed import shard_range, combine_heads, _pack_head
+from commonroad_rp_amd.distributed import shard_range, pack_result, combine_results
 from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -46,3 +46,17 @@ def test_sharded_exchange_matches_unsharded(tmp_path, world):
                 assert res["best_cost"] == full.best_cost
                 assert res["states_sum"] == float(np.sum(full.best_states))
                 assert res["lon"] == full.best_lon_coeffs.tolist()
+
+
+def test_pack_and_combine_roundtrip():
+    g = Golden("arc_hv_l2_obs")
+    C = g.inputs.n_candidates
+    n = g.inputs.params.N + 1
+    full = oracle.plan(g.inputs, g.oracle_tables()).out
+    msgs = np.stack([pack_result(oracle.plan(g.inputs, g.oracle_tables(), *shard_range(C, r, 4)).out, n) for r in range(4)])
+    glob, owner = combine_results(msgs, n)
+    assert glob.best_index == full.best_index and glob.best_cost == full.best_cost
+    assert shard_range(C, owner, 4)[0] <= full.best_index < shard_range(C, owner, 4)[1]
+    np.testing.assert_array_equal(glob.best_states, full.best_states)
+    np.testing.assert_array_equal(glob.reason_counts, full.reason_counts)
+    assert (glob.n_feasible, glob.n_collision, glob.n_candidates) == (full.n_feasible, full.n_collision, C)
