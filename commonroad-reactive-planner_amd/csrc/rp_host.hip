@@ -65,6 +65,7 @@ struct rp_ctx {
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
+    unsigned int *d_fin_counter = nullptr;   // "workgroups done" word of the fused selection epilogue
     unsigned long long *d_debug = nullptr;   // diagnostic build only
     unsigned long long seq = 0;              // completion tickets handed to the kernels
     bool spin_wait = true;                   // wait for the ticket in the pinned result block instead of hipStreamSynchronize
@@ -282,6 +283,21 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ka.partials = c->d_partials;
     int n_partials = grid;
 
+    const bool small = count <= RP_FINALIZE_MAX;
+    const bool copy_states = mat && best_states != nullptr && count > 0;
+    const bool winner_pass = !mat && best_states != nullptr && count > 0;
+    const bool ticket = c->spin_wait && small;
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    const unsigned long long seq = ++c->seq;
+    if (ticket) hrb_host->seq = 0;
+    const unsigned long long fin_seq = (ticket && !winner_pass) ? seq : 0ull;
+    // Optional: selection epilogue on the evaluation kernel's last workgroup instead of a separate launch.
+    // Measured SLOWER on MI355X (cfg2: eval 21.6 -> 37.8 us): every workgroup then pays an agent-scope release
+    // fence (L2 write-back) before its ticket, which costs more than one kernel boundary.  Off by default.
+    const bool fused_fin = !skip_eval && count > 0 && std::getenv("RP_AMD_FUSED_FINALIZE") != nullptr;
+    ka.fin_counter = fused_fin ? c->d_fin_counter : nullptr;
+    ka.fin_dev = drb; ka.fin_host = hrb_dev;
+    ka.fin_count_inline = small ? 1 : 0; ka.fin_copy_states = copy_states ? 1 : 0; ka.fin_seq = fin_seq;
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
         if (count > 0) {
@@ -308,15 +324,9 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         else
             n_partials = 0;
     }
-    const bool small = count <= RP_FINALIZE_MAX;
-    const bool copy_states = mat && best_states != nullptr && count > 0;
-    const bool winner_pass = !mat && best_states != nullptr && count > 0;
-    const bool ticket = c->spin_wait && small;
-    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
-    const unsigned long long seq = ++c->seq;
-    if (ticket) hrb_host->seq = 0;
-    hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, c->d_partials, n_partials,
-                       small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, (ticket && !winner_pass) ? seq : 0ull);
+    if (!fused_fin)
+        hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, c->d_partials, n_partials,
+                           small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, fin_seq);
     if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
         const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
         hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
@@ -333,6 +343,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.coeffs = nullptr;
         kw.partials = nullptr;
+        kw.fin_counter = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
         launch_eval(c, kw, 1, true, cin, G);
@@ -418,6 +429,8 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_fin_counter, sizeof(unsigned int)));
+    HIP_TRY(c, hipMemset(c->d_fin_counter, 0, sizeof(unsigned int)));
 #if defined(RP_STAMPS) || defined(RP_TIMELINE)
     HIP_TRY(c, hipMalloc((void **)&c->d_debug, (32 + 2 * 4096) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
@@ -433,7 +446,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs, c->d_profile, c->d_profile_one,
-                   c->d_pair_hdr, c->d_pair_hdr_one};
+                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_fin_counter};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -703,6 +716,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
     kw.coeffs = nullptr;
     kw.partials = nullptr;
+    kw.fin_counter = nullptr;
     // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own
     if ((rc = grow(c, c->d_profile_one, c->cap_profile_one, (size_t)PF_FIELDS * (size_t)n)) != RP_OK) return rc;
     kw.pair_begin = c->last_coeffs ? index : index / l.nD;

@@ -67,6 +67,11 @@ struct KArgs {
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
     unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
     unsigned long long seq_value;
+    // selection epilogue run by the last workgroup of rp_eval_kernel (fin_counter != nullptr)
+    unsigned int *fin_counter;      // device word, zero between launches (the last workgroup resets it)
+    struct FinalizeOut *fin_dev, *fin_host;
+    int32_t fin_count_inline, fin_copy_states;
+    unsigned long long fin_seq;
 };
 
 // fields of one step of a longitudinal profile
@@ -137,6 +142,173 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 //   * divisions by quantities reused several times (s_dot, 1 - k_r d, segment length) become one
 //     Newton-refined reciprocal each; threshold tests are rearranged to multiplications.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// One-launch epilogue for batches up to RP_FINALIZE_MAX candidates: reduce the block partials,
+// count the colliding samples that precede the winner (lazy semantics of _check_collisions),
+// fetch the winner's state block from the materialised states (if any) and its polynomial
+// coefficients, and write the whole result block to device memory AND to the pinned host mirror
+// (no separate memset / count / copy operations on the stream).
+// ------------------------------------------------------------------------------------------------
+#define RP_FIN_THREADS 256
+#define RP_FINALIZE_MAX (1 << 17)
+
+struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
+    rp_result r;
+    unsigned long long n_before;
+    uint32_t w_status, pad_;
+    double w_cost;
+    double w_coeffs[13];
+    unsigned long long seq;   // completion ticket: written to the host mirror after everything else
+    // followed by best_states[14][n]
+};
+
+// lexicographic (cost, index) minimum over a wavefront, result in every lane
+__device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(c, o, 64);
+        const long long oi = __shfl_xor(i, o, 64);
+        if (oi >= 0 && better(oc, (int64_t)oi, c, (int64_t)i)) { c = oc; i = oi; }
+    }
+}
+
+// Body shared by rp_finalize_kernel and by the LAST workgroup of rp_eval_kernel (blockDim.x == RP_FIN_THREADS).
+__device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial *partials, int n_partials, int count_inline,
+                                              int copy_states, FinalizeOut *dev_out, FinalizeOut *host_out,
+                                              unsigned long long seq) {
+    __shared__ double sh_cost[RP_FIN_THREADS / 64];
+    __shared__ long long sh_idx[RP_FIN_THREADS / 64];
+    __shared__ unsigned long long sh_cnt[10];
+    __shared__ unsigned long long sh_before;
+    __shared__ FinalizeOut sh_out;
+    const int tid = threadIdx.x;
+    double bc = 0.0;
+    long long bi = -1;
+    unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid == 0) sh_before = 0;
+    for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
+        const BlockPartial p = partials[k];
+        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
+        cnt[0] += (unsigned long long)p.n_feasible;
+        cnt[1] += (unsigned long long)p.n_collision;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned long long)p.reasons[r];
+    }
+    wave_min_pair(bc, bi);
+    // counters: wavefront sums through DPP (exact in double: counts are far below 2^53), one LDS add per wave
+    __shared__ double sh_wcnt[RP_FIN_THREADS / 64][10];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const double t = group_sum_last<64>((double)cnt[r]);
+        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = t;
+    }
+    if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid < 10) {
+        double t = 0.0;
+        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
+        sh_cnt[tid] = (unsigned long long)t;
+    }
+    __syncthreads();
+    double wcost = sh_cost[0];
+    long long widx_ = sh_idx[0];
+#pragma unroll
+    for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
+        if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
+    const int64_t widx = (int64_t)widx_;
+    const unsigned long long n_coll = sh_cnt[1];
+    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
+    if (count_inline && n_coll > 0) {
+        int nloc = 0;
+        for (int64_t i = tid; i < a.count; i += RP_FIN_THREADS) {
+            if (RP_STATUS_LABEL(a.status[i]) == RP_LABEL_INFEASIBLE_COLLISION) {
+                const double c = a.cost[i];
+                nloc += (widx < 0 || c < wcost || (c == wcost && a.cand_begin + i < widx));
+            }
+        }
+        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
+    }
+    __syncthreads();
+    const int n = a.N + 1;
+    if (tid == 0) {
+        FinalizeOut &o = sh_out;
+        o.r.best_index = widx;
+        o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
+        o.r.n_candidates = a.count;
+        o.r.n_feasible = (int64_t)sh_cnt[0];
+        o.r.n_collision = (int64_t)n_coll;
+        o.r.n_collision_before_best = (int64_t)sh_before;
+        for (int r = 0; r < 8; ++r) o.r.reason_counts[r] = (int64_t)sh_cnt[2 + r];
+        o.r.kernel_ms = 0.0;
+        o.r.best_lat_T = __builtin_nan("");
+        for (int k = 0; k < 6; ++k) o.r.best_lon_coeffs[k] = o.r.best_lat_coeffs[k] = __builtin_nan("");
+        o.n_before = sh_before;
+        o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
+        for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
+        o.seq = 0;
+        if (widx >= 0) {
+            // the winner's polynomials, recomputed with the evaluation kernel's own formulas
+            Poly lon, lat;
+            double lat_T = 0.0;
+            if (a.lon_coeffs) {
+                const double *pl = a.lon_coeffs + 6 * widx, *pt = a.lat_coeffs + 6 * widx;
+                lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
+                lat = {pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]};
+            } else {
+                const int64_t nLD = (int64_t)a.nL * a.nD;
+                const int iT = (int)(widx / nLD);
+                const int rem = (int)(widx - (int64_t)iT * nLD);
+                const int iL = rem / a.nD, iD = rem - iL * a.nD;
+                const double T = a.T[iT];
+                if (a.lon_mode == RP_LON_STOPPING) lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);
+                else lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);
+                lat_T = T;
+                if (a.low_vel_mode) {
+                    const double sg = lon.pos(T) - a.x0_lon[0];
+                    lat_T = sg <= 0.0 ? T : sg;
+                }
+                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], a.D[iD], 0.0, 0.0, lat_T);
+            }
+            o.w_coeffs[0] = lon.c0; o.w_coeffs[1] = lon.c1; o.w_coeffs[2] = lon.c2; o.w_coeffs[3] = lon.c3;
+            o.w_coeffs[4] = lon.c4; o.w_coeffs[5] = lon.c5;
+            o.w_coeffs[6] = lat.c0; o.w_coeffs[7] = lat.c1; o.w_coeffs[8] = lat.c2; o.w_coeffs[9] = lat.c3;
+            o.w_coeffs[10] = lat.c4; o.w_coeffs[11] = lat.c5; o.w_coeffs[12] = lat_T;
+            for (int k = 0; k < 6; ++k) { o.r.best_lon_coeffs[k] = o.w_coeffs[k]; o.r.best_lat_coeffs[k] = o.w_coeffs[6 + k]; }
+            o.r.best_lat_T = a.lon_coeffs ? __builtin_nan("") : lat_T;
+            o.w_status = a.status[widx - a.cand_begin];
+        }
+    }
+    __syncthreads();
+    {   // result header: cooperative copy (8-byte words), everything except the ticket
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
+        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
+        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
+    }
+    if (copy_states && widx >= 0) {   // winner's state block straight from the materialised states
+        const double *src = a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n;
+        double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
+        for (int k = tid; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
+            const double v = src[k];
+            d1[k] = v;
+            d2[k] = v;
+        }
+    }
+    if (seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
+                                                                      int count_inline, int copy_states, FinalizeOut *dev_out,
+                                                                      FinalizeOut *host_out, unsigned long long seq) {
+    finalize_body(a, partials, n_partials, count_inline, copy_states, dev_out, host_out, seq);
+}
+
 // Per-group LDS scratch of the evaluation kernel.  Values that are identical in all lanes of a group
 // and live for the whole candidate are parked here and re-read (broadcast reads) where they are used.
 //   poly[0..14]  lateral polynomial: c0..c5 | c1, 2c2, 3c3, 4c4, 5c5 | 2c2, 6c3, 12c4, 20c5
@@ -736,6 +908,26 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
             a.partials[blockIdx.x] = bp;
         }
+        // ---- selection epilogue by the workgroup that finishes last (no separate launch).  Visibility of the
+        //      other workgroups' partials: agent-scope release before the ticket, acquire after it
+        //      (cdna_hip_programming.md, Guideline 16).
+        if (a.fin_counter) {
+            __shared__ int sh_last_block;
+            if (tid == 0) {
+                __threadfence();
+                const unsigned int t = atomicAdd(a.fin_counter, 1u);
+                sh_last_block = (t == gridDim.x - 1);
+                if (sh_last_block) {
+                    *a.fin_counter = 0u;   // ready for the next launch (stream order)
+                    __threadfence();
+                }
+            }
+            __syncthreads();
+            if (sh_last_block) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                finalize_body(a, a.partials, (int)gridDim.x, a.fin_count_inline, a.fin_copy_states, a.fin_dev, a.fin_host, a.fin_seq);
+            }
+        }
     }
     RP_STAMP(14);
     RP_TL(1);
@@ -867,162 +1059,3 @@ __global__ void rp_apply_costs_kernel(const double *user, double *cost, const ui
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// One-launch epilogue for batches up to RP_FINALIZE_MAX candidates: reduce the block partials,
-// count the colliding samples that precede the winner (lazy semantics of _check_collisions),
-// fetch the winner's state block from the materialised states (if any) and its polynomial
-// coefficients, and write the whole result block to device memory AND to the pinned host mirror
-// (no separate memset / count / copy operations on the stream).
-// ------------------------------------------------------------------------------------------------
-#define RP_FIN_THREADS 256
-#define RP_FINALIZE_MAX (1 << 17)
-
-struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
-    rp_result r;
-    unsigned long long n_before;
-    uint32_t w_status, pad_;
-    double w_cost;
-    double w_coeffs[13];
-    unsigned long long seq;   // completion ticket: written to the host mirror after everything else
-    // followed by best_states[14][n]
-};
-
-// lexicographic (cost, index) minimum over a wavefront, result in every lane
-__device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double oc = __shfl_xor(c, o, 64);
-        const long long oi = __shfl_xor(i, o, 64);
-        if (oi >= 0 && better(oc, (int64_t)oi, c, (int64_t)i)) { c = oc; i = oi; }
-    }
-}
-
-__global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
-                                                                      int count_inline, int copy_states, FinalizeOut *dev_out,
-                                                                      FinalizeOut *host_out, unsigned long long seq) {
-    __shared__ double sh_cost[RP_FIN_THREADS / 64];
-    __shared__ long long sh_idx[RP_FIN_THREADS / 64];
-    __shared__ unsigned long long sh_cnt[10];
-    __shared__ unsigned long long sh_before;
-    __shared__ FinalizeOut sh_out;
-    const int tid = threadIdx.x;
-    double bc = 0.0;
-    long long bi = -1;
-    unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (tid == 0) sh_before = 0;
-    for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
-        const BlockPartial p = partials[k];
-        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
-        cnt[0] += (unsigned long long)p.n_feasible;
-        cnt[1] += (unsigned long long)p.n_collision;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned long long)p.reasons[r];
-    }
-    wave_min_pair(bc, bi);
-    // counters: wavefront sums through DPP (exact in double: counts are far below 2^53), one LDS add per wave
-    __shared__ double sh_wcnt[RP_FIN_THREADS / 64][10];
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const double t = group_sum_last<64>((double)cnt[r]);
-        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = t;
-    }
-    if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
-    __syncthreads();
-    if (tid < 10) {
-        double t = 0.0;
-        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
-        sh_cnt[tid] = (unsigned long long)t;
-    }
-    __syncthreads();
-    double wcost = sh_cost[0];
-    long long widx_ = sh_idx[0];
-#pragma unroll
-    for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
-        if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
-    const int64_t widx = (int64_t)widx_;
-    const unsigned long long n_coll = sh_cnt[1];
-    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
-    if (count_inline && n_coll > 0) {
-        int nloc = 0;
-        for (int64_t i = tid; i < a.count; i += RP_FIN_THREADS) {
-            if (RP_STATUS_LABEL(a.status[i]) == RP_LABEL_INFEASIBLE_COLLISION) {
-                const double c = a.cost[i];
-                nloc += (widx < 0 || c < wcost || (c == wcost && a.cand_begin + i < widx));
-            }
-        }
-        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
-    }
-    __syncthreads();
-    const int n = a.N + 1;
-    if (tid == 0) {
-        FinalizeOut &o = sh_out;
-        o.r.best_index = widx;
-        o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
-        o.r.n_candidates = a.count;
-        o.r.n_feasible = (int64_t)sh_cnt[0];
-        o.r.n_collision = (int64_t)n_coll;
-        o.r.n_collision_before_best = (int64_t)sh_before;
-        for (int r = 0; r < 8; ++r) o.r.reason_counts[r] = (int64_t)sh_cnt[2 + r];
-        o.r.kernel_ms = 0.0;
-        o.r.best_lat_T = __builtin_nan("");
-        for (int k = 0; k < 6; ++k) o.r.best_lon_coeffs[k] = o.r.best_lat_coeffs[k] = __builtin_nan("");
-        o.n_before = sh_before;
-        o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
-        for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
-        o.seq = 0;
-        if (widx >= 0) {
-            // the winner's polynomials, recomputed with the evaluation kernel's own formulas
-            Poly lon, lat;
-            double lat_T = 0.0;
-            if (a.lon_coeffs) {
-                const double *pl = a.lon_coeffs + 6 * widx, *pt = a.lat_coeffs + 6 * widx;
-                lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
-                lat = {pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]};
-            } else {
-                const int64_t nLD = (int64_t)a.nL * a.nD;
-                const int iT = (int)(widx / nLD);
-                const int rem = (int)(widx - (int64_t)iT * nLD);
-                const int iL = rem / a.nD, iD = rem - iL * a.nD;
-                const double T = a.T[iT];
-                if (a.lon_mode == RP_LON_STOPPING) lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);
-                else lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);
-                lat_T = T;
-                if (a.low_vel_mode) {
-                    const double sg = lon.pos(T) - a.x0_lon[0];
-                    lat_T = sg <= 0.0 ? T : sg;
-                }
-                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], a.D[iD], 0.0, 0.0, lat_T);
-            }
-            o.w_coeffs[0] = lon.c0; o.w_coeffs[1] = lon.c1; o.w_coeffs[2] = lon.c2; o.w_coeffs[3] = lon.c3;
-            o.w_coeffs[4] = lon.c4; o.w_coeffs[5] = lon.c5;
-            o.w_coeffs[6] = lat.c0; o.w_coeffs[7] = lat.c1; o.w_coeffs[8] = lat.c2; o.w_coeffs[9] = lat.c3;
-            o.w_coeffs[10] = lat.c4; o.w_coeffs[11] = lat.c5; o.w_coeffs[12] = lat_T;
-            for (int k = 0; k < 6; ++k) { o.r.best_lon_coeffs[k] = o.w_coeffs[k]; o.r.best_lat_coeffs[k] = o.w_coeffs[6 + k]; }
-            o.r.best_lat_T = a.lon_coeffs ? __builtin_nan("") : lat_T;
-            o.w_status = a.status[widx - a.cand_begin];
-        }
-    }
-    __syncthreads();
-    {   // result header: cooperative copy (8-byte words), everything except the ticket
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
-        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
-        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
-        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
-    }
-    if (copy_states && widx >= 0) {   // winner's state block straight from the materialised states
-        const double *src = a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n;
-        double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
-        for (int k = tid; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
-            const double v = src[k];
-            d1[k] = v;
-            d2[k] = v;
-        }
-    }
-    if (seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
