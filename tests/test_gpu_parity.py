@@ -211,3 +211,102 @@ def test_edge_cases(ctx):
     with pytest.raises(_capi.RpError, match="rp_set_reference"):
         c2.plan(g2.inputs)
     c2.close()
+
+
+def _synthetic_case(ref_path, N=30, seed=0, low=False):
+    """Inputs on an arbitrary polyline: oracle tables + PlanInputs (no fixture behind it)."""
+    from commonroad_rp_amd.coordinate_system import CoordinateSystem
+    from commonroad_rp_amd.workloads import VEHICLE2, traj_len_of
+    from commonroad_rp_amd._capi import make_params, make_cost
+    co = CoordinateSystem(ref_path)
+    dt = 0.1
+    T = np.array([dt * k for k in range(8, N + 1, 3)])
+    L = np.linspace(4.0, 14.0, 7)
+    D = np.append(np.linspace(-2.5, 2.5, 6), 0.3)
+    s0 = co.ref_pos[len(co.ref_pos) // 4]
+    params = make_params(dt=dt, N=N, x0_lon=[s0, 1.5 if low else 9.0, 0.2], x0_lat=[0.3, 0.05, 0.0],
+                         x0_orientation=float(co.ref_theta[len(co.ref_pos) // 4]), low_vel_mode=low, **VEHICLE2)
+    return co, PlanInputs(params, make_cost(desired_speed=8.0), T, traj_len_of(T, dt), L, D)
+
+
+@pytest.mark.parametrize("kind", ["long_table_global_memory", "irregular_spacing_binary_search"])
+def test_table_fallback_paths(ctx, kind):
+    """Reference tables too large for LDS (read through L1/L2 instead) and spacing too irregular for
+    the bucket lookup (binary search instead): same results as the oracle."""
+    from oracle import oracle
+    from commonroad_rp_amd.collision import ObstacleTables
+    if kind == "long_table_global_memory":
+        s = np.arange(0.0, 1400.0, 0.5)                     # 2800 vertices -> 9 rows x 2800 x 8 B = 197 KB > 64 KB
+        path = np.stack((s, 30.0 * np.sin(s / 90.0)), axis=1)
+    else:
+        rng = np.random.default_rng(4)
+        seg = np.where(rng.random(400) < 0.1, 1e-4, rng.uniform(0.5, 2.0, 400))   # 1e-4 m segments -> > 8192 buckets
+        s = np.concatenate(([0.0], np.cumsum(seg)))
+        path = np.stack((s, 10.0 * np.sin(s / 60.0)), axis=1)
+    co, inp = _synthetic_case(path)
+    ctx.set_coordinate_system(co)
+    ctx.set_obstacles(ObstacleTables())
+    tb = oracle.OracleTables.from_coordinate_system(co)
+    for flags in (0, FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL):
+        i2 = _with_flags(inp, flags)
+        orun = oracle.plan(i2, tb)
+        out = ctx.plan(i2)
+        status, cost = ctx.fetch_status()
+        _compare_status(status, cost, orun)
+        _compare_out(out, orun.out)
+        if flags:
+            np.testing.assert_allclose(ctx.fetch_states(), orun.states, rtol=0, atol=STATE_ATOL)
+
+
+def test_many_static_shapes_and_triangles(ctx):
+    """Road-boundary style input: hundreds of triangles, circles and boxes."""
+    from oracle import oracle
+    from commonroad_rp_amd.collision import ObstacleTables
+    g = Golden("arc_hv_l2_obs")
+    rng = np.random.default_rng(7)
+    co_xy = g["ref_path"]
+    tris, circs, boxes = [], [], []
+    for k in range(300):
+        p = co_xy[rng.integers(0, len(co_xy))] + rng.normal(size=2) * 1.0 + np.array([0.0, rng.choice([-1, 1]) * 4.5])
+        tris.append([p[0], p[1], p[0] + rng.uniform(0.5, 2), p[1] + rng.uniform(-1, 1), p[0] + rng.uniform(-1, 1), p[1] + rng.uniform(0.5, 2)])
+    for k in range(40):
+        p = co_xy[rng.integers(0, len(co_xy))] + np.array([0.0, rng.choice([-1, 1]) * rng.uniform(2.0, 5.0)])
+        circs.append([p[0], p[1], rng.uniform(0.2, 0.8)])
+        boxes.append([p[0] + 1.0, p[1] + rng.choice([-1, 1]) * 2.0, rng.uniform(-3, 3), rng.uniform(0.5, 2.5), rng.uniform(0.3, 1.0)])
+    tables = ObstacleTables(static_tri=tris, static_circ=circs, static_obb=boxes)
+    z = g.z
+    ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
+    ctx.set_obstacles(tables)
+    tb = oracle.OracleTables(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"],
+                             float(z["proj_d_limit"]), tables)
+    orun = oracle.plan(g.inputs, tb)
+    out = ctx.plan(g.inputs)
+    status, cost = ctx.fetch_status()
+    _compare_status(status, cost, orun)
+    _compare_out(out, orun.out)
+    assert out.n_collision > 0 and out.n_feasible > out.n_collision
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 129])
+def test_horizon_lengths_around_lane_group_boundaries(ctx, N):
+    """N + 1 below, at and above 16 / 32 / 64 / 128 steps, in low- and high-velocity mode."""
+    from oracle import oracle
+    from commonroad_rp_amd.collision import ObstacleTables
+    from commonroad_rp_amd.workloads import traj_len_of
+    s = np.arange(0.0, 400.0, 1.0)
+    path = np.stack((s, 25.0 * np.sin(s / 70.0)), axis=1)
+    for low in (False, True):
+        co, inp = _synthetic_case(path, N=N, low=low)
+        if N < 8:   # the T grid of _synthetic_case starts at 8 dt
+            T = np.array([0.1 * k for k in range(1, N + 1)])
+            inp = PlanInputs(inp.params, inp.cost, T, traj_len_of(T, 0.1), inp.L, inp.D)
+        ctx.set_coordinate_system(co)
+        ctx.set_obstacles(ObstacleTables())
+        tb = oracle.OracleTables.from_coordinate_system(co)
+        i2 = _with_flags(inp, FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL)
+        orun = oracle.plan(i2, tb)
+        out = ctx.plan(i2)
+        status, cost = ctx.fetch_status()
+        _compare_status(status, cost, orun)
+        _compare_out(out, orun.out)
+        np.testing.assert_allclose(ctx.fetch_states(), orun.states, rtol=0, atol=STATE_ATOL)
