@@ -96,7 +96,9 @@ def run():
 
     ctx = RpContext(local_rank)
     w.setup(ctx)
-    ctx.set_profiling(True)
+    # HIP events bracket the evaluation kernel of every 4th step of the timed region (each bracket costs ~8 us of
+    # stream time on this 20-us kernel; profiles/host_overhead.py), the average is over the sampled launches
+    ctx.set_profiling(4)
 
     def step():
         out = ctx.plan(inp, lo, hi)
@@ -114,7 +116,8 @@ def run():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g, loc = step()
-        kernel_ms.append(loc.kernel_ms)
+        if loc.kernel_ms > 0:
+            kernel_ms.append(loc.kernel_ms)
         n_feasible = loc.n_feasible
     torch.cuda.synchronize()
     if dist is not None:
@@ -164,10 +167,12 @@ def run():
             t1 = time.perf_counter()
             kk = []
             for _ in range(max(20, args.steps // 4)):
-                kk.append(ctx.plan(inf).kernel_ms)
+                km = ctx.plan(inf).kernel_ms
+                if km > 0:
+                    kk.append(km)
             el = time.perf_counter() - t1
-            result["fused_mode"] = {"value": C_total * len(kk) / el, "unit": "candidates/s",
-                                    "ms_per_step": el / len(kk) * 1e3, "kernel_ms": float(np.mean(kk))}
+            result["fused_mode"] = {"value": C_total * max(20, args.steps // 4) / el, "unit": "candidates/s",
+                                    "ms_per_step": el / max(20, args.steps // 4) * 1e3, "kernel_ms": float(np.mean(kk))}
         # second half of BASELINE.json's metric: p50 latency of a whole planner.plan() call, Python boundary and
         # output packing included (production mode), >= 200 replans after 20 warm-ups
         if base.n_candidates <= 100000:

@@ -66,6 +66,9 @@ class RpResult(C.Structure):
                 ("best_lat_coeffs", C.c_double * 6), ("best_lat_T", C.c_double), ("kernel_ms", C.c_double)]
 
 
+_DP = C.POINTER(C.c_double)
+
+
 def f64(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -96,8 +99,11 @@ class PlanInputs:
         return len(self.T) * len(self.L) * len(self.D)
 
     def grids(self) -> RpGrids:
-        return RpGrids(len(self.T), len(self.L), len(self.D), 0, dptr(self.T),
-                       self.traj_len.ctypes.data_as(C.POINTER(C.c_int32)), dptr(self.L), dptr(self.D))
+        g = getattr(self, "_grids", None)
+        if g is None:
+            g = self._grids = RpGrids(len(self.T), len(self.L), len(self.D), 0, dptr(self.T),
+                                      self.traj_len.ctypes.data_as(C.POINTER(C.c_int32)), dptr(self.L), dptr(self.D))
+        return g
 
 
 @dataclasses.dataclass
@@ -221,6 +227,7 @@ class RpContext:
         self.device = device
         self._N = None
         self._last_count = 0
+        self._res = RpResult()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -237,8 +244,9 @@ class RpContext:
         if rc != 0:
             raise RpError(f"{what} -> {rc}: {(self._lib.rp_last_error(self._h) or b'').decode()}")
 
-    def set_profiling(self, enable: bool):
-        self._check(self._lib.rp_set_profiling(self._h, int(enable)), "rp_set_profiling")
+    def set_profiling(self, every: int):
+        """Time the evaluation kernel of every ``every``-th plan with HIP events (0 / False = off)."""
+        self._check(self._lib.rp_set_profiling(self._h, int(every)), "rp_set_profiling")
 
     def set_reference(self, ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit: float = 20.0):
         ref_pos, ref_theta, ref_curv, ref_curv_d = f64(ref_pos), f64(ref_theta), f64(ref_curv), f64(ref_curv_d)
@@ -265,14 +273,16 @@ class RpContext:
             len(tb.static_circ), dptr(tb.static_circ), nd, ns, int(tb.dyn_t0), dptr(tb.dyn_obb)), "rp_set_obstacles")
 
     def plan(self, inp: PlanInputs, cand_begin: int = 0, cand_end: int = -1, want_best_states: bool = True) -> PlanOutput:
-        res = RpResult()
+        res = self._res
         n = inp.params.N + 1
         best = np.empty((N_ARRAYS, n)) if want_best_states else None
         g = inp.grids()
-        self._check(self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), int(cand_begin),
-                                      int(cand_end), C.byref(res), dptr(best)), "rp_plan")
+        rc = self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end,
+                               C.byref(res), best.ctypes.data_as(_DP) if best is not None else None)
+        if rc != 0:
+            self._check(rc, "rp_plan")
         self._N = inp.params.N
-        self._last_count = int(res.n_candidates)
+        self._last_count = res.n_candidates
         return PlanOutput.from_c(res, best)
 
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,

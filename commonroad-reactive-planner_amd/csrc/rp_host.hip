@@ -33,7 +33,8 @@ struct rp_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int num_cus = 256;
-    bool profiling = false;
+    int profiling = 0;            // 0 off, k > 0: time the evaluation kernel of every k-th rp_plan with HIP events
+    unsigned long long calls = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // reference tables
@@ -298,6 +299,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ka.fin_counter = fused_fin ? c->d_fin_counter : nullptr;
     ka.fin_dev = drb; ka.fin_host = hrb_dev;
     ka.fin_count_inline = small ? 1 : 0; ka.fin_copy_states = copy_states ? 1 : 0; ka.fin_seq = fin_seq;
+    const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
         if (count > 0) {
@@ -312,9 +314,9 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             ka.pair_hdr = c->d_pair_hdr;
             launch_lon(c, ka, cin);
         }
-        if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) launch_eval(c, ka, grid, mat, cin, G);
-        if (c->profiling) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         if (count == 0) n_partials = 0;
     } else {
         n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
@@ -389,7 +391,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     }
 #endif
     result->kernel_ms = 0.0;
-    if (c->profiling && !skip_eval) {
+    if (timed) {
         float ms = 0.f;
         hipError_t e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
         if (e == hipErrorNotReady) {   // ticket arrived ahead of the driver's bookkeeping
@@ -462,7 +464,7 @@ const char *rp_last_error(const rp_ctx *c) { return c ? c->err.c_str() : "null c
 
 int rp_set_profiling(rp_ctx *c, int enable) {
     if (!c) return RP_EINVAL;
-    c->profiling = enable != 0;
+    c->profiling = enable < 0 ? 0 : enable;   // k: every k-th call is timed (1 = every call)
     return RP_OK;
 }
 
@@ -590,6 +592,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     if (rc != RP_OK) return rc;
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
     const int64_t total = (int64_t)g->nT * g->nL * g->nD;
+    if (total > 0x7fffffffLL) return fail(c, RP_EINVAL, "rp_plan: more than 2^31 - 1 candidates in one grid");
     if (total > 0 && (!g->T || !g->traj_len || !g->L || !g->D)) return fail(c, RP_EINVAL, "rp_plan: null grid array");
     if (cand_end < 0) cand_end = total;
     if (cand_begin < 0 || cand_begin > cand_end || cand_end > total) return fail(c, RP_EINVAL, "rp_plan: bad candidate range");

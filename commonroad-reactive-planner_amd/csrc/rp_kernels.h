@@ -488,8 +488,10 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) 
         for (int k = 0; k < 6; ++k) ci.v[k] = pt[k];
         pair = gidx;
     } else {
-        pair = gidx / a.nD;
-        ci.v[0] = a.D[(int)(gidx - pair * a.nD)];
+        const uint32_t g32 = (uint32_t)gidx, nd = (uint32_t)a.nD;   // candidate indices fit 32 bits (checked by the host)
+        const uint32_t p32 = g32 / nd;
+        pair = p32;
+        ci.v[0] = a.D[g32 - p32 * nd];
     }
     ci.pair_slot = pair - a.pair_begin;
     const PairHdr h = a.pair_hdr[ci.pair_slot];
@@ -536,10 +538,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int64_t count = a.single_index ? 1 : a.count;
 
     CandIn cin;
+    ProfStep pf_first;   // first step block of the first candidate: requested together with its header
     {
         const int64_t slot0 = wave_first + group_in_wave;
         const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
         cin = fetch_candidate<COEFFS_IN>(a, g0);
+        const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - a.pair_begin;
+        const int n0 = a.N + 1;
+        pf_first = load_profile(a.profile + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
     }
 
     __shared__ GroupScratch sh_grp[GPB];
@@ -590,10 +596,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
-        const int64_t pair_slot_ = (COEFFS_IN ? gidx : gidx / a.nD) - a.pair_begin;
+        const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - a.pair_begin;
         const double *const prow = a.profile + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
         // first step block of the profile: requested before the header-dependent polynomial set-up
-        ProfStep pf = load_profile(prow, n, gl <= N ? gl : N);
+        ProfStep pf = (w0 == wave_first) ? pf_first : load_profile(prow, n, gl <= N ? gl : N);
         {
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};

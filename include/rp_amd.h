@@ -155,7 +155,8 @@ int rp_abi_version(void);
 int rp_create(rp_ctx **out, int device);
 void rp_destroy(rp_ctx *ctx);
 const char *rp_last_error(const rp_ctx *ctx);
-/* record HIP events around the evaluation kernel of every rp_plan (rp_result.kernel_ms) */
+/* enable = k > 0: record HIP events around the evaluation kernel of every k-th rp_plan on this ctx
+ * (rp_result.kernel_ms; 0 for the calls in between); 0 = off */
 int rp_set_profiling(rp_ctx *ctx, int enable);
 
 /* ---- tables (once per reset / reference path) -------------------------------------------------- */

@@ -1,0 +1,24 @@
+"""Where does a bench step spend its host time?  Splits RpContext.plan() into the C call and the Python around it."""
+import sys, os, time, numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")]
+from commonroad_rp_amd import workloads as W
+from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL
+w = W.cfg2()
+p = copy_params(w.inputs.params); p.flags |= FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL
+inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
+ctx = RpContext(0); w.setup(ctx)
+orig = ctx._lib.rp_plan
+acc = []
+def timed(*a):
+    t = time.perf_counter(); r = orig(*a); acc.append(time.perf_counter() - t); return r
+for prof in (False, True):
+    ctx.set_profiling(prof)
+    for _ in range(20): ctx.plan(inp)
+    ctx._lib.rp_plan = timed
+    acc.clear()
+    t0 = time.perf_counter()
+    for _ in range(300): ctx.plan(inp)
+    tot = (time.perf_counter() - t0) / 300
+    ctx._lib.rp_plan = orig
+    print(f"profiling={prof}: step {tot*1e6:.1f} us, C call {np.mean(acc)*1e6:.1f} us, python around it {(tot-np.mean(acc))*1e6:.1f} us")
