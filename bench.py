@@ -140,6 +140,17 @@ def run():
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else float("nan")
 
+    # HBM bytes per launch from the PMC counters: cannot be collected inside this process (rocprofv3 --pmc wraps the
+    # command), so the figure measured for this workload + mode by profiles/collect_pmc.sh is read back
+    # (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md); null if never measured
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json"))).get(base.name)
+        if pmc and pmc.get("mode") == args.mode and world == 1:
+            traffic = pmc["traffic_bytes"]
+    except Exception:
+        traffic = None
+
     result = {
         "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
         "value": C_total * args.steps / elapsed,
@@ -153,7 +164,7 @@ def run():
                    "n_obstacles": int(w.obstacles.dyn_obb.shape[0] + len(w.obstacles.static_obb)),
                    "parallelism": f"candidate-range sharding x{world}"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "rp_eval_kernel",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rp_eval_kernel",
                      "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
     }
 
