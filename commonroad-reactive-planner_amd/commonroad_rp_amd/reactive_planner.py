@@ -523,19 +523,22 @@ class ReactivePlanner(GpuBackendMixin):
 
     def _compute_trajectory_pair(self, trajectory: TrajectorySample):
         """Output packing, reactive_planner.py:514-568."""
-        cart_list, cl_list, lon_list, lat_list = [], [], [], []
         ca, cu = trajectory.cartesian, trajectory.curvilinear
-        factor = self.config.planning.factor
-        for i in range(len(ca.x)):
-            yaw = (ca.theta[i] - ca.theta[i - 1]) / self.dt if i > 0 else self.x_0.yaw_rate
-            cart_list.append(ReactivePlannerState(
-                time_step=self.x_0.time_step + factor * i, position=np.array([ca.x[i], ca.y[i]]), orientation=ca.theta[i],
-                velocity=ca.v[i], acceleration=ca.a[i], yaw_rate=yaw,
-                steering_angle=np.arctan2(self.vehicle_params.wheelbase * ca.kappa[i], 1.0)))
-            cl_list.append(CustomState(time_step=self.x_0.time_step + factor * i, position=np.array([cu.s[i], cu.d[i]]),
-                                       velocity=ca.v[i], acceleration=ca.a[i], orientation=ca.theta[i], yaw_rate=ca.kappa[i]))
-            lon_list.append([cu.s[i], cu.s_dot[i], cu.s_ddot[i]])
-            lat_list.append([cu.d[i], cu.d_dot[i], cu.d_ddot[i]])
+        n = len(ca.x)
+        t0, factor, dt = self.x_0.time_step, self.config.planning.factor, self.dt
+        theta = np.asarray(ca.theta, dtype=float)
+        yaw = np.empty(n)
+        yaw[1:] = (theta[1:] - theta[:-1]) / dt
+        steer = np.arctan2(self.vehicle_params.wheelbase * np.asarray(ca.kappa, dtype=float), 1.0)
+        pos = np.stack((ca.x, ca.y), axis=1)
+        sd = np.stack((cu.s, cu.d), axis=1)
+        th, v, a, ka = theta.tolist(), np.asarray(ca.v).tolist(), np.asarray(ca.a).tolist(), np.asarray(ca.kappa).tolist()
+        yawl, steerl = yaw.tolist(), steer.tolist()
+        yawl[0] = self.x_0.yaw_rate
+        cart_list = [ReactivePlannerState(t0 + factor * i, pos[i], th[i], v[i], steerl[i], a[i], yawl[i]) for i in range(n)]
+        cl_list = [CustomState(t0 + factor * i, sd[i], th[i], v[i], a[i], ka[i]) for i in range(n)]
+        lon_list = np.stack((cu.s, cu.s_dot, cu.s_ddot), axis=1).tolist()
+        lat_list = np.stack((cu.d, cu.d_dot, cu.d_ddot), axis=1).tolist()
         cart = Trajectory(self.x_0.time_step, cart_list)
         lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
         for st in cart.state_list:   # shift_orientation, utility/general.py:49-55

@@ -122,13 +122,40 @@ class FixedIntervalSampling(SamplingSpace):
         ``traj_len`` follows reactive_planner.py:733,748.  In stopping mode the longitudinal samples
         not ahead of the vehicle are dropped, which is what ``filter_goals_behind`` does to the list
         (trajectories.py:545-550, reactive_planner.py:1076-1077)."""
-        T = np.array([float(t) for t in self.samples_t.samples_at_level(level_sampling)], dtype=np.float64)
-        L = [float(v) for v in self._get_lon_samples(level_sampling, longitudinal_mode)]
+        T, traj_len = self._cached_T(self.samples_t.samples_at_level(level_sampling))
+        lon_set = self._get_lon_samples(level_sampling, longitudinal_mode)
+        L = self._cached_array(lon_set)
         if longitudinal_mode == "stopping":
-            L = [v for v in L if x_0_lon[0] < v]
-        D = [float(d) for d in self.samples_d.samples_at_level(level_sampling).union({x_0_lat[0]})]
-        traj_len = np.array([len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in T], dtype=np.int32)
-        return T, traj_len, np.array(L, dtype=np.float64), np.array(D, dtype=np.float64)
+            L = L[L > x_0_lon[0]]
+        d_set = self.samples_d.samples_at_level(level_sampling)
+        d0 = x_0_lat[0]
+        if d0 in d_set:
+            D = self._cached_array(d_set)
+        else:   # set.union({d0}) keeps the iteration order of the copy and appends / hashes d0 in
+            D = np.array([float(d) for d in d_set.union({d0})], dtype=np.float64)
+        return T, traj_len, L, D
+
+    # The sample sets only change when a set_*_sampling_parameters call replaces them, so their array form
+    # (in set-iteration order) is cached per set object; the set is kept alive next to it, hence ids are unique.
+    def _cached_array(self, sample_set: set) -> np.ndarray:
+        cache = self.__dict__.setdefault("_set_cache", {})
+        hit = cache.get(id(sample_set))
+        if hit is None or hit[0] is not sample_set or len(hit[1]) != len(sample_set):
+            if len(cache) > 64:
+                cache.clear()
+            hit = cache[id(sample_set)] = (sample_set, np.array([float(v) for v in sample_set], dtype=np.float64))
+        return hit[1]
+
+    def _cached_T(self, t_set: set):
+        cache = self.__dict__.setdefault("_t_cache", {})
+        hit = cache.get(id(t_set))
+        if hit is None or hit[0] is not t_set or len(hit[1]) != len(t_set):
+            if len(cache) > 64:
+                cache.clear()
+            T = np.array([float(t) for t in t_set], dtype=np.float64)
+            traj_len = np.array([len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in T], dtype=np.int32)
+            hit = cache[id(t_set)] = (t_set, T, traj_len)
+        return hit[1], hit[2]
 
     # ---- reference interface (one object per candidate) --------------------------------------------
     def generate_trajectories_at_level(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str,

@@ -538,14 +538,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int64_t count = a.single_index ? 1 : a.count;
 
     CandIn cin;
-    ProfStep pf_first;   // first step block of the first candidate: requested together with its header
+    ProfStep pf_carry;   // first step block of the NEXT candidate to run (initially the first one): always requested
+                         // ahead of the current candidate's state-row stores so that it never queues behind them
     {
         const int64_t slot0 = wave_first + group_in_wave;
         const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
         cin = fetch_candidate<COEFFS_IN>(a, g0);
         const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - a.pair_begin;
         const int n0 = a.N + 1;
-        pf_first = load_profile(a.profile + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+        pf_carry = load_profile(a.profile + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
     }
 
     __shared__ GroupScratch sh_grp[GPB];
@@ -598,8 +599,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
         const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - a.pair_begin;
         const double *const prow = a.profile + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
-        // first step block of the profile: requested before the header-dependent polynomial set-up
-        ProfStep pf = (w0 == wave_first) ? pf_first : load_profile(prow, n, gl <= N ? gl : N);
+        ProfStep pf = pf_carry;   // this candidate's first step block (requested one candidate ago)
         {
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
@@ -850,6 +850,12 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0));
         }
         RP_STAMP(12);  // state stores issued, chunk loop done
+        if (w0 + total_groups < count) {   // next candidate's first profile rows, ahead of the copy-out burst below
+            const int64_t nslot = slot + total_groups;
+            const int64_t ng = a.cand_begin + (nslot < count ? nslot : 0);
+            const int64_t nps = (COEFFS_IN ? ng : (int64_t)((uint32_t)ng / (uint32_t)a.nD)) - a.pair_begin;
+            pf_carry = load_profile(a.profile + ((size_t)nps * PF_FIELDS) * (size_t)n, n, gl <= N ? gl : N);
+        }
         if (MAT && STAGE_OUT) {   // linear copy-out of this wavefront's candidates (wave-uniform)
             // blocks are written for every candidate that passed the pre-filter; failed candidates keep
             // whatever steps were computed (same contract as direct stores)

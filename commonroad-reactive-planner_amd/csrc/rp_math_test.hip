@@ -27,3 +27,35 @@ extern "C" int rpt_math(int kind, int n, const double *in, double *out, double *
     hipFree(d_in); hipFree(d_out); hipFree(d_out2);
     return e == hipSuccess ? 0 : -2;
 }
+
+// ---- store-bandwidth ceiling probe (profiles/store_ceiling.py): plain coalesced streaming stores of `bytes` bytes,
+//      16 B per lane (wide) or 8 B per lane, grid-stride; returns the average kernel time in ms over `reps` launches
+__global__ void k_fill16(double2 *p, size_t n2) {
+    const double2 v = make_double2(1.0, 2.0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill8(double *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 1.0;
+}
+extern "C" double rpt_store_ceiling(size_t bytes, int wide, int reps) {
+    void *d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return -1.0;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = 256 * 8;
+    for (int r = 0; r < 2; ++r) {
+        if (wide) hipLaunchKernelGGL(k_fill16, dim3(grid), dim3(256), 0, 0, (double2 *)d, bytes / 16);
+        else hipLaunchKernelGGL(k_fill8, dim3(grid), dim3(256), 0, 0, (double *)d, bytes / 8);
+    }
+    hipEventRecord(e0, 0);
+    for (int r = 0; r < reps; ++r) {
+        if (wide) hipLaunchKernelGGL(k_fill16, dim3(grid), dim3(256), 0, 0, (double2 *)d, bytes / 16);
+        else hipLaunchKernelGGL(k_fill8, dim3(grid), dim3(256), 0, 0, (double *)d, bytes / 8);
+    }
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipFree(d);
+    return (double)ms / reps;
+}

