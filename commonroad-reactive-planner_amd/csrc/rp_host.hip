@@ -73,6 +73,7 @@ struct rp_ctx {
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
+    size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
     std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
 };
@@ -143,8 +144,48 @@ constexpr size_t kStageOutLimit = 65536;   // LDS bytes per workgroup up to whic
 
 template <int G, bool MAT, bool CIN, bool COLL, bool STAGE>
 void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
-    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
-    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE, false>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE, false>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+}
+
+// ---- single-launch variant (longitudinal profiles computed by each workgroup into LDS) ---------------------
+constexpr int kFusedLonG = 16;                 // lanes per candidate of the single-launch variant
+constexpr size_t kFusedLonLdsLimit = 49152;    // LDS bytes per workgroup it may use for profile rows
+int fused_lon_max_blocks(const rp_ctx *c) {    // batches up to this many workgroups (16 candidates each) take it
+    if (const char *e = std::getenv("RP_AMD_FUSED_LON_BLOCKS")) return std::atoi(e);
+    return c->num_cus * 4;
+}
+
+// LDS bytes of the single-launch variant for this batch (0: not eligible); *pairs = profile capacity per workgroup
+size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool cin, int *pairs) {
+    if (G != kFusedLonG || count <= 0) return 0;
+    const int gpb = RP_BLOCK / kFusedLonG;
+    if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
+    // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
+    const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
+    const size_t bytes = (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int));
+    if (bytes > kFusedLonLdsLimit) return 0;
+    *pairs = P;
+    return (bytes + 15) & ~(size_t)15;
+}
+
+template <bool MAT, bool CIN, bool COLL>
+void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+    constexpr int G = kFusedLonG;
+    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, false, true>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, false, true>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+}
+
+template <bool MAT, bool CIN>
+void launch_eval_fused_t(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+    const bool coll = ka.has_obstacles && !(ka.flags & RP_FLAG_SKIP_COLLISION);
+    if (coll) launch_eval_fused_c<MAT, CIN, true>(c, ka, grid, lds);
+    else launch_eval_fused_c<MAT, CIN, false>(c, ka, grid, lds);
+}
+
+void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, size_t lds) {
+    if (mat) { if (cin) launch_eval_fused_t<true, true>(c, ka, grid, lds); else launch_eval_fused_t<true, false>(c, ka, grid, lds); }
+    else     { if (cin) launch_eval_fused_t<false, true>(c, ka, grid, lds); else launch_eval_fused_t<false, false>(c, ka, grid, lds); }
 }
 
 template <int G, bool MAT, bool CIN, bool COLL>
@@ -272,7 +313,12 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
     const int64_t count = ka.count;
     const int G = lanes_per_candidate(c, ka.N, count, mat);
-    const int grid = eval_grid(c, count, G);
+    // small batches: one launch computes the longitudinal profiles and evaluates (rp_eval_kernel<.., LON_FUSED>)
+    int fused_pairs = 0;
+    const size_t fused_lds = (skip_eval || std::getenv("RP_AMD_NO_FUSED_LON")) ? 0 : fused_lon_lds(c, ka, count, G, cin, &fused_pairs);
+    ka.lds_pairs = fused_pairs;
+    if (!skip_eval) c->last_fused_lds = fused_lds;
+    const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
     if (grid > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
@@ -302,7 +348,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
-        if (count > 0) {
+        if (count > 0 && !fused_lds) {
             if (cin) { ka.pair_begin = 0; ka.pair_count = count; }
             else {
                 ka.pair_begin = ka.cand_begin / ka.nD;
@@ -315,7 +361,10 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             launch_lon(c, ka, cin);
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (count > 0) launch_eval(c, ka, grid, mat, cin, G);
+        if (count > 0) {
+            if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds);
+            else launch_eval(c, ka, grid, mat, cin, G);
+        }
         if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         if (count == 0) n_partials = 0;
     } else {
@@ -348,7 +397,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.fin_counter = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
-        launch_eval(c, kw, 1, true, cin, G);
+        if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds);
+        else launch_eval(c, kw, 1, true, cin, G);
     }
     HIP_TRY(c, hipGetLastError());
     bool done = false;
@@ -726,8 +776,13 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.pair_count = 1;
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
-    launch_lon(c, kw, c->last_coeffs);
-    launch_eval(c, kw, 1, true, c->last_coeffs, lanes_per_candidate(c, kw.N, 1, true));
+    const int G1 = lanes_per_candidate(c, kw.N, 1, true);
+    if (c->last_fused_lds && G1 == kFusedLonG) {   // same code path as the batch: results agree bit for bit
+        launch_eval_fused(c, kw, 1, true, c->last_coeffs, c->last_fused_lds);
+    } else {
+        launch_lon(c, kw, c->last_coeffs);
+        launch_eval(c, kw, 1, true, c->last_coeffs, G1);
+    }
     const size_t bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
     HIP_TRY(c, hipMemcpyAsync(c->h_result, c->d_result, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

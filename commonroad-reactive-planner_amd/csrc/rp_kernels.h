@@ -58,6 +58,7 @@ struct KArgs {
     double *profile;            // [pair_count][PF_FIELDS][N+1]
     struct PairHdr *pair_hdr;   // [pair_count]
     int64_t pair_begin, pair_count;
+    int32_t lds_pairs, pad3_;   // LON_FUSED: capacity (pairs) of the workgroup's LDS profile area
     // outputs
     uint32_t *status;  // [count]
     double *cost;      // [count]
@@ -333,8 +334,101 @@ __device__ __forceinline__ double poly_vel(const double *o, double t) {
 __device__ __forceinline__ double poly_acc(const double *o, double t) { return ((o[14] * t + o[13]) * t + o[12]) * t + o[11]; }
 
 // ------------------------------------------------------------------------------------------------
-// Longitudinal profiles: one group of G lanes per (T, longitudinal sample) pair, lane = time step.
+// Longitudinal profiles.  Everything of a step that does not depend on the lateral sample d.
 // ------------------------------------------------------------------------------------------------
+struct RefTab {   // rows of the reference-path table block (rp_device.h: TB_*), in LDS or global memory
+    const double *pos, *theta, *curv, *curv_d, *x, *y, *tx, *ty, *inv;
+    const int *bucket;
+    int n_ref;
+    double pos_first, pos_last;
+};
+
+__device__ __forceinline__ RefTab ref_tab(const double *tab, int n_ref) {
+    RefTab r;
+    r.pos = tab + TB_POS * n_ref; r.theta = tab + TB_THETA * n_ref; r.curv = tab + TB_CURV * n_ref;
+    r.curv_d = tab + TB_CURV_D * n_ref; r.x = tab + TB_X * n_ref; r.y = tab + TB_Y * n_ref;
+    r.tx = tab + TB_TX * n_ref; r.ty = tab + TB_TY * n_ref; r.inv = tab + TB_INVLEN * n_ref;
+    r.bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
+    r.n_ref = n_ref;
+    r.pos_first = r.pos[0];
+    r.pos_last = r.pos[n_ref - 1];
+    return r;
+}
+
+struct LonPair {
+    Poly lon;
+    double lat_T;   // delta_tau of the pair's lateral polynomials (sampling.py:229-237); 0 with COEFFS_IN
+    int L;          // traj_len clamped to [1, N+1]
+};
+
+// longitudinal polynomial of a (T, longitudinal sample) pair: sampling.py:253-266
+template <bool COEFFS_IN>
+__device__ __forceinline__ LonPair lon_pair(const KArgs &a, int64_t pair, int n) {
+    LonPair r;
+    r.lat_T = 0.0;
+    int L;
+    if (COEFFS_IN) {
+        const double *pl = a.lon_coeffs + 6 * pair;
+        r.lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
+        L = a.traj_len_c[pair];
+    } else {
+        const int iT = (int)((uint32_t)pair / (uint32_t)a.nL), iL = (int)((uint32_t)pair - (uint32_t)iT * (uint32_t)a.nL);
+        const double T = a.T[iT];
+        L = a.traj_len[iT];
+        if (a.lon_mode == RP_LON_STOPPING)
+            r.lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);  // sampling.py:259-263
+        else
+            r.lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);             // sampling.py:254-258
+        r.lat_T = T;
+        if (a.low_vel_mode) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
+            const double sg = r.lon.pos(T) - a.x0_lon[0];
+            r.lat_T = sg <= 0.0 ? T : sg;
+        }
+    }
+    r.L = L > n ? n : (L < 1 ? 1 : L);
+    return r;
+}
+
+// step i of a pair's profile -> f[PF_FIELDS]
+__device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const Poly &lon, int i, double *f) {
+    const int n_ref = rt.n_ref;
+    const double t = (double)i * a.dt;
+    // -- polynomial evaluation, reactive_planner.py:751-753,776
+    const double s = lon.pos(t), sdd = lon.acc(t);
+    double sd = lon.vel(t);
+    if (fabs(sd) < RP_EPS) sd = 0.0;
+    const bool moving = sd > 0.001;              // :811,:822,:842
+    const double inv_sd = moving ? rp_rcp(sd) : 0.0;
+    // -- segment lookup + interpolation factors (:835-839); Python's negative index wraps
+    const int ub = a.n_buckets > 0
+                       ? upper_bound_bucket(rt.pos, rt.bucket, n_ref, a.n_buckets, a.bucket_inv_h, rt.pos_first, rt.pos_last, s)
+                       : upper_bound(rt.pos, n_ref, a.search_iters, s);
+    const int s_idx = (ub == n_ref) ? -1 : ub - 1;
+    const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
+    const double p0 = rt.pos[k0], inv_len = rt.inv[k0];
+    const double ds = s - p0;
+    const double lam = ds * inv_len;
+    const double th0 = rt.theta[k0];
+    const double th_ref = make_valid_orientation((rt.theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
+    const double c0 = rt.curv[k0], cd0 = rt.curv_d[k0];
+    const double k_r = (rt.curv[k1] - c0) * lam + c0;              // :876-880
+    const double k_r_d = (rt.curv_d[k1] - cd0) * lam + cd0;
+    // -- foot point and unit normal of (s, d) -> (x, y) = foot + d * normal, :908-917
+    int k = ub - 1;
+    k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
+    const double lam2 = (s - rt.pos[k]) * rt.inv[k];
+    const double bx = rt.x[k], by = rt.y[k], ux0 = rt.tx[k], uy0 = rt.ty[k];
+    const double px = bx + lam2 * (rt.x[k + 1] - bx), py = by + lam2 * (rt.y[k + 1] - by);
+    const double ax = ux0 + lam2 * (rt.tx[k + 1] - ux0), ay = uy0 + lam2 * (rt.ty[k + 1] - uy0);
+    const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
+    f[PF_S] = s; f[PF_SD] = sd; f[PF_SDD] = sdd; f[PF_INV_SD] = inv_sd; f[PF_TH_REF] = th_ref;
+    f[PF_KR] = k_r; f[PF_KRD] = k_r_d; f[PF_PX] = px; f[PF_PY] = py;
+    f[PF_NX] = -(ay * inv_tn); f[PF_NY] = ax * inv_tn;
+    f[PF_INDOM] = (s >= rt.pos_first && s <= rt.pos_last) ? 1.0 : 0.0;
+}
+
+// One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
+// and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
 __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     extern __shared__ double lds[];
@@ -352,11 +446,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     } else {
         tab = a.tables;
     }
-    const double *t_pos = tab + TB_POS * n_ref, *t_theta = tab + TB_THETA * n_ref, *t_curv = tab + TB_CURV * n_ref,
-                 *t_curv_d = tab + TB_CURV_D * n_ref, *t_x = tab + TB_X * n_ref, *t_y = tab + TB_Y * n_ref,
-                 *t_tx = tab + TB_TX * n_ref, *t_ty = tab + TB_TY * n_ref, *t_inv = tab + TB_INVLEN * n_ref;
-    const int *t_bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
-    const double pos_first = t_pos[0], pos_last = t_pos[n_ref - 1];
+    const RefTab rt = ref_tab(tab, n_ref);
 
     const int lane = tid & 63;
     const int gl = lane & (G - 1);
@@ -364,94 +454,33 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     constexpr int GPB = RP_BLOCK / G;
     const int N = a.N, n = N + 1;
     const int nchunks = (n + G - 1) / G;
-    const double dt = a.dt;
     const bool draw = (a.flags & RP_FLAG_DRAW_ALL) != 0;
-    const bool low = a.low_vel_mode != 0;
 
     for (int64_t slot = (int64_t)blockIdx.x * GPB + tid / G; slot < a.pair_count; slot += (int64_t)gridDim.x * GPB) {
         // all lanes of a group share the slot; groups of one wave may leave the loop at different trip counts,
         // which is fine here: the body uses only group-level ballots on lanes that are all still active.
-        const int64_t pair = a.pair_begin + slot;
-        // ---- longitudinal polynomial: sampling.py:253-266
-        Poly lon;
-        double lat_T = 0.0;
-        int L;
-        if (COEFFS_IN) {
-            const double *pl = a.lon_coeffs + 6 * pair;
-            lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
-            L = a.traj_len_c[pair];
-        } else {
-            const int iT = (int)(pair / a.nL), iL = (int)(pair - (int64_t)iT * a.nL);
-            const double T = a.T[iT];
-            L = a.traj_len[iT];
-            if (a.lon_mode == RP_LON_STOPPING)
-                lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);  // sampling.py:259-263
-            else
-                lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);             // sampling.py:254-258
-            lat_T = T;
-            if (low) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
-                const double sg = lon.pos(T) - a.x0_lon[0];
-                lat_T = sg <= 0.0 ? T : sg;
-            }
-        }
-        L = L > n ? n : (L < 1 ? 1 : L);
+        const LonPair lp = lon_pair<COEFFS_IN>(a, a.pair_begin + slot, n);
+        const int L = lp.L;
         double *const prow = a.profile + ((size_t)slot * PF_FIELDS) * (size_t)n;
         bool bad_a = false, bad_v = false;
 #pragma nounroll
         for (int c = 0; c < nchunks; ++c) {
             const int i = c * G + gl;
-            const double t = (double)i * dt;
-            // -- polynomial evaluation, reactive_planner.py:751-753,776
-            const double s = lon.pos(t), sdd = lon.acc(t);
-            double sd = lon.vel(t);
-            if (fabs(sd) < RP_EPS) sd = 0.0;
-            bad_a |= (i < L) && (fabs(sdd) > a.a_max);   // pre-filter, :798
-            bad_v |= (i < L) && (sd < -RP_EPS);          // pre-filter, :802
-            const bool moving = sd > 0.001;              // :811,:822,:842
-            const double inv_sd = moving ? rp_rcp(sd) : 0.0;
-            // -- segment lookup + interpolation factors (:835-839); Python's negative index wraps
-            const int ub = a.n_buckets > 0
-                               ? upper_bound_bucket(t_pos, t_bucket, n_ref, a.n_buckets, a.bucket_inv_h, pos_first, pos_last, s)
-                               : upper_bound(t_pos, n_ref, a.search_iters, s);
-            const int s_idx = (ub == n_ref) ? -1 : ub - 1;
-            const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
-            const double p0 = t_pos[k0], inv_len = t_inv[k0];
-            const double ds = s - p0;
-            const double lam = ds * inv_len;
-            const double th0 = t_theta[k0];
-            const double th_ref = make_valid_orientation((t_theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
-            const double c0 = t_curv[k0], cd0 = t_curv_d[k0];
-            const double k_r = (t_curv[k1] - c0) * lam + c0;              // :876-880
-            const double k_r_d = (t_curv_d[k1] - cd0) * lam + cd0;
-            // -- foot point and unit normal of (s, d) -> (x, y) = foot + d * normal, :908-917
-            int k = ub - 1;
-            k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
-            const double lam2 = (s - t_pos[k]) * t_inv[k];
-            const double bx = t_x[k], by = t_y[k], ux0 = t_tx[k], uy0 = t_ty[k];
-            const double px = bx + lam2 * (t_x[k + 1] - bx), py = by + lam2 * (t_y[k + 1] - by);
-            const double ax = ux0 + lam2 * (t_tx[k + 1] - ux0), ay = uy0 + lam2 * (t_ty[k + 1] - uy0);
-            const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
+            double f[PF_FIELDS];
+            lon_step(a, rt, lp.lon, i, f);
+            bad_a |= (i < L) && (fabs(f[PF_SDD]) > a.a_max);   // pre-filter, :798
+            bad_v |= (i < L) && (f[PF_SD] < -RP_EPS);          // pre-filter, :802
             if (i <= N) {
                 double *o = prow + i;
-                o[(size_t)PF_S * n] = s;
-                o[(size_t)PF_SD * n] = sd;
-                o[(size_t)PF_SDD * n] = sdd;
-                o[(size_t)PF_INV_SD * n] = inv_sd;
-                o[(size_t)PF_TH_REF * n] = th_ref;
-                o[(size_t)PF_KR * n] = k_r;
-                o[(size_t)PF_KRD * n] = k_r_d;
-                o[(size_t)PF_PX * n] = px;
-                o[(size_t)PF_PY * n] = py;
-                o[(size_t)PF_NX * n] = -(ay * inv_tn);
-                o[(size_t)PF_NY * n] = ax * inv_tn;
-                o[(size_t)PF_INDOM * n] = (s >= pos_first && s <= pos_last) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n] = f[k];
             }
         }
         const bool any_a = group_ballot<G>(bad_a, gbase) != 0, any_v = group_ballot<G>(bad_v, gbase) != 0;
         if (gl == 0) {
             PairHdr h;
-            h.lat_T = lat_T;
-            h.s0 = lon.c0;   // s[0] == c0 exactly (:762)
+            h.lat_T = lp.lat_T;
+            h.s0 = lp.lon.c0;   // s[0] == c0 exactly (:762)
             h.pre_reason = draw ? RP_REASON_NONE : (any_a ? RP_REASON_ACCELERATION : (any_v ? RP_REASON_VELOCITY : RP_REASON_NONE));
             h.L = L;
             a.pair_hdr[slot] = h;
@@ -478,8 +507,9 @@ struct CandIn {
     int64_t pair_slot;
 };
 
+// hdrs[pair - hdr_pair0]: the pair headers written by rp_lon_kernel (global) or by the workgroup itself (LDS)
 template <bool COEFFS_IN>
-__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) {
+__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, const PairHdr *hdrs, int64_t hdr_pair0) {
     CandIn ci;
     int64_t pair;
     if (COEFFS_IN) {
@@ -493,8 +523,8 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) 
         pair = p32;
         ci.v[0] = a.D[g32 - p32 * nd];
     }
-    ci.pair_slot = pair - a.pair_begin;
-    const PairHdr h = a.pair_hdr[ci.pair_slot];
+    ci.pair_slot = pair - hdr_pair0;
+    const PairHdr h = hdrs[ci.pair_slot];
     ci.lat_T = h.lat_T;
     ci.s0 = h.s0;
     ci.pre_reason = h.pre_reason;
@@ -517,9 +547,15 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx) 
 // as ONE linear, 16-byte-per-lane stream -- the [14][N+1] blocks of consecutive candidates are
 // contiguous in memory and 112 (N+1) bytes long, i.e. always 16-byte aligned.  Half the store
 // instructions of row-wise 8-byte stores, every one of them a full 1 KiB.
-template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE_OUT>
+//
+// LON_FUSED (single-launch step for batches of at most one candidate per lane group, i.e.
+// gridDim.x * GPB >= count): the workgroup first computes the longitudinal profiles of the (at most
+// a.lds_pairs) pairs its own candidates belong to into LDS -- the work of rp_lon_kernel without the
+// launch, the global round trip of the profile rows and the kernel boundary.
+template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
-    extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1]
+    extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: profiles, headers, flags
+    static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
     const int tid = threadIdx.x;
     RP_STAMP(0);
     RP_TL(0);
@@ -537,25 +573,76 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave
     const int64_t count = a.single_index ? 1 : a.count;
 
+    __shared__ GroupScratch sh_grp[GPB];
+    __shared__ double sh_best_cost[GPB];
+    __shared__ long long sh_best_idx[GPB];
+    __shared__ int sh_cnt[10];
+
+    // where the profile rows and pair headers live: global memory (rp_lon_kernel) or this workgroup's LDS
+    const double *prof_base = a.profile;
+    const PairHdr *hdr_base = a.pair_hdr;
+    int64_t pair0 = a.pair_begin;
+    if (LON_FUSED) {
+        const int n0 = a.N + 1;
+        double *const lds_prof = lds_out;
+        PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_FIELDS * (size_t)n0);
+        int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
+        // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
+        const int64_t s_first = (int64_t)blockIdx.x * GPB;
+        const int64_t s_last = (s_first + GPB <= count ? s_first + GPB : count) - 1;
+        const int64_t g_first = a.single_index ? *a.single_index : a.cand_begin + (s_first < count ? s_first : 0);
+        const int64_t g_last = a.single_index ? g_first : a.cand_begin + (s_last >= s_first ? s_last : s_first);
+        const int64_t p_first = COEFFS_IN ? g_first : (int64_t)((uint32_t)g_first / (uint32_t)a.nD);
+        const int64_t p_last = COEFFS_IN ? g_last : (int64_t)((uint32_t)g_last / (uint32_t)a.nD);
+        int P = (int)(p_last - p_first) + 1;
+        P = P > a.lds_pairs ? a.lds_pairs : P;   // (cannot happen: the host sizes lds_pairs for the worst alignment)
+        if (tid < P) lds_flags[tid] = 0;
+        if (tid < 10) sh_cnt[tid] = 0;
+        if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
+        __syncthreads();
+        const RefTab rt = ref_tab(a.tables, a.n_ref);
+        for (int j = tid; j < P * n0; j += RP_BLOCK) {   // item = (pair, step)
+            const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
+            const LonPair lp = lon_pair<COEFFS_IN>(a, p_first + p, n0);
+            double f[PF_FIELDS];
+            lon_step(a, rt, lp.lon, i, f);
+            double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
+#pragma unroll
+            for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n0] = f[k];
+            int fl = 0;   // pre-filter votes, reactive_planner.py:798,802
+            if (i < lp.L) fl = (fabs(f[PF_SDD]) > a.a_max ? 1 : 0) | (f[PF_SD] < -RP_EPS ? 2 : 0);
+            if (fl) atomicOr(&lds_flags[p], fl);
+            if (i == 0) { lds_hdr[p].lat_T = lp.lat_T; lds_hdr[p].s0 = lp.lon.c0; lds_hdr[p].L = lp.L; }
+        }
+        __syncthreads();
+        if (tid < P) {
+            const int fl = lds_flags[tid];
+            lds_hdr[tid].pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
+                                      : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
+        }
+        __syncthreads();
+        prof_base = lds_prof;
+        hdr_base = lds_hdr;
+        pair0 = p_first;
+    }
+
     CandIn cin;
     ProfStep pf_carry;   // first step block of the NEXT candidate to run (initially the first one): always requested
                          // ahead of the current candidate's state-row stores so that it never queues behind them
     {
         const int64_t slot0 = wave_first + group_in_wave;
         const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
-        cin = fetch_candidate<COEFFS_IN>(a, g0);
-        const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - a.pair_begin;
+        cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
+        const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0;
         const int n0 = a.N + 1;
-        pf_carry = load_profile(a.profile + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+        pf_carry = load_profile(prof_base + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
     }
 
-    __shared__ GroupScratch sh_grp[GPB];
-    __shared__ double sh_best_cost[GPB];
-    __shared__ long long sh_best_idx[GPB];
-    __shared__ int sh_cnt[10];
-    if (tid < 10) sh_cnt[tid] = 0;
-    if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
-    __syncthreads();
+    if (!LON_FUSED) {
+        if (tid < 10) sh_cnt[tid] = 0;
+        if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
+        __syncthreads();
+    }
     RP_STAMP(1);
 
     const int N = a.N, n = N + 1;
@@ -597,8 +684,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
-        const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - a.pair_begin;
-        const double *const prow = a.profile + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
+        const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - pair0;
+        const double *const prow = prof_base + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
         ProfStep pf = pf_carry;   // this candidate's first step block (requested one candidate ago)
         {
             Poly lat;
@@ -847,14 +934,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         // next candidate's inputs (software pipelining; consumed at the top of the next iteration)
         if (w0 + total_groups < count) {
             const int64_t nslot = slot + total_groups;
-            cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0));
+            cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0), hdr_base, pair0);
         }
         RP_STAMP(12);  // state stores issued, chunk loop done
         if (w0 + total_groups < count) {   // next candidate's first profile rows, ahead of the copy-out burst below
             const int64_t nslot = slot + total_groups;
             const int64_t ng = a.cand_begin + (nslot < count ? nslot : 0);
-            const int64_t nps = (COEFFS_IN ? ng : (int64_t)((uint32_t)ng / (uint32_t)a.nD)) - a.pair_begin;
-            pf_carry = load_profile(a.profile + ((size_t)nps * PF_FIELDS) * (size_t)n, n, gl <= N ? gl : N);
+            const int64_t nps = (COEFFS_IN ? ng : (int64_t)((uint32_t)ng / (uint32_t)a.nD)) - pair0;
+            pf_carry = load_profile(prof_base + ((size_t)nps * PF_FIELDS) * (size_t)n, n, gl <= N ? gl : N);
         }
         if (MAT && STAGE_OUT) {   // linear copy-out of this wavefront's candidates (wave-uniform)
             // blocks are written for every candidate that passed the pre-filter; failed candidates keep
