@@ -150,7 +150,7 @@ void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
 
 // ---- single-launch variant (longitudinal profiles computed by each workgroup into LDS) ---------------------
 constexpr int kFusedLonG = 16;                 // lanes per candidate of the single-launch variant
-constexpr size_t kFusedLonLdsLimit = 49152;    // LDS bytes per workgroup it may use for profile rows
+constexpr size_t kFusedLonLdsLimit = 61440;    // LDS bytes per workgroup it may use (tables + profile rows)
 int fused_lon_max_blocks(const rp_ctx *c) {    // batches up to this many workgroups (16 candidates each) take it
     if (const char *e = std::getenv("RP_AMD_FUSED_LON_BLOCKS")) return std::atoi(e);
     return c->num_cus * 4;
@@ -163,7 +163,9 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
-    const size_t bytes = (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int));
+    // reference tables + profile rows + pair headers + pre-filter votes
+    const size_t bytes = (size_t)ka.table_words * sizeof(double) +
+                         (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int));
     if (bytes > kFusedLonLdsLimit) return 0;
     *pairs = P;
     return (bytes + 15) & ~(size_t)15;

@@ -128,6 +128,35 @@ struct DevResult {
 #define RP_TL(slot) do { } while (0)
 #endif
 
+// The kernarg segment (528 bytes of KArgs + the hidden launch arguments) is written by the host right before
+// the launch and is cold in every cache.  The compiler fetches its fields in many small scalar loads spread
+// over the prologue, each first touch of a 64-byte line a full memory round trip in series with the others.
+// One batch of loads that touches every line up front turns these into a single round trip; the scattered
+// loads that follow hit the scalar cache.
+template <int LINES>
+__device__ __forceinline__ void touch_kernargs() {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(LINES >= 1 && LINES <= 10, "kernarg lines");
+    unsigned t0, t1, t2, t3, t4, t5, t6, t7, t8, t9;
+    asm volatile(
+        "s_load_dword %0, %10, 0x0\n\t"
+        "s_load_dword %1, %10, %11\n\t"
+        "s_load_dword %2, %10, %12\n\t"
+        "s_load_dword %3, %10, %13\n\t"
+        "s_load_dword %4, %10, %14\n\t"
+        "s_load_dword %5, %10, %15\n\t"
+        "s_load_dword %6, %10, %16\n\t"
+        "s_load_dword %7, %10, %17\n\t"
+        "s_load_dword %8, %10, %18\n\t"
+        "s_load_dword %9, %10, %19\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9)
+        : "s"(kp), "n"(LINES > 1 ? 0x40 : 0), "n"(LINES > 2 ? 0x80 : 0), "n"(LINES > 3 ? 0xc0 : 0), "n"(LINES > 4 ? 0x100 : 0),
+          "n"(LINES > 5 ? 0x140 : 0), "n"(LINES > 6 ? 0x180 : 0), "n"(LINES > 7 ? 0x1c0 : 0), "n"(LINES > 8 ? 0x200 : 0),
+          "n"(LINES > 9 ? 0x240 : 0)
+        : "memory");
+}
+
 __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t bi) {
     return bi < 0 || c < bc || (c == bc && i < bi);
 }
@@ -307,6 +336,7 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
 __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
                                                                       int count_inline, int copy_states, FinalizeOut *dev_out,
                                                                       FinalizeOut *host_out, unsigned long long seq) {
+    touch_kernargs<10>();
     finalize_body(a, partials, n_partials, count_inline, copy_states, dev_out, host_out, seq);
 }
 
@@ -361,32 +391,55 @@ struct LonPair {
     int L;          // traj_len clamped to [1, N+1]
 };
 
-// longitudinal polynomial of a (T, longitudinal sample) pair: sampling.py:253-266
-template <bool COEFFS_IN>
-__device__ __forceinline__ LonPair lon_pair(const KArgs &a, int64_t pair, int n) {
-    LonPair r;
-    r.lat_T = 0.0;
+// raw inputs of a pair's longitudinal polynomial (loads only, so that they can be requested early)
+struct LonPairIn {
+    double c[6];   // COEFFS_IN: the coefficients; grid mode: c[0] = T, c[1] = longitudinal sample
     int L;
+};
+
+template <bool COEFFS_IN>
+__device__ __forceinline__ LonPairIn lon_pair_fetch(const KArgs &a, int64_t pair) {
+    LonPairIn r;
     if (COEFFS_IN) {
         const double *pl = a.lon_coeffs + 6 * pair;
-        r.lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
-        L = a.traj_len_c[pair];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) r.c[k] = pl[k];
+        r.L = a.traj_len_c[pair];
     } else {
         const int iT = (int)((uint32_t)pair / (uint32_t)a.nL), iL = (int)((uint32_t)pair - (uint32_t)iT * (uint32_t)a.nL);
-        const double T = a.T[iT];
-        L = a.traj_len[iT];
+        r.c[0] = a.T[iT];
+        r.c[1] = a.L[iL];
+        r.L = a.traj_len[iT];
+    }
+    return r;
+}
+
+// longitudinal polynomial of a (T, longitudinal sample) pair: sampling.py:253-266
+template <bool COEFFS_IN>
+__device__ __forceinline__ LonPair lon_pair_make(const KArgs &a, const LonPairIn &in, int n) {
+    LonPair r;
+    r.lat_T = 0.0;
+    if (COEFFS_IN) {
+        r.lon = {in.c[0], in.c[1], in.c[2], in.c[3], in.c[4], in.c[5]};
+    } else {
+        const double T = in.c[0];
         if (a.lon_mode == RP_LON_STOPPING)
-            r.lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);  // sampling.py:259-263
+            r.lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], in.c[1], 0.0, 0.0, T);  // sampling.py:259-263
         else
-            r.lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);             // sampling.py:254-258
+            r.lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, in.c[1]);             // sampling.py:254-258
         r.lat_T = T;
         if (a.low_vel_mode) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
             const double sg = r.lon.pos(T) - a.x0_lon[0];
             r.lat_T = sg <= 0.0 ? T : sg;
         }
     }
-    r.L = L > n ? n : (L < 1 ? 1 : L);
+    r.L = in.L > n ? n : (in.L < 1 ? 1 : in.L);
     return r;
+}
+
+template <bool COEFFS_IN>
+__device__ __forceinline__ LonPair lon_pair(const KArgs &a, int64_t pair, int n) {
+    return lon_pair_make<COEFFS_IN>(a, lon_pair_fetch<COEFFS_IN>(a, pair), n);
 }
 
 // step i of a pair's profile -> f[PF_FIELDS]
@@ -432,6 +485,7 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
 __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     extern __shared__ double lds[];
+    touch_kernargs<9>();
     const int tid = threadIdx.x;
     const int n_ref = a.n_ref;
     const double *tab;
@@ -507,10 +561,9 @@ struct CandIn {
     int64_t pair_slot;
 };
 
-// hdrs[pair - hdr_pair0]: the pair headers written by rp_lon_kernel (global) or by the workgroup itself (LDS)
+// lateral input of a candidate (global loads only): the lateral sample d, or the explicit coefficients
 template <bool COEFFS_IN>
-__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, const PairHdr *hdrs, int64_t hdr_pair0) {
-    CandIn ci;
+__device__ __forceinline__ void fetch_lateral(const KArgs &a, int64_t gidx, CandIn &ci, int64_t hdr_pair0) {
     int64_t pair;
     if (COEFFS_IN) {
         const double *pt = a.lat_coeffs + 6 * gidx;
@@ -524,11 +577,22 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
         ci.v[0] = a.D[g32 - p32 * nd];
     }
     ci.pair_slot = pair - hdr_pair0;
+}
+
+__device__ __forceinline__ void fetch_header(const PairHdr *hdrs, CandIn &ci) {
     const PairHdr h = hdrs[ci.pair_slot];
     ci.lat_T = h.lat_T;
     ci.s0 = h.s0;
     ci.pre_reason = h.pre_reason;
     ci.L = h.L;
+}
+
+// hdrs[pair - hdr_pair0]: the pair headers written by rp_lon_kernel (global) or by the workgroup itself (LDS)
+template <bool COEFFS_IN>
+__device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, const PairHdr *hdrs, int64_t hdr_pair0) {
+    CandIn ci;
+    fetch_lateral<COEFFS_IN>(a, gidx, ci, hdr_pair0);
+    fetch_header(hdrs, ci);
     return ci;
 }
 
@@ -554,8 +618,9 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
 // launch, the global round trip of the profile rows and the kernel boundary.
 template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
-    extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: profiles, headers, flags
+    extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
+    touch_kernargs<9>();
     const int tid = threadIdx.x;
     RP_STAMP(0);
     RP_TL(0);
@@ -582,9 +647,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const double *prof_base = a.profile;
     const PairHdr *hdr_base = a.pair_hdr;
     int64_t pair0 = a.pair_begin;
+    CandIn cin;
+    ProfStep pf_carry;   // first step block of the NEXT candidate to run (initially the first one): always requested
+                         // ahead of the current candidate's state-row stores so that it never queues behind them
     if (LON_FUSED) {
+        // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes
         const int n0 = a.N + 1;
-        double *const lds_prof = lds_out;
+        double *const lds_tab = lds_out;
+        double *const lds_prof = lds_tab + a.table_words;   // table_words is even: 16-byte aligned
         PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_FIELDS * (size_t)n0);
         int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
@@ -596,14 +666,33 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int64_t p_last = COEFFS_IN ? g_last : (int64_t)((uint32_t)g_last / (uint32_t)a.nD);
         int P = (int)(p_last - p_first) + 1;
         P = P > a.lds_pairs ? a.lds_pairs : P;   // (cannot happen: the host sizes lds_pairs for the worst alignment)
+        const int items = P * n0;                // item = (pair, step)
+        // -- every global load of the prologue is requested here, one round trip for all of them:
+        //    this lane's candidate input, the grid values of its first item, the table block
+        {
+            const int64_t slot0 = wave_first + group_in_wave;
+            const int64_t g0 = a.single_index ? g_first : a.cand_begin + (slot0 < count ? slot0 : s_first);
+            fetch_lateral<COEFFS_IN>(a, g0, cin, p_first);
+        }
+        int j = tid;
+        LonPairIn lin;
+        if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
+        {
+            const double2 *src = reinterpret_cast<const double2 *>(a.tables);
+            double2 *dst = reinterpret_cast<double2 *>(lds_tab);
+            const int nw2 = a.table_words >> 1;
+#pragma unroll 4
+            for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+        }
         if (tid < P) lds_flags[tid] = 0;
         if (tid < 10) sh_cnt[tid] = 0;
         if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
         __syncthreads();
-        const RefTab rt = ref_tab(a.tables, a.n_ref);
-        for (int j = tid; j < P * n0; j += RP_BLOCK) {   // item = (pair, step)
+        RP_STAMP(4);    // single-launch prologue: inputs and tables have arrived
+        const RefTab rt = ref_tab(lds_tab, a.n_ref);
+        while (j < items) {
             const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
-            const LonPair lp = lon_pair<COEFFS_IN>(a, p_first + p, n0);
+            const LonPair lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
             double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
@@ -613,23 +702,26 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             if (i < lp.L) fl = (fabs(f[PF_SDD]) > a.a_max ? 1 : 0) | (f[PF_SD] < -RP_EPS ? 2 : 0);
             if (fl) atomicOr(&lds_flags[p], fl);
             if (i == 0) { lds_hdr[p].lat_T = lp.lat_T; lds_hdr[p].s0 = lp.lon.c0; lds_hdr[p].L = lp.L; }
+            j += RP_BLOCK;
+            if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
         }
         __syncthreads();
-        if (tid < P) {
-            const int fl = lds_flags[tid];
-            lds_hdr[tid].pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
-                                      : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
-        }
-        __syncthreads();
+        RP_STAMP(10);   // single-launch prologue: profile rows in LDS
         prof_base = lds_prof;
         hdr_base = lds_hdr;
         pair0 = p_first;
-    }
-
-    CandIn cin;
-    ProfStep pf_carry;   // first step block of the NEXT candidate to run (initially the first one): always requested
-                         // ahead of the current candidate's state-row stores so that it never queues behind them
-    {
+        // header of this lane's candidate; the pre-filter verdict comes from the votes
+        {
+            const PairHdr h = lds_hdr[cin.pair_slot];
+            const int fl = lds_flags[cin.pair_slot];
+            cin.lat_T = h.lat_T;
+            cin.s0 = h.s0;
+            cin.L = h.L;
+            cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
+                             : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
+            pf_carry = load_profile(lds_prof + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+        }
+    } else {
         const int64_t slot0 = wave_first + group_in_wave;
         const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
         cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
@@ -677,7 +769,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     for (int64_t w0 = wave_first; w0 < count; w0 += total_groups) {   // wave-uniform trip count
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
         const bool valid = slot < count;
-        const int64_t gidx = a.single_index ? *a.single_index : a.cand_begin + (valid ? slot : 0);
+        // (lanes without a candidate shadow one whose profile rows exist: slot 0, or the workgroup's first)
+        const int64_t gidx = a.single_index ? *a.single_index
+                                            : a.cand_begin + (valid ? slot : (LON_FUSED ? (int64_t)blockIdx.x * GPB : (int64_t)0));
 
         // ---- lateral polynomial: sampling.py:226-238, 268-270
         const int L = cin.L;
