@@ -22,6 +22,8 @@
 namespace {
 
 constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
+constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
+constexpr int kFoldThreshold = 2048;
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
 
 using ResultBlock = FinalizeOut;   // device -> host result block (rp_kernels.h)
@@ -61,12 +63,11 @@ struct rp_ctx {
     size_t cap_profile = 0, cap_profile_one = 0;
     PairHdr *d_pair_hdr = nullptr, *d_pair_hdr_one = nullptr;
     size_t cap_pair_hdr = 0;
-    BlockPartial *d_partials = nullptr;
+    BlockPartial *d_partials = nullptr;   // [cap_partials] one per workgroup, then [kFoldPartials] folded ones
     int cap_partials = 0;
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
-    unsigned int *d_fin_counter = nullptr;   // "workgroups done" word of the fused selection epilogue
     unsigned long long *d_debug = nullptr;   // diagnostic build only
     unsigned long long seq = 0;              // completion tickets handed to the kernels
     bool spin_wait = true;                   // wait for the ticket in the pinned result block instead of hipStreamSynchronize
@@ -254,8 +255,8 @@ void launch_lon(rp_ctx *c, const KArgs &ka, bool cin) {
 int eval_grid(const rp_ctx *c, int64_t count, int G) {
     const int gpb = RP_BLOCK / G;
     int64_t blocks = (count + gpb - 1) / gpb;
-    int64_t cap = (int64_t)c->num_cus * kBlocksPerCU;
-    return (int)std::max<int64_t>(1, std::min(blocks, cap));
+    (void)c;
+    return (int)std::max<int64_t>(1, blocks);   // the grid covers the batch: one candidate per lane group
 }
 
 void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs &ka) {
@@ -325,8 +326,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
         c->cap_partials = 0;
-        int want = std::max(grid, c->num_cus * kBlocksPerCU);
-        HIP_TRY(c, hipMalloc((void **)&c->d_partials, sizeof(BlockPartial) * (size_t)want));
+        int want = std::max(grid + grid / 4, c->num_cus * kBlocksPerCU);
+        HIP_TRY(c, hipMalloc((void **)&c->d_partials, sizeof(BlockPartial) * ((size_t)want + kFoldPartials)));
         c->cap_partials = want;
     }
     ka.partials = c->d_partials;
@@ -340,13 +341,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     const unsigned long long seq = ++c->seq;
     if (ticket) hrb_host->seq = 0;
     const unsigned long long fin_seq = (ticket && !winner_pass) ? seq : 0ull;
-    // Optional: selection epilogue on the evaluation kernel's last workgroup instead of a separate launch.
-    // Measured SLOWER on MI355X (cfg2: eval 21.6 -> 37.8 us): every workgroup then pays an agent-scope release
-    // fence (L2 write-back) before its ticket, which costs more than one kernel boundary.  Off by default.
-    const bool fused_fin = !skip_eval && count > 0 && std::getenv("RP_AMD_FUSED_FINALIZE") != nullptr;
-    ka.fin_counter = fused_fin ? c->d_fin_counter : nullptr;
-    ka.fin_dev = drb; ka.fin_host = hrb_dev;
-    ka.fin_count_inline = small ? 1 : 0; ka.fin_copy_states = copy_states ? 1 : 0; ka.fin_seq = fin_seq;
+    // (A selection epilogue run by the evaluation kernel's last workgroup was tried and measured slower -- cfg2: eval
+    //  21.6 -> 37.8 us: every workgroup then pays an agent-scope release fence, an L2 write-back, before its ticket.)
     const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
@@ -377,9 +373,17 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         else
             n_partials = 0;
     }
-    if (!fused_fin)
-        hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, c->d_partials, n_partials,
+    {
+        const BlockPartial *fin_in = c->d_partials;
+        if (n_partials > kFoldThreshold) {   // one partial per workgroup of a large batch: fold before the one-workgroup epilogue
+            BlockPartial *folded = c->d_partials + c->cap_partials;
+            hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, n_partials, folded);
+            fin_in = folded;
+            n_partials = kFoldPartials;
+        }
+        hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, fin_in, n_partials,
                            small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, fin_seq);
+    }
     if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
         const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
         hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
@@ -396,7 +400,6 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.coeffs = nullptr;
         kw.partials = nullptr;
-        kw.fin_counter = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
         if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds);
@@ -483,8 +486,6 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_fin_counter, sizeof(unsigned int)));
-    HIP_TRY(c, hipMemset(c->d_fin_counter, 0, sizeof(unsigned int)));
 #if defined(RP_STAMPS) || defined(RP_TIMELINE)
     HIP_TRY(c, hipMalloc((void **)&c->d_debug, (32 + 2 * 4096) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
@@ -500,7 +501,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs, c->d_profile, c->d_profile_one,
-                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_fin_counter};
+                   c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -771,7 +772,6 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
     kw.coeffs = nullptr;
     kw.partials = nullptr;
-    kw.fin_counter = nullptr;
     // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own
     if ((rc = grow(c, c->d_profile_one, c->cap_profile_one, (size_t)PF_FIELDS * (size_t)n)) != RP_OK) return rc;
     kw.pair_begin = c->last_coeffs ? index : index / l.nD;

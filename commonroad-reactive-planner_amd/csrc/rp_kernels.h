@@ -17,8 +17,9 @@
 
 #define RP_BLOCK 256  // 4 wavefronts per workgroup
 #ifndef RP_WAVES_PER_SIMD
-#define RP_WAVES_PER_SIMD 2  // register budget of the evaluation kernel: 512 / 2 = 256 VGPRs (no scratch spills;
-                             // measured faster than 3 or 4 waves with spills, profiles/r01_occupancy_ab.txt)
+#define RP_WAVES_PER_SIMD 3  // register budget of the evaluation kernel: 512 / 3 -> 168 VGPRs.  One wavefront issues
+                             // an instruction only every ~10-13 cycles (profiles/r01_instruction_costs.txt), so the
+                             // vector ALU needs >= 3 resident wavefronts per SIMD to fill; 4 would spill to scratch
 #endif
 
 // Everything the evaluation kernel needs; passed by value (kernarg segment).
@@ -68,11 +69,6 @@ struct KArgs {
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
     unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
     unsigned long long seq_value;
-    // selection epilogue run by the last workgroup of rp_eval_kernel (fin_counter != nullptr)
-    unsigned int *fin_counter;      // device word, zero between launches (the last workgroup resets it)
-    struct FinalizeOut *fin_dev, *fin_host;
-    int32_t fin_count_inline, fin_copy_states;
-    unsigned long long fin_seq;
 };
 
 // fields of one step of a longitudinal profile
@@ -202,7 +198,7 @@ __device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
     }
 }
 
-// Body shared by rp_finalize_kernel and by the LAST workgroup of rp_eval_kernel (blockDim.x == RP_FIN_THREADS).
+// Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).
 __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial *partials, int n_partials, int count_inline,
                                               int copy_states, FinalizeOut *dev_out, FinalizeOut *host_out,
                                               unsigned long long seq) {
@@ -633,8 +629,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int group_in_wave = gbase / G;
     const int grp = tid / G;              // group inside the block
 
-    if (a.single_index && *a.single_index < 0) return;   // no winner to re-evaluate (uniform)
-    const int64_t total_groups = (int64_t)gridDim.x * GPB;
+    if (a.single_index && *a.single_index < 0) {   // no winner to re-evaluate (uniform): only the completion ticket
+        if (a.host_seq && tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave
     const int64_t count = a.single_index ? 1 : a.count;
 
@@ -648,8 +646,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const PairHdr *hdr_base = a.pair_hdr;
     int64_t pair0 = a.pair_begin;
     CandIn cin;
-    ProfStep pf_carry;   // first step block of the NEXT candidate to run (initially the first one): always requested
-                         // ahead of the current candidate's state-row stores so that it never queues behind them
+    ProfStep pf0;        // first step block of this lane group's candidate
     if (LON_FUSED) {
         // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes
         const int n0 = a.N + 1;
@@ -719,7 +716,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             cin.L = h.L;
             cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
                              : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
-            pf_carry = load_profile(lds_prof + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+            pf0 = load_profile(lds_prof + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
         }
     } else {
         const int64_t slot0 = wave_first + group_in_wave;
@@ -727,7 +724,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
         const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0;
         const int n0 = a.N + 1;
-        pf_carry = load_profile(prof_base + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+        pf0 = load_profile(prof_base + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
     }
 
     if (!LON_FUSED) {
@@ -766,7 +763,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         return cst;
     };
 
-    for (int64_t w0 = wave_first; w0 < count; w0 += total_groups) {   // wave-uniform trip count
+    // The grid covers the batch: every lane group evaluates exactly one candidate (no persistent loop -- a loop over
+    // candidates costs ~40 VGPRs of hoisted invariants and look-ahead state, i.e. the third wavefront per SIMD).
+    if (wave_first < count) {   // wave-uniform
+        const int64_t w0 = wave_first;
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
         const bool valid = slot < count;
         // (lanes without a candidate shadow one whose profile rows exist: slot 0, or the workgroup's first)
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
         const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - pair0;
         const double *const prow = prof_base + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
-        ProfStep pf = pf_carry;   // this candidate's first step block (requested one candidate ago)
+        ProfStep pf = pf0;
         {
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
@@ -1025,18 +1025,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 RP_STAMP(11);  // collision
             }
         }
-        // next candidate's inputs (software pipelining; consumed at the top of the next iteration)
-        if (w0 + total_groups < count) {
-            const int64_t nslot = slot + total_groups;
-            cin = fetch_candidate<COEFFS_IN>(a, a.cand_begin + (nslot < count ? nslot : 0), hdr_base, pair0);
-        }
         RP_STAMP(12);  // state stores issued, chunk loop done
-        if (w0 + total_groups < count) {   // next candidate's first profile rows, ahead of the copy-out burst below
-            const int64_t nslot = slot + total_groups;
-            const int64_t ng = a.cand_begin + (nslot < count ? nslot : 0);
-            const int64_t nps = (COEFFS_IN ? ng : (int64_t)((uint32_t)ng / (uint32_t)a.nD)) - pair0;
-            pf_carry = load_profile(prof_base + ((size_t)nps * PF_FIELDS) * (size_t)n, n, gl <= N ? gl : N);
-        }
         if (MAT && STAGE_OUT) {   // linear copy-out of this wavefront's candidates (wave-uniform)
             // blocks are written for every candidate that passed the pre-filter; failed candidates keep
             // whatever steps were computed (same contract as direct stores)
@@ -1101,26 +1090,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
             a.partials[blockIdx.x] = bp;
         }
-        // ---- selection epilogue by the workgroup that finishes last (no separate launch).  Visibility of the
-        //      other workgroups' partials: agent-scope release before the ticket, acquire after it
-        //      (cdna_hip_programming.md, Guideline 16).
-        if (a.fin_counter) {
-            __shared__ int sh_last_block;
-            if (tid == 0) {
-                __threadfence();
-                const unsigned int t = atomicAdd(a.fin_counter, 1u);
-                sh_last_block = (t == gridDim.x - 1);
-                if (sh_last_block) {
-                    *a.fin_counter = 0u;   // ready for the next launch (stream order)
-                    __threadfence();
-                }
-            }
-            __syncthreads();
-            if (sh_last_block) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                finalize_body(a, a.partials, (int)gridDim.x, a.fin_count_inline, a.fin_copy_states, a.fin_dev, a.fin_host, a.fin_seq);
-            }
-        }
     }
     RP_STAMP(14);
     RP_TL(1);
@@ -1128,6 +1097,37 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         __threadfence_system();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large batches leave one partial per workgroup (tens of thousands): fold them to gridDim.x partials
+// before the one-workgroup selection epilogue.  One wavefront per output partial.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rp_fold_partials_kernel(const BlockPartial *in, int n_in, BlockPartial *out) {
+    const int lane = threadIdx.x;
+    double bc = 0.0;
+    long long bi = -1;
+    double cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // exact in double: counts are far below 2^53
+    for (int k = blockIdx.x * 64 + lane; k < n_in; k += gridDim.x * 64) {
+        const BlockPartial p = in[k];
+        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
+        cnt[0] += (double)p.n_feasible;
+        cnt[1] += (double)p.n_collision;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cnt[2 + r] += (double)p.reasons[r];
+    }
+    wave_min_pair(bc, bi);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) cnt[r] = group_sum_last<64>(cnt[r]);
+    if (lane == 63) {
+        BlockPartial o;
+        o.best_cost = bc;
+        o.best_index = bi;
+        o.n_feasible = (int64_t)cnt[0];
+        o.n_collision = (int64_t)cnt[1];
+        for (int r = 0; r < 8; ++r) o.reasons[r] = (int64_t)cnt[2 + r];
+        out[blockIdx.x] = o;
     }
 }
 

@@ -224,6 +224,13 @@ def test_edge_cases(ctx):
     g2 = Golden("arc_all_collide")
     g2.setup_context(ctx)
     assert ctx.plan(g2.inputs).best_index == -1
+    # ... and "no winner" must come back as promptly as a winner does (the completion ticket is written on
+    # that path too; a missing ticket shows up as the 200 ms fall-back of the host's spin wait)
+    import time
+    t0 = time.perf_counter()
+    for _ in range(5):
+        assert ctx.plan(g2.inputs).best_index == -1
+    assert (time.perf_counter() - t0) / 5 < 0.05
     out = ctx.plan(_with_flags(g2.inputs, FLAG_SKIP_COLLISION))
     assert out.best_index >= 0 and out.n_collision == 0
     # error paths: bad range, plan before reference
