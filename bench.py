@@ -8,7 +8,10 @@ One *step* = one ``rp_plan`` call over the whole candidate batch of one replanni
 parameters staged host->device inside the call: a few hundred bytes; tables resident), including
 the winner's state block coming back to the host.  N > 1: one process per GPU, every rank evaluates
 its contiguous shard of an N-times denser longitudinal grid (weak scaling) and the ranks exchange
-one (cost, index) pair + counters per step over RCCL.
+one {cost, index, counters, winner block} message per step (commonroad_rp_amd/distributed.py: shared-memory
+mailbox between the ranks of one node -- the result blocks are already in pinned host memory --, RCCL
+collectives otherwise or with RP_AMD_EXCHANGE=collective); the group, barriers and the max-over-ranks
+timing run over torch.distributed (nccl).
 
 Prints ONE JSON line (rank 0).  Modes:
   draw        every candidate fully evaluated (no pre-filter / early exit, the reference's
@@ -72,17 +75,25 @@ def run():
     import torch
     dist = None
     force_dist = os.environ.get("RP_BENCH_FORCE_DIST") == "1"   # rehearse the N > 1 code path on one GPU
+    # RP_BENCH_REHEARSE=1: several ranks on ONE GPU (gloo group, every rank on cuda:0) -- a functional rehearsal of
+    # the N > 1 path on a one-GPU box; its timings mean nothing
+    rehearse = os.environ.get("RP_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import (RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL)
-    from commonroad_rp_amd.distributed import shard_range, exchange_winner
+    from commonroad_rp_amd.distributed import shard_range, exchange_winner, close_exchanges
 
     flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[args.mode]
     base = W.WORKLOADS[args.workload]()
@@ -124,7 +135,7 @@ def run():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if rehearse else torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -162,7 +173,8 @@ def run():
         "config": {"workload": f"{base.name}: {w.description}", "mode": args.mode, "candidates_per_step": C_total,
                    "candidates_per_gpu": C_loc, "horizon_steps": N,
                    "n_obstacles": int(w.obstacles.dyn_obb.shape[0] + len(w.obstacles.static_obb)),
-                   "parallelism": f"candidate-range sharding x{world}"},
+                   "parallelism": f"candidate-range sharding x{world}",
+                   "exchange": (os.environ.get("RP_AMD_EXCHANGE", "auto") if dist is not None else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rp_eval_kernel",
                      "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
@@ -203,6 +215,7 @@ def run():
             result["cpu_baseline"] = cpu_baseline(w, inp, args.cpu_seconds)
     ctx.close()
     if dist is not None:
+        close_exchanges()
         dist.destroy_process_group()
     return json.dumps(result) if rank == 0 else None
 

@@ -10,10 +10,20 @@ evaluates a contiguous range of the reference's list index and the ranks exchang
      candidates that sort before the *global* winner, ``rp_count_collisions_before``) and one
      all_reduce(sum) of 8 bytes -> ``infeasible_count_collision``
 
-over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
 This replaces the reference's only "communication backend", the multiprocessing.Queue fan-out of
 ReactivePlanner._get_optimal_trajectory (commonroad_rp/reactive_planner.py:1084-1111).
 Messages are latency-bound; no state block other than a rank's winner ever crosses GPUs.
+
+Two transports carry the same two messages:
+
+  * ``CollectiveExchange``  ``torch.distributed`` collectives (backend "nccl" = RCCL over xGMI on the GPU box,
+    "gloo" in CPU tests).  Works across nodes.  On a 40-us replanning step the fixed cost of a device collective
+    (pack, H2D, RCCL launch + ring latency, D2H, sync: ~60 us measured on MI355X) is larger than the step.
+  * ``MailboxExchange``     ranks of ONE node: every rank's result block already sits in its pinned host memory
+    when ``rp_plan`` returns (the kernels write it there), so the ranks post their 3.7 KB messages to a POSIX
+    shared-memory mailbox and spin on per-rank sequence words -- one cache-line hand-over per peer instead of a
+    device collective.  Chosen automatically when all ranks report the same host (``transport="auto"``);
+    ``torch.distributed`` is still what sets the group up and carries barriers.
 """
 from __future__ import annotations
 
@@ -55,8 +65,7 @@ def combine_results(msgs: np.ndarray, n: int):
     """msgs: [world, HEAD + 14 n] -> (global PlanOutput without the collision-before count, owner rank)."""
     mi = msgs.view(np.int64)
     owner, cost, idx = -1, np.nan, -1
-    for r in range(msgs.shape[0]):
-        i, c = int(mi[r, 1]), float(msgs[r, 0])
+    for r, (c, i) in enumerate(zip(msgs[:, 0].tolist(), mi[:, 1].tolist())):
         if i >= 0 and (idx < 0 or c < cost or (c == cost and i < idx)):
             owner, cost, idx = r, c, i
     counters = mi[:, 2:12].sum(axis=0)
@@ -72,7 +81,84 @@ def combine_results(msgs: np.ndarray, n: int):
     return out, owner
 
 
-class WinnerExchange:
+class MailboxExchange:
+    """Shared-memory mailbox of the ranks of one node.  Slot layout per (parity, rank), 64-byte aligned:
+    ``[seq u64 | 7 pad][HEAD + 14 n doubles][cnt_seq u64][cnt i64][6 pad]``.  Two parities alternate between
+    consecutive steps: a rank can run at most one step ahead of the slowest reader (it cannot finish step k+1
+    before every peer has published k+1, which a peer does only after it has read step k), so the buffer a rank
+    overwrites at step k+2 has been read by everyone."""
+
+    def __init__(self, dist, n: int, name_hint: str = ""):
+        from multiprocessing import shared_memory
+        self.dist, self.n = dist, n
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.words = 8 + HEAD + N_ARRAYS * n + 8          # doubles per slot
+        self.words = (self.words + 7) & ~7                 # 64-byte multiple
+        size = 2 * self.world * self.words * 8
+        names = [None]
+        if self.rank == 0:
+            self.shm = shared_memory.SharedMemory(create=True, size=size)
+            self.shm.buf[:size] = bytes(size)
+            names = [self.shm.name]
+        dist.broadcast_object_list(names, src=0)
+        if self.rank != 0:
+            self.shm = shared_memory.SharedMemory(name=names[0])
+            try:   # the creator unlinks; do not let this process's resource tracker do it as well
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self.shm._name, "shared_memory")
+            except Exception:
+                pass
+        self.box = np.ndarray((2, self.world, self.words), dtype=np.float64, buffer=self.shm.buf)
+        self.ibox = self.box.view(np.int64)
+        self.seq = 0
+        self._msgs = np.zeros((self.world, HEAD + N_ARRAYS * n), dtype=np.float64)
+        dist.barrier()   # everyone is attached before the first post
+
+    def close(self):
+        try:
+            self.box = self.ibox = None
+            self.shm.close()
+            if self.rank == 0:
+                self.shm.unlink()
+        except Exception:
+            pass
+
+    def _wait(self, par: int, word: int, value: int):
+        col = self.ibox[par, :, word]
+        spins = 0
+        while not (col == value).all():
+            spins += 1
+            if spins > 50_000_000:
+                raise TimeoutError("MailboxExchange: a peer rank did not post its result")
+
+    def __call__(self, ctx, out: PlanOutput) -> PlanOutput:
+        self.seq += 1
+        k, par, r = self.seq, self.seq & 1, self.rank
+        pack_result(out, self.n, self.box[par, r, 8:8 + HEAD + N_ARRAYS * self.n])
+        self.ibox[par, r, 0] = k                       # publish (x86: stores are not reordered with older stores)
+        self._wait(par, 0, k)
+        np.copyto(self._msgs, self.box[par, :, 8:8 + HEAD + N_ARRAYS * self.n])
+        glob, _owner = combine_results(self._msgs, self.n)
+        glob.kernel_ms = out.kernel_ms
+        if glob.n_collision > 0:   # second pass only when some rank saw a colliding candidate
+            c0 = 8 + HEAD + N_ARRAYS * self.n
+            n_before = ctx.count_collisions_before(glob.best_cost if glob.best_index >= 0 else 0.0, glob.best_index)
+            self.ibox[par, r, c0 + 1] = int(n_before)
+            self.ibox[par, r, c0] = k
+            self._wait(par, c0, k)
+            glob.n_collision_before_best = int(self.ibox[par, :, c0 + 1].sum())
+        return glob
+
+
+def same_host(dist) -> bool:
+    """True when every rank of the default group runs on this host."""
+    import socket
+    names = [None] * dist.get_world_size()
+    dist.all_gather_object(names, socket.gethostname())
+    return all(nm == names[0] for nm in names)
+
+
+class CollectiveExchange:
     """Persistent buffers + the two collectives of one sharded replanning step."""
 
     def __init__(self, dist, device, n: int):
@@ -108,15 +194,38 @@ class WinnerExchange:
         return glob
 
 
+WinnerExchange = CollectiveExchange   # former name
+
 _exchanges = {}
 
 
-def exchange_winner(ctx, out: PlanOutput, dist, device) -> PlanOutput:
+def exchange_winner(ctx, out: PlanOutput, dist, device, transport: str = "auto") -> PlanOutput:
     """Combine the per-rank results of one sharded ``rp_plan`` into the global result.
-    ``ctx`` must still hold the rank's last plan (for the optional second pass)."""
+    ``ctx`` must still hold the rank's last plan (for the optional second pass).
+    ``transport``: "mailbox" (ranks of one node), "collective" (``torch.distributed``), or "auto".
+    The choice is collective on first use (all ranks must pass the same value)."""
+    import os
     n = (out.best_states.shape[1] if out.best_states is not None else ctx._N + 1)
-    key = (id(dist), str(device), n, dist.get_world_size())
+    transport = os.environ.get("RP_AMD_EXCHANGE", transport)
+    key = (id(dist), str(device), n, dist.get_world_size(), transport)
     ex = _exchanges.get(key)
     if ex is None:
-        ex = _exchanges[key] = WinnerExchange(dist, device, n)
+        use_mailbox = transport == "mailbox" or (transport == "auto" and same_host(dist))
+        if use_mailbox:
+            try:
+                ex = MailboxExchange(dist, n)
+            except (OSError, ImportError):
+                if transport == "mailbox":
+                    raise
+        if ex is None:
+            ex = CollectiveExchange(dist, device, n)
+        _exchanges[key] = ex
     return ex(ctx, out)
+
+
+def close_exchanges():
+    """Release the shared-memory mailboxes (call before ``destroy_process_group``)."""
+    for ex in _exchanges.values():
+        if hasattr(ex, "close"):
+            ex.close()
+    _exchanges.clear()

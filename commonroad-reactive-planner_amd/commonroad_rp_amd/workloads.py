@@ -113,7 +113,7 @@ def _with_d0(D: np.ndarray, d0: float) -> np.ndarray:
 
 
 def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired_speed=None, extra_obstacles=0,
-                       flags=0, description="") -> Workload:
+                       flags=0, description="", extra_jitter=1.5, extra_lane=4.0) -> Workload:
     sc = _load_scenario(scen_name)
     dt = float(sc["dt"])
     co = CoordinateSystem(smooth_ref_path(sc["centre"]))
@@ -134,8 +134,8 @@ def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired
         ext[:dyn.shape[0], :dyn.shape[1]] = dyn
         s_max = co.ref_pos[-1]
         for j in range(extra_obstacles):   # constant-velocity 4.5 x 2.0 m boxes along the route
-            s0, vel, off = rng.uniform(0.0, s_max), rng.uniform(5.0, 15.0), rng.uniform(-1.5, 1.5)
-            lane = rng.choice([-1.0, 1.0]) * 4.0      # neighbouring lanes
+            s0, vel, off = rng.uniform(0.0, s_max), rng.uniform(5.0, 15.0), rng.uniform(-extra_jitter, extra_jitter)
+            lane = rng.choice([-1.0, 1.0]) * extra_lane      # neighbouring lanes
             for k in range(n_steps):
                 s = s0 + vel * dt * k
                 if s >= s_max - 1.0:
@@ -174,8 +174,10 @@ def cfg3(flags: int = 0) -> Workload:
     """DEU_Test-1_1_T-1, 31 x 31 x 63 grid, N = 60, 1 static + 1 dynamic + 49 synthetic obstacles."""
     dt, N = 0.1, 60
     T = [dt * (30 + k) for k in range(31)]
+    # synthetic boxes 5 m either side of the route (+- 1.5 m): at 4 m every candidate collides with something
+    # within the 6 s horizon and no replanning step has a winner; at 5 m ~1.5 % of the feasible candidates survive
     return _scenario_workload("cfg3", "DEU_Test-1_1_T-1", N, T, 63, 31, low_vel_threshold=4.0, extra_obstacles=49,
-                              flags=flags,
+                              flags=flags, extra_lane=5.0,
                               description="DEU_Test-1_1_T-1, 31x31x63 grid, N=60, 51 obstacles (49 synthetic, seed 0)")
 
 

@@ -18,7 +18,7 @@ def main():
     import torch.distributed as dist
     from _golden import Golden
     from _oracle_ctx import OracleContext
-    from commonroad_rp_amd.distributed import shard_range, exchange_winner
+    from commonroad_rp_amd.distributed import shard_range, exchange_winner, close_exchanges
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -35,6 +35,7 @@ def main():
                              n_candidates=glob.n_candidates, reasons=glob.reason_counts.tolist(),
                              states_sum=None if glob.best_states is None else float(np.sum(glob.best_states)),
                              lon=glob.best_lon_coeffs.tolist())
+    close_exchanges()
     dist.barrier()
     with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
         json.dump(results, f)

@@ -24,10 +24,13 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_exchange_matches_unsharded(tmp_path, world):
-    port = 29650 + world
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1")
+@pytest.mark.parametrize("world,transport", [(2, "mailbox"), (3, "mailbox"), (2, "collective"), (3, "auto")])
+def test_sharded_exchange_matches_unsharded(tmp_path, world, transport):
+    """Both transports of the winner exchange: the shared-memory mailbox of the ranks of one node (what
+    bench.py --gpus N uses) and the torch.distributed collectives (gloo here, RCCL on the GPU box)."""
+    port = 29650 + world + {"mailbox": 0, "collective": 10, "auto": 20}[transport]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), OMP_NUM_THREADS="1",
+               RP_AMD_EXCHANGE=transport)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(tmp_path)] + CASES,
                               env=dict(env, RANK=str(r))) for r in range(world)]
     for p in procs:
