@@ -227,47 +227,140 @@ __device__ __forceinline__ bool obb_circ(const Obb &a, double cx, double cy, dou
 // lanes of a group (consecutive time steps) read consecutive addresses.
 enum { OB_CX = 0, OB_CY, OB_UX, OB_UY, OB_HL, OB_HW, OB_R, OB_PAD, OB_ROW };  // static obb row
 struct ObsTables {
-    const double *sobb;  // [n_sobb][8]  cx, cy, ux, uy, hl, hw, r_bound, -
-    const double *tri;   // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
-    const double *circ;  // [n_circ][4]  cx, cy, r, -
-    const double *dyn;   // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent)
+    const double *sobb;     // [n_sobb][8]  cx, cy, ux, uy, hl, hw, r_bound, -
+    const double *tri;      // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
+    const double *circ;     // [n_circ][4]  cx, cy, r, -
+    const double *dyn;      // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent)
     int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0;
 };
 
+typedef const double __attribute__((address_space(1))) *gcdouble;   // the tables live in global memory
+
+// ---- wave-level culling --------------------------------------------------------------------------
+// All lanes of a wavefront hold poses that are close in space (a few candidates x consecutive time steps).
+// One circle around the ego rectangles of the lanes that want a query is tested against each obstacle's
+// bounding circle with wave-uniform arithmetic on scalar-loaded table rows; only obstacles that survive
+// reach the per-lane work (row loads, per-lane circle test, separating-axis test).  Conservative by
+// construction, so the exact results are unchanged.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {   // lanes without a valid source keep their own value
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, dpp_f32<DPP_ROW_SHR1, 0xf>(v));
+    v = fminf(v, dpp_f32<DPP_ROW_SHR2, 0xf>(v));
+    v = fminf(v, dpp_f32<DPP_ROW_SHR4, 0xf>(v));
+    v = fminf(v, dpp_f32<DPP_ROW_SHR8, 0xf>(v));       // lane 15 of every row: minimum of the row
+    v = fminf(v, dpp_f32<DPP_ROW_BCAST15, 0xa>(v));    // rows 1, 3 also see row 0, 2
+    v = fminf(v, dpp_f32<DPP_ROW_BCAST31, 0xc>(v));    // rows 2, 3 also see rows 0 + 1
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+
+struct WaveBound { double mx, my, R; };   // every ego rectangle of a querying lane lies within R of (mx, my)
+
+__device__ __forceinline__ WaveBound ego_wave_bound(bool want, double cx, double cy, double ego_r) {
+    const float inf = __builtin_huge_valf();
+    const float fx = (float)cx, fy = (float)cy;
+    const double x0 = wave_min_f32(want ? fx : inf), x1 = wave_max_f32(want ? fx : -inf);
+    const double y0 = wave_min_f32(want ? fy : inf), y1 = wave_max_f32(want ? fy : -inf);
+    WaveBound b;
+    b.mx = 0.5 * (x0 + x1);
+    b.my = 0.5 * (y0 + y1);
+    const double hx = 0.5 * (x1 - x0), hy = 0.5 * (y1 - y0);
+    // |c - (float)c| <= 2^-24 |c| for the lane values; L1 norm of the half extents >= their L2 norm (no square root)
+    b.R = hx + hy + ego_r + (fabs(b.mx) + fabs(b.my) + hx + hy) * 2.4e-7;
+    return b;
+}
+
+__device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, double cy, double r) {
+    const double dx = cx - wb.mx, dy = cy - wb.my, rr = r + wb.R;
+    return dx * dx + dy * dy <= rr * rr * 1.000001;   // false for NaN (absent)
+}
+
 // cc.collide(ego pose at scenario time index t)  (reactive_planner.py:1040-1042).
-// Bounding-circle rejection first (conservative: a small relative margin keeps it from ever
-// rejecting a pair the exact test would accept).
-__device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t) {
+// `want`: this lane asks; `masked` (wave-uniform): `near` holds this lane's (pair, step) mask of dynamic obstacles
+// (rp_kernels.h: near_mask_step), otherwise every dynamic obstacle is tested.
+// Per lane, a bounding-circle rejection comes before the exact test (conservative: a small relative margin keeps
+// it from ever rejecting a pair the exact test would accept).
+__device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, bool masked,
+                                              uint64_t near) {
     bool hit = false;
+    WaveBound wb = {0.0, 0.0, 0.0};
+    if (ob.n_sobb + ob.n_tri + ob.n_circ > 0) wb = ego_wave_bound(want, ego.cx, ego.cy, ego_r);   // wave-uniform
+    const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
     for (int j = 0; j < ob.n_sobb; ++j) {
-        const double *o = ob.sobb + j * OB_ROW;
-        double dx = o[OB_CX] - ego.cx, dy = o[OB_CY] - ego.cy, rr = ego_r + o[OB_R];
-        if (dx * dx + dy * dy <= rr * rr * 1.000001) {
-            Obb b = {o[OB_CX], o[OB_CY], o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
+        const gcdouble o = sobb + j * OB_ROW;
+        const double cx = o[OB_CX], cy = o[OB_CY], r = o[OB_R];
+        if (!coarse_near(wb, cx, cy, r)) continue;   // wave-uniform
+        const double dx = cx - ego.cx, dy = cy - ego.cy, rr = ego_r + r;
+        if (want && dx * dx + dy * dy <= rr * rr * 1.000001) {
+            Obb b = {cx, cy, o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
             hit |= obb_obb(ego, b);
         }
     }
     for (int j = 0; j < ob.n_tri; ++j) {
-        const double *o = ob.tri + j * 10;
-        double dx = o[6] - ego.cx, dy = o[7] - ego.cy, rr = ego_r + o[8];
-        if (dx * dx + dy * dy <= rr * rr * 1.000001) hit |= obb_tri(ego, o);
+        const gcdouble o = tri + j * 10;
+        const double bx = o[6], by = o[7], r = o[8];
+        if (!coarse_near(wb, bx, by, r)) continue;   // wave-uniform
+        const double dx = bx - ego.cx, dy = by - ego.cy, rr = ego_r + r;
+        if (want && dx * dx + dy * dy <= rr * rr * 1.000001) {
+            const double tv[6] = {o[0], o[1], o[2], o[3], o[4], o[5]};
+            hit |= obb_tri(ego, tv);
+        }
     }
     for (int j = 0; j < ob.n_circ; ++j) {
-        const double *o = ob.circ + j * 4;
-        hit |= obb_circ(ego, o[0], o[1], o[2]);
+        const gcdouble o = circ + j * 4;
+        const double cx = o[0], cy = o[1], r = o[2];
+        if (!coarse_near(wb, cx, cy, r)) continue;   // wave-uniform
+        if (want) hit |= obb_circ(ego, cx, cy, r);
     }
-    int k = t - ob.dyn_t0;
-    if (k >= 0 && k < ob.n_steps) {
-        const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+    // dynamic obstacles: only those whose bit is set in the (pair, step) mask of the longitudinal profile
+    const int k = t - ob.dyn_t0;
+    const bool k_ok = want && k >= 0 && k < ob.n_steps;
+    const int kc = k_ok ? k : 0;
+    const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+    if (!masked) {
+        if (__any(k_ok)) {
 #pragma unroll 4
-        for (int j = 0; j < ob.n_dyn; ++j) {
-            const double *o = ob.dyn + (size_t)j * ob.n_steps + k;
-            // all seven loads are independent and issue back to back; NaN centre = obstacle absent
-            const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane],
-                         hw = o[5 * plane], rr = ego_r + o[6 * plane];
+            for (int j = 0; j < ob.n_dyn; ++j) {
+                const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
+                const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane], hw = o[5 * plane],
+                             rr = ego_r + o[6 * plane];
+                const double dx = cx - ego.cx, dy = cy - ego.cy;
+                if (k_ok && dx * dx + dy * dy <= rr * rr * 1.000001) {   // false for NaN
+                    Obb b = {cx, cy, ux, uy, hl, hw};
+                    hit |= obb_obb(ego, b);
+                }
+            }
+        }
+        return hit;
+    }
+    uint64_t m = k_ok ? near : 0;
+    const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
+    m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
+    while (__any(m != 0)) {   // wave-uniform trip count = largest number of near obstacles among the lanes
+        const bool act = m != 0;
+        const int j = act ? __ffsll((unsigned long long)m) - 1 : 0;
+        m &= m - 1;           // (0 stays 0)
+        const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
+        // all seven loads are independent and issue back to back; NaN centre = obstacle absent
+        const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane], hw = o[5 * plane],
+                     rr = ego_r + o[6 * plane];
+        const double dx = cx - ego.cx, dy = cy - ego.cy;
+        if (act && dx * dx + dy * dy <= rr * rr * 1.000001) {   // false for NaN
+            Obb b = {cx, cy, ux, uy, hl, hw};
+            hit |= obb_obb(ego, b);
+        }
+    }
+    if (__any(overflow)) {    // more than 63 dynamic obstacles: the tail is tested one by one
+        for (int j = 63; j < ob.n_dyn; ++j) {
+            const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
+            const double cx = o[0], cy = o[plane], rr = ego_r + o[6 * plane];
             const double dx = cx - ego.cx, dy = cy - ego.cy;
-            if (dx * dx + dy * dy <= rr * rr * 1.000001) {   // false for NaN
-                Obb b = {cx, cy, ux, uy, hl, hw};
+            if (overflow && dx * dx + dy * dy <= rr * rr * 1.000001) {
+                Obb b = {cx, cy, o[2 * plane], o[3 * plane], o[4 * plane], o[5 * plane]};
                 hit |= obb_obb(ego, b);
             }
         }

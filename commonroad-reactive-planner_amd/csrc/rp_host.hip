@@ -24,6 +24,8 @@ namespace {
 constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
 constexpr int kFoldThreshold = 2048;
+constexpr int kNearMaskMinObstacles = 0;  // (pair, step) broad phase of the collision query above this many dynamic obstacles
+                                          // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
 
 using ResultBlock = FinalizeOut;   // device -> host result block (rp_kernels.h)
@@ -47,7 +49,6 @@ struct rp_ctx {
     // obstacles
     double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr;
     ObsTables obs{};
-    ObsTables *d_obs = nullptr;   // device copy of the descriptor
 
     // per-call staging (pinned host + device mirror)
     char *h_stage = nullptr, *d_stage = nullptr;
@@ -74,6 +75,11 @@ struct rp_ctx {
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
+    // RP_AMD_TIMING=1: host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
+    bool timing = false;
+    double t_sum[4] = {0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack
+    unsigned long long t_calls = 0;
+    std::chrono::steady_clock::time_point t_entry;
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
     std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
@@ -288,7 +294,7 @@ void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs
     ka.c_yaw = 1e5 / p->dt;
     ka.c_kdot = p->dt * p->v_delta_max / p->wheelbase;
     ka.proj_d_limit = c->proj_d_limit;
-    ka.obs = c->d_obs;
+    ka.obs = c->obs;
     ka.debug = c->d_debug;
     ka.has_obstacles = (c->obs.n_sobb + c->obs.n_tri + c->obs.n_circ > 0 || (c->obs.n_dyn > 0 && c->obs.n_steps > 0)) ? 1 : 0;
 }
@@ -344,6 +350,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     // (A selection epilogue run by the evaluation kernel's last workgroup was tried and measured slower -- cfg2: eval
     //  21.6 -> 37.8 us: every workgroup then pays an agent-scope release fence, an L2 write-back, before its ticket.)
     const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
+    const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
         if (count > 0 && !fused_lds) {
@@ -406,6 +413,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         else launch_eval(c, kw, 1, true, cin, G);
     }
     HIP_TRY(c, hipGetLastError());
+    const auto tp1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     bool done = false;
     if (ticket) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
         const volatile unsigned long long *flag = &hrb_host->seq;
@@ -418,6 +426,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         }
     }
     if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const auto tp2 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
     *result = hrb->r;
@@ -445,6 +454,14 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         std::fprintf(stderr, "\n");
     }
 #endif
+    if (c->timing && !skip_eval) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        c->t_sum[0] += us(c->t_entry, tp0); c->t_sum[1] += us(tp0, tp1); c->t_sum[2] += us(tp1, tp2); c->t_sum[3] += us(tp2, tp3);
+        c->t_calls++;
+    }
     result->kernel_ms = 0.0;
     if (timed) {
         float ms = 0.f;
@@ -484,23 +501,25 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_obs, sizeof(ObsTables)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
 #if defined(RP_STAMPS) || defined(RP_TIMELINE)
     HIP_TRY(c, hipMalloc((void **)&c->d_debug, (32 + 2 * 4096) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
 #endif
-    HIP_TRY(c, hipMemset(c->d_obs, 0, sizeof(ObsTables)));
     HIP_TRY(c, hipHostMalloc((void **)&c->h_single, sizeof(int64_t), hipHostMallocDefault));
+    c->timing = std::getenv("RP_AMD_TIMING") != nullptr;
     return RP_OK;
 }
 
 void rp_destroy(rp_ctx *c) {
     if (!c) return;
+    if (c->timing && c->t_calls)
+        std::fprintf(stderr, "rp_plan host phases over %llu calls (us): entry->launch %.2f | launches %.2f | wait %.2f | unpack %.2f\n",
+                     c->t_calls, c->t_sum[0] / c->t_calls, c->t_sum[1] / c->t_calls, c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
-                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_obs, c->d_profile, c->d_profile_one,
+                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
                    c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -634,7 +653,6 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.sobb = c->d_sobb; c->obs.tri = c->d_tri; c->obs.circ = c->d_circ; c->obs.dyn = c->d_dyn;
     c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
-    HIP_TRY(c, hipMemcpy(c->d_obs, &c->obs, sizeof(ObsTables), hipMemcpyHostToDevice));
     c->have_last = false;
     return RP_OK;
 }
@@ -643,6 +661,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
             rp_result *result, double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    if (c->timing) c->t_entry = std::chrono::steady_clock::now();
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
     const int64_t total = (int64_t)g->nT * g->nL * g->nD;
     if (total > 0x7fffffffLL) return fail(c, RP_EINVAL, "rp_plan: more than 2^31 - 1 candidates in one grid");
@@ -684,6 +703,13 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     ka.status = c->d_status; ka.cost = c->d_cost;
     ka.states = mat ? c->d_states : nullptr;
     ka.coeffs = nullptr;
+    // inputs of the (pair, step) broad phase of the collision query (rp_kernels.h: near_mask_step)
+    ka.use_near_mask = g->nD > 0 ? 1 : 0;
+    ka.lat_dmin = ka.lat_dmax = g->nD > 0 ? g->D[0] : 0.0;
+    for (int i = 1; i < g->nD; ++i) { ka.lat_dmin = std::min(ka.lat_dmin, g->D[i]); ka.lat_dmax = std::max(ka.lat_dmax, g->D[i]); }
+    ka.lat_abs_d = std::max(std::fabs(p->x0_lat[0]), std::max(std::fabs(ka.lat_dmin), std::fabs(ka.lat_dmax)));
+    if (!(ka.lat_abs_d < 1e300)) ka.use_near_mask = 0;   // NaN / inf samples: no bound
+    if (c->obs.n_dyn <= kNearMaskMinObstacles) ka.use_near_mask = 0;
     c->have_last = false;
     rc = run_pipeline(c, ka, mat, false, false, result, best_states);
     if (rc != RP_OK) return rc;

@@ -53,13 +53,16 @@ struct KArgs {
     int32_t n_ref, search_iters, n_buckets, table_words;
     double bucket_inv_h;
     double proj_d_limit;
-    const ObsTables *obs;  // device copy of the obstacle table descriptor (loaded only by the collision block)
+    ObsTables obs;         // obstacle table descriptor, by value: a pointer to a device copy costs a dependent
+                           // memory round trip before the first obstacle row can be requested
     int32_t has_obstacles, pad2_;
     // longitudinal profiles (rp_lon_kernel -> rp_eval_kernel): pairs [pair_begin, pair_begin + pair_count)
     double *profile;            // [pair_count][PF_FIELDS][N+1]
     struct PairHdr *pair_hdr;   // [pair_count]
     int64_t pair_begin, pair_count;
-    int32_t lds_pairs, pad3_;   // LON_FUSED: capacity (pairs) of the workgroup's LDS profile area
+    int32_t lds_pairs, use_near_mask;   // LON_FUSED: capacity (pairs) of the workgroup's LDS profile area | PF_NEAR masks are bounds
+    double lat_abs_d;           // max(|d0|, max |D|): largest lateral offset a lateral polynomial starts or ends at
+    double lat_dmin, lat_dmax;  // range of the lateral samples D
     // outputs
     uint32_t *status;  // [count]
     double *cost;      // [count]
@@ -72,7 +75,9 @@ struct KArgs {
 };
 
 // fields of one step of a longitudinal profile
-enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_FIELDS };
+enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_FIELDS };
+// PF_NEAR: bit pattern of a 64-bit mask, bit j = dynamic obstacle j can touch SOME candidate of the pair at this step
+// (bit 63: one of the obstacles 63, 64, ... can), see near_mask_step
 
 struct PairHdr {
     double lat_T;        // delta_tau of the lateral polynomials of this pair (sampling.py:229-237)
@@ -256,6 +261,16 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
     }
     __syncthreads();
     const int n = a.N + 1;
+    // the winner's state rows are requested now, so that their round trip overlaps the coefficient section below
+    constexpr int kRowsPerThread = 4;   // covers 14 (N+1) <= 1024 doubles in registers; longer blocks loop at the end
+    double wrow[kRowsPerThread];
+    const bool want_rows = copy_states && widx >= 0;
+    const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n : nullptr;
+#pragma unroll
+    for (int q = 0; q < kRowsPerThread; ++q) {
+        const int k = tid + q * RP_FIN_THREADS;
+        wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[k] : 0.0;
+    }
     if (tid == 0) {
         FinalizeOut &o = sh_out;
         o.r.best_index = widx;
@@ -311,11 +326,15 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
         constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
         for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
     }
-    if (copy_states && widx >= 0) {   // winner's state block straight from the materialised states
-        const double *src = a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n;
+    if (want_rows) {   // winner's state block straight from the materialised states
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
-        for (int k = tid; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
-            const double v = src[k];
+#pragma unroll
+        for (int q = 0; q < kRowsPerThread; ++q) {
+            const int k = tid + q * RP_FIN_THREADS;
+            if (k < RP_N_ARRAYS * n) { d1[k] = wrow[q]; d2[k] = wrow[q]; }
+        }
+        for (int k = tid + kRowsPerThread * RP_FIN_THREADS; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
+            const double v = wsrc[k];
             d1[k] = v;
             d2[k] = v;
         }
@@ -384,6 +403,7 @@ __device__ __forceinline__ RefTab ref_tab(const double *tab, int n_ref) {
 struct LonPair {
     Poly lon;
     double lat_T;   // delta_tau of the pair's lateral polynomials (sampling.py:229-237); 0 with COEFFS_IN
+    double T;       // the pair's time sample (grid mode)
     int L;          // traj_len clamped to [1, N+1]
 };
 
@@ -415,6 +435,7 @@ template <bool COEFFS_IN>
 __device__ __forceinline__ LonPair lon_pair_make(const KArgs &a, const LonPairIn &in, int n) {
     LonPair r;
     r.lat_T = 0.0;
+    r.T = 0.0;
     if (COEFFS_IN) {
         r.lon = {in.c[0], in.c[1], in.c[2], in.c[3], in.c[4], in.c[5]};
     } else {
@@ -424,6 +445,7 @@ __device__ __forceinline__ LonPair lon_pair_make(const KArgs &a, const LonPairIn
         else
             r.lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, in.c[1]);             // sampling.py:254-258
         r.lat_T = T;
+        r.T = T;
         if (a.low_vel_mode) {  // sampling.py:229-234 (evaluate_state_at_tau clamps nothing here: tau == delta_tau)
             const double sg = r.lon.pos(T) - a.x0_lon[0];
             r.lat_T = sg <= 0.0 ? T : sg;
@@ -476,12 +498,85 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
     f[PF_INDOM] = (s >= rt.pos_first && s <= rt.pos_last) ? 1.0 : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Broad phase of the collision query, once per (pair, step) instead of once per (candidate, step, obstacle).
+// All nD candidates of a pair are, at step i, inside a circle that follows from the pair's profile alone:
+//   valid steps (i < L):  rear axle = foot_i + d n_i with |d| <= lat_abs_d + 0.2 |d0'| T + 0.0173 |d0''| T^2
+//       (quintic Hermite basis: d = d1 + (d0 - d1) A + d0' T B + d0'' T^2 C, 0 <= A <= 1, |B| <= 0.196, |C| <= 0.01728);
+//   extended steps (i >= L, trajectories.py:168-197): rear axle = last valid point + c_i (cos, sin)(theta_last) with
+//       theta_last = theta_ref(s_last) (the lateral polynomial ends with d' = 0), c_i monotone in (v_last, a_last),
+//       which are linear in the lateral sample d at the last valid step.
+// The ego rectangle adds wb_rear_axle + ego_radius.  Obstacles whose bounding circle at this step misses that
+// circle cannot touch any candidate of the pair; the others get their bit.  Where the assumptions do not hold
+// (explicit polynomials, T not on the time grid, standstill at the last valid step, lateral variable outside
+// [0, lat_T]) every bit is set, i.e. nothing is culled.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mask_as_double(uint64_t m) { return __longlong_as_double((long long)m); }
+__device__ __forceinline__ uint64_t double_as_mask(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// dt * sum_{t=1..m} max(0, v + t dt a): distance covered by the extension after m steps (trajectories.py:182-196)
+__device__ __forceinline__ double ext_travel(double v, double acc, int m, double dt) {
+    double c = 0.0;
+    for (int t = 1; t <= m; ++t) {
+        const double vt = v + ((double)t * dt) * acc;
+        c += dt * (vt >= 0.0 ? vt : 0.0);
+    }
+    return c;
+}
+
+template <bool COEFFS_IN>
+__device__ __forceinline__ double near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, const double *f) {
+    const uint64_t all = ~0ull;
+    if (COEFFS_IN || !a.use_near_mask || !a.has_obstacles) return mask_as_double(0);   // masks unused: every obstacle is tested
+    const ObsTables &ob = a.obs;
+    if (ob.n_dyn <= 0) return mask_as_double(0);
+    const int k = a.time_step0 + i * a.factor - ob.dyn_t0;
+    if (k < 0 || k >= ob.n_steps) return mask_as_double(0);   // no dynamic obstacle exists at this scenario step
+    const int L = lp.L;
+    if (!(fabs((double)(L - 1) * a.dt - lp.T) <= 1e-9 * lp.T)) return mask_as_double(all);   // T is not the last valid step
+    const double wb = fabs(a.wb_rear_axle);
+    double cx, cy, R;
+    if (i < L) {
+        const double tau = a.low_vel_mode ? f[PF_S] - lp.lon.c0 : (double)i * a.dt;
+        if (!(tau >= 0.0 && tau <= lp.lat_T * (1.0 + 1e-12))) return mask_as_double(all);
+        const double dmax = a.lat_abs_d + 0.2 * fabs(a.x0_lat[1]) * lp.lat_T + 0.0173 * fabs(a.x0_lat[2]) * lp.lat_T * lp.lat_T;
+        cx = f[PF_PX]; cy = f[PF_PY];
+        R = dmax + wb + a.ego_radius;
+    } else {
+        double g[PF_FIELDS];
+        lon_step(a, rt, lp.lon, L - 1, g);
+        const bool moving = g[PF_INV_SD] > 0.0 || a.low_vel_mode;
+        if (!moving) return mask_as_double(all);   // orientation of the last valid step is carried, not theta_ref
+        const double sd = g[PF_SD], sdd = g[PF_SDD], kr = g[PF_KR], krd = g[PF_KRD];
+        const double d0 = a.lat_dmin, d1 = a.lat_dmax;
+        const double v0 = sd * (1.0 - kr * d0), v1 = sd * (1.0 - kr * d1);                       // v = s' (1 - k_r d) / cos(0)
+        const double a0 = sdd * (1.0 - kr * d0) - sd * sd * krd * d0, a1 = sdd * (1.0 - kr * d1) - sd * sd * krd * d1;
+        const int m = i - L + 1;
+        const double c_lo = ext_travel(fmin(v0, v1), fmin(a0, a1), m, a.dt), c_hi = ext_travel(fmax(v0, v1), fmax(a0, a1), m, a.dt);
+        double sn, cs;
+        rp_sincos(g[PF_TH_REF], &sn, &cs);
+        const double along = 0.5 * (c_lo + c_hi) + wb;
+        cx = g[PF_PX] + along * cs; cy = g[PF_PY] + along * sn;
+        R = 0.5 * (c_hi - c_lo) + fmax(fabs(d0), fabs(d1)) + a.ego_radius;
+    }
+    R = R * (1.0 + 1e-9) + 1e-6;
+    const gcdouble dyn = (gcdouble)ob.dyn;
+    const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+    uint64_t m = 0;
+    for (int j = 0; j < ob.n_dyn; ++j) {
+        const gcdouble o = dyn + (size_t)j * ob.n_steps + k;
+        const double dx = o[0] - cx, dy = o[plane] - cy, rr = R + o[6 * plane];   // NaN centre: absent, no bit
+        if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (j < 63 ? j : 63);
+    }
+    return mask_as_double(m);
+}
+
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
 // and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
 __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     extern __shared__ double lds[];
-    touch_kernargs<9>();
+    touch_kernargs<10>();
     const int tid = threadIdx.x;
     const int n_ref = a.n_ref;
     const double *tab;
@@ -518,6 +613,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
             const int i = c * G + gl;
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
+            f[PF_NEAR] = i <= N ? near_mask_step<COEFFS_IN>(a, rt, lp, i, f) : 0.0;
             bad_a |= (i < L) && (fabs(f[PF_SDD]) > a.a_max);   // pre-filter, :798
             bad_v |= (i < L) && (f[PF_SD] < -RP_EPS);          // pre-filter, :802
             if (i <= N) {
@@ -616,7 +712,7 @@ template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
-    touch_kernargs<9>();
+    touch_kernargs<10>();
     const int tid = threadIdx.x;
     RP_STAMP(0);
     RP_TL(0);
@@ -692,6 +788,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             const LonPair lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
+            f[PF_NEAR] = near_mask_step<COEFFS_IN>(a, rt, lp, i, f);
             double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
 #pragma unroll
             for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n0] = f[k];
@@ -1011,14 +1108,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (COLL) {
                     const bool want = live && alive && fail_step < 0 && ood_step < 0;
                     bool hit = false;
-                    if (__any(want)) {
+                    if (__any(want)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
                         double sn, cn;
                         rp_sincos(th_gl, &sn, &cn);
-                        if (want) {
-                            const ObsTables ob = *a.obs;
-                            const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
-                            hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor);
-                        }
+                        const ObsTables &ob = a.obs;
+                        const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
+                        hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, want, !COEFFS_IN && a.use_near_mask != 0,
+                                            double_as_mask(pf.f[PF_NEAR])) && want;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }

@@ -68,7 +68,7 @@ extern "C" double rpt_store_ceiling(size_t bytes, int wide, int reps) {
 __global__ void k_ubench(int which, int iters, unsigned long long *out, double *sink) {
     double x0 = 1.0 + threadIdx.x * 1e-9, x1 = 1.1, x2 = 1.2, x3 = 1.3, x4 = 1.4, x5 = 1.5, x6 = 1.6, x7 = 1.7;
     const double ca = 0.999999, cb = 1e-7;
-    unsigned u0 = threadIdx.x, u1 = 7;
+    unsigned u0 = threadIdx.x, u1 = 7, u2 = 1, u3 = 2, u4 = 3;
     unsigned long long p0 = threadIdx.x;
     __shared__ double lds[64];
     lds[threadIdx.x & 63] = 1.0;
@@ -78,36 +78,43 @@ __global__ void k_ubench(int which, int iters, unsigned long long *out, double *
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < iters; ++it) {
         switch (which) {
-        case 0: UB_REP64(asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x0) : "v"(ca), "v"(cb));) break;
+        // every case: 8 asm blocks of 8 instructions (the compiler puts one s_nop behind each asm block: 64 + 8 issue slots)
+#define UB8(one) one "\n\t" one "\n\t" one "\n\t" one "\n\t" one "\n\t" one "\n\t" one "\n\t" one
+        case 0: UB_REP8(asm volatile(UB8("v_fma_f64 %0, %0, %1, %2") : "+v"(x0) : "v"(ca), "v"(cb));) break;
         case 1: UB_REP8(asm volatile("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
                                      "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9"
                                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(ca), "v"(cb));) break;
-        case 2: UB_REP64(asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x0) : "v"(ca));) break;
-        case 3: UB_REP64(asm volatile("v_add_f64 %0, %0, %1" : "+v"(x0) : "v"(cb));) break;
-        case 4: UB_REP64(asm volatile("v_rcp_f64 %0, %0" : "+v"(x0));) break;
-        case 5: UB_REP64(asm volatile("v_rsq_f64 %0, %0" : "+v"(x0));) break;
-        case 6: UB_REP64(asm volatile("v_readlane_b32 s20, %0, 5" ::"v"(u0) : "s20");) break;
-        case 7: UB_REP64(asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u0));) break;
-        case 8: UB_REP64(asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u0) : "v"(u1) : );) break;
-        case 9: UB_REP64(asm volatile("v_lshl_add_u64 %0, %0, 3, %1" : "+v"(p0) : "v"(p0));) break;
-        case 10: UB_REP64(asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x0) : "v"(ldsaddr));) break;
-        case 11: UB_REP64(asm volatile("v_cmp_lt_f64 vcc, %0, %1" ::"v"(x0), "v"(x1) : "vcc");) break;
+        case 2: UB_REP8(asm volatile(UB8("v_mul_f64 %0, %0, %1") : "+v"(x0) : "v"(ca));) break;
+        case 3: UB_REP8(asm volatile(UB8("v_add_f64 %0, %0, %1") : "+v"(x0) : "v"(cb));) break;
+        case 4: UB_REP8(asm volatile(UB8("v_rcp_f64 %0, %0") : "+v"(x0));) break;
+        case 5: UB_REP8(asm volatile(UB8("v_rsq_f64 %0, %0") : "+v"(x0));) break;
+        case 6: UB_REP8(asm volatile(UB8("v_readlane_b32 s20, %0, 5") ::"v"(u0) : "s20");) break;
+        case 7: UB_REP8(asm volatile(UB8("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf") : "+v"(u0));) break;
+        case 8: UB_REP8(asm volatile(UB8("v_cndmask_b32 %0, %0, %1, vcc") : "+v"(u0) : "v"(u1) : );) break;
+        case 9: UB_REP8(asm volatile(UB8("v_lshl_add_u64 %0, %0, 3, %1") : "+v"(p0) : "v"(p0));) break;
+        case 10: UB_REP8(asm volatile(UB8("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)") : "=v"(x0) : "v"(ldsaddr));) break;
+        case 11: UB_REP8(asm volatile(UB8("v_cmp_lt_f64 vcc, %0, %1") ::"v"(x0), "v"(x1) : "vcc");) break;
         case 12: UB_REP8(asm volatile("v_rcp_f64 %0, %0\n\tv_rcp_f64 %1, %1\n\tv_rcp_f64 %2, %2\n\tv_rcp_f64 %3, %3\n\t"
                                       "v_rcp_f64 %4, %4\n\tv_rcp_f64 %5, %5\n\tv_rcp_f64 %6, %6\n\tv_rcp_f64 %7, %7"
                                       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));) break;
-        case 13: UB_REP64(asm volatile("v_add_u32 %0, %0, %1" : "+v"(u0) : "v"(u1));) break;
-        case 14: UB_REP64(asm volatile("s_add_u32 s20, s20, 1" ::: "s20", "scc");) break;
-        case 15: UB_REP64(asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u0) : "v"(u1));) break;
-        case 16: UB_REP64(asm volatile("v_writelane_b32 %0, s20, 3" : "+v"(u0) :: );) break;
-        case 17: UB_REP64(asm volatile("ds_read_b64 %0, %1" : "=v"(x0) : "v"(ldsaddr));) asm volatile("s_waitcnt lgkmcnt(0)"); break;
-        case 18: UB_REP64(asm volatile("v_rndne_f64 %0, %0" : "+v"(x0));) break;
-        case 19: UB_REP64(asm volatile("v_mov_b32 %0, %1" : "=v"(u0) : "v"(u1));) break;
+        case 13: UB_REP8(asm volatile(UB8("v_add_u32 %0, %0, %1") : "+v"(u0) : "v"(u1));) break;
+        case 14: UB_REP8(asm volatile(UB8("s_add_u32 s20, s20, 1") ::: "s20", "scc");) break;
+        case 15: UB_REP8(asm volatile(UB8("v_mul_lo_u32 %0, %0, %1") : "+v"(u0) : "v"(u1));) break;
+        case 16: UB_REP8(asm volatile(UB8("v_writelane_b32 %0, s20, 3") : "+v"(u0) :: );) break;
+        case 17: UB_REP8(asm volatile(UB8("ds_read_b64 %0, %1") : "=v"(x0) : "v"(ldsaddr));) asm volatile("s_waitcnt lgkmcnt(0)"); break;
+        case 18: UB_REP8(asm volatile(UB8("v_rndne_f64 %0, %0") : "+v"(x0));) break;
+        case 19: UB_REP8(asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t"
+                                      "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4"
+                                      : "+v"(u0), "+v"(u2), "+v"(u3), "+v"(u4) : "v"(u1));) break;
+        case 20: UB_REP8(asm volatile("v_fma_f64 %0, %0, %2, %3\n\ts_add_u32 s20, s20, 1\n\tv_fma_f64 %1, %1, %2, %3\n\ts_add_u32 s21, s21, 1\n\t"
+                                      "v_fma_f64 %0, %0, %2, %3\n\ts_add_u32 s20, s20, 1\n\tv_fma_f64 %1, %1, %2, %3\n\ts_add_u32 s21, s21, 1"
+                                      : "+v"(x0), "+v"(x1) : "v"(ca), "v"(cb) : "s20", "s21", "scc");) break;
         default: break;
         }
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
-    sink[threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (double)u0 + (double)p0;
+    sink[threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (double)u0 + (double)p0 + (double)(u2 + u3 + u4);
 }
 
 // returns ticks per instruction (mean over the wavefronts of one workgroup of `waves` wavefronts)

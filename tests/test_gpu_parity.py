@@ -339,3 +339,28 @@ def test_horizon_lengths_around_lane_group_boundaries(ctx, N):
         _compare_status(status, cost, orun)
         _compare_out(out, orun.out)
         np.testing.assert_allclose(ctx.fetch_states(), orun.states, rtol=0, atol=STATE_ATOL)
+
+
+@pytest.mark.parametrize("name,lo,count,low_vel", [("cfg2", 0, 7440, False), ("cfg3", 0, 4000, False), ("cfg3", 30000, 4000, False),
+                                                   ("cfg3", 58000, 2543, False), ("cfg4", 250000, 3000, False),
+                                                   ("cfg5obs", 500000, 3000, False), ("cfg3", 12000, 3000, True)])
+def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
+    """The benchmark workloads (many dynamic obstacles, extended horizons, curved routes): labels -- in particular
+    INFEASIBLE_COLLISION -- exact against the oracle's brute-force query, in production and in draw mode.  This is
+    what pins the (pair, step) broad phase of the collision query (csrc/rp_kernels.h: near_mask_step)."""
+    from oracle import oracle
+    from commonroad_rp_amd import workloads as W
+    w = W.cfg5(obstacles=50) if name == "cfg5obs" else W.WORKLOADS[name]()
+    w.setup(ctx)
+    tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+    for extra in (0, FLAG_DRAW_ALL):
+        inp = _with_flags(w.inputs, extra)
+        if low_vel:   # lateral motion sampled over arc length (reactive_planner.py:756-772)
+            inp.params.low_vel_mode = 1
+        hi = min(lo + count, inp.n_candidates)
+        orun = oracle.plan(inp, tb, lo, hi, want_states=False, nthreads=8)
+        out = ctx.plan(inp, lo, hi)
+        status, cost = ctx.fetch_status()
+        _compare_status(status, cost, orun)
+        assert out.n_collision == orun.out.n_collision and out.best_index == orun.out.best_index
+        assert out.n_collision_before_best == orun.out.n_collision_before_best
