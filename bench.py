@@ -62,6 +62,8 @@ def run():
     ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--road-boundary", action="store_true",
+                    help="scenario workloads: add the road boundary (thin rectangles, collision.road_boundary_obb) to the obstacle tables")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,7 +98,7 @@ def run():
     from commonroad_rp_amd.distributed import shard_range, exchange_winner, close_exchanges
 
     flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[args.mode]
-    base = W.WORKLOADS[args.workload]()
+    base = W.WORKLOADS[args.workload](road_boundary=True) if args.road_boundary else W.WORKLOADS[args.workload]()
     w = W.replicate_for_ranks(base, world)
     p = copy_params(w.inputs.params)
     p.flags |= flags

@@ -21,7 +21,7 @@ from typing import Iterable, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["ObstacleTables", "triangulate_polygon_fan"]
+__all__ = ["ObstacleTables", "triangulate_polygon_fan", "road_boundary_obb", "SimpleLanelet", "lanelets_from_arrays"]
 
 
 def _arr(a, cols: int) -> np.ndarray:
@@ -58,12 +58,15 @@ class ObstacleTables:
 
     # ------------------------------------------------------------------------------------------
     @classmethod
-    def from_scenario(cls, scenario, road_boundary_triangles: Optional[np.ndarray] = None) -> "ObstacleTables":
+    def from_scenario(cls, scenario, road_boundary_triangles: Optional[np.ndarray] = None,
+                      road_boundary: bool = False) -> "ObstacleTables":
         """Extract tables from a CommonRoad ``Scenario`` (duck-typed: ``static_obstacles`` /
         ``dynamic_obstacles`` with ``obstacle_shape``, ``initial_state`` and
         ``prediction.trajectory.state_list``), mirroring what ``set_collision_checker`` feeds to
         pycrcc (reactive_planner.py:234-251).  Rectangles and circles are supported directly,
-        polygons are fan-triangulated (convex polygons only)."""
+        polygons are fan-triangulated (convex polygons only).  ``road_boundary=True`` adds the
+        rectangles of ``road_boundary_obb(scenario.lanelet_network.lanelets)`` (the reference calls
+        ``create_road_boundary_obstacle(scenario)``, reactive_planner.py:246-248)."""
         sobb, stri, scirc = [], [], []
         for ob in getattr(scenario, "static_obstacles", []):
             st = ob.initial_state
@@ -87,6 +90,8 @@ class ObstacleTables:
                                                   0.5 * shape.length, 0.5 * shape.width)
         if road_boundary_triangles is not None:
             stri.extend(np.asarray(road_boundary_triangles, dtype=np.float64).reshape(-1, 6).tolist())
+        if road_boundary:
+            sobb.extend(road_boundary_obb(scenario.lanelet_network.lanelets).tolist())
         return cls(static_obb=sobb or None, static_tri=stri or None, static_circ=scirc or None,
                    dyn_obb=tab, dyn_t0=t0)
 
@@ -114,3 +119,106 @@ def _add_shape(shape, position, orientation, sobb, stri, scirc):
             _add_shape(sub, position, orientation, sobb, stri, scirc)
     else:
         raise TypeError(f"unsupported obstacle shape {type(shape).__name__}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Road boundary.  The reference delegates to commonroad_dc.boundary.create_road_boundary_obstacle
+# (third party, not under /root/reference; reactive_planner.py:29,246-248).  This build generates the
+# boundary as thin rectangles along the outer borders of the lanelet network -- the flavour
+# commonroad-dc calls "obb_rectangles": a continuous trajectory that starts on the road cannot leave
+# it without overlapping one of them.
+# ---------------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class SimpleLanelet:
+    """The fields of a CommonRoad ``Lanelet`` the generator reads (same attribute names)."""
+    lanelet_id: int
+    left_vertices: np.ndarray
+    right_vertices: np.ndarray
+    adj_left: Optional[int] = None
+    adj_right: Optional[int] = None
+    predecessor: Sequence[int] = ()
+    successor: Sequence[int] = ()
+
+
+def lanelets_from_arrays(ids, left, right, offsets, flags) -> list:
+    """Lanelets from the flat arrays of the scenario fixtures (tests/golden/make_scenarios.py):
+    ``flags[k] = (has adjacent left, has adjacent right, has predecessor, has successor)``."""
+    out = []
+    for k, lid in enumerate(ids):
+        a, b = int(offsets[k]), int(offsets[k + 1])
+        f = flags[k]
+        out.append(SimpleLanelet(int(lid), np.asarray(left[a:b], dtype=float), np.asarray(right[a:b], dtype=float),
+                                 adj_left=-1 if f[0] else None, adj_right=-1 if f[1] else None,
+                                 predecessor=(-1,) if f[2] else (), successor=(-1,) if f[3] else ()))
+    return out
+
+
+def _points_in_polygon(pts: np.ndarray, poly: np.ndarray) -> np.ndarray:
+    """Even-odd rule, points strictly inside (vectorised over points)."""
+    x, y = pts[:, 0][:, None], pts[:, 1][:, None]
+    x0, y0 = poly[:, 0][None, :], poly[:, 1][None, :]
+    x1, y1 = np.roll(poly[:, 0], -1)[None, :], np.roll(poly[:, 1], -1)[None, :]
+    cross = (y0 > y) != (y1 > y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xi = x0 + (y - y0) * (x1 - x0) / (y1 - y0)
+    return (np.sum(cross & (x < xi), axis=1) % 2) == 1
+
+
+def road_boundary_obb(lanelets: Iterable, thickness: float = 0.1, inside_margin: float = 0.05,
+                      merge_tol: float = 1e-6) -> np.ndarray:
+    """Rectangles ``(cx, cy, theta, half_length, half_width)`` along the outer border of a lanelet network.
+
+    Candidate segments: the left border of every lanelet without a left neighbour, the right border of every
+    lanelet without a right neighbour, and the start / end edge of lanelets without predecessor / successor.
+    A segment is dropped when its midpoint, moved ``inside_margin`` to either side, lies inside some lanelet on
+    BOTH sides -- i.e. it runs through drivable area (overlapping lanelets of an intersection).  Connected
+    collinear segments (sine of the angle between them <= ``merge_tol``) are merged into one rectangle."""
+    lls = list(lanelets)
+    polys = [np.concatenate((np.asarray(l.left_vertices, dtype=float), np.asarray(l.right_vertices, dtype=float)[::-1])) for l in lls]
+    segs, owner = [], []
+    for k, l in enumerate(lls):
+        left, right = np.asarray(l.left_vertices, dtype=float), np.asarray(l.right_vertices, dtype=float)
+        borders = []
+        if getattr(l, "adj_left", None) is None:
+            borders.append(left)
+        if getattr(l, "adj_right", None) is None:
+            borders.append(right)
+        if not list(getattr(l, "predecessor", ()) or ()):
+            borders.append(np.stack((left[0], right[0])))
+        if not list(getattr(l, "successor", ()) or ()):
+            borders.append(np.stack((left[-1], right[-1])))
+        for b in borders:
+            for p, q in zip(b[:-1], b[1:]):
+                if np.hypot(*(q - p)) > 1e-9:
+                    segs.append((p, q)); owner.append(k)
+    if not segs:
+        return np.zeros((0, 5))
+    P = np.array([s[0] for s in segs]); Q = np.array([s[1] for s in segs]); owner = np.array(owner)
+    mid = 0.5 * (P + Q)
+    d = Q - P
+    ln = np.hypot(d[:, 0], d[:, 1])
+    nrm = np.stack((-d[:, 1], d[:, 0]), axis=1) / ln[:, None]
+    inside_a = np.zeros(len(segs), dtype=bool); inside_b = np.zeros(len(segs), dtype=bool)
+    for poly in polys:   # (the segment's own lanelet counts: its inner side is drivable area)
+        inside_a |= _points_in_polygon(mid + inside_margin * nrm, poly)
+        inside_b |= _points_in_polygon(mid - inside_margin * nrm, poly)
+    keep = ~(inside_a & inside_b)
+    # merge runs of connected, collinear segments (straight borders are often given in 1 m pieces)
+    out = []
+    run_p = run_q = None
+    for k in np.flatnonzero(keep):
+        p, q = P[k], Q[k]
+        if run_p is not None and np.allclose(run_q, p, atol=1e-9):
+            u, v = run_q - run_p, q - p
+            if abs(u[0] * v[1] - u[1] * v[0]) <= merge_tol * np.hypot(*u) * np.hypot(*v) and u @ v > 0:
+                run_q = q
+                continue
+        if run_p is not None:
+            out.append((run_p, run_q))
+        run_p, run_q = p, q
+    if run_p is not None:
+        out.append((run_p, run_q))
+    P2 = np.array([o[0] for o in out]).reshape(-1, 2); Q2 = np.array([o[1] for o in out]).reshape(-1, 2)
+    d2 = Q2 - P2
+    return np.stack((0.5 * (P2[:, 0] + Q2[:, 0]), 0.5 * (P2[:, 1] + Q2[:, 1]), np.arctan2(d2[:, 1], d2[:, 0]),
+                     0.5 * np.hypot(d2[:, 0], d2[:, 1]), np.full(len(out), 0.5 * thickness)), axis=1)

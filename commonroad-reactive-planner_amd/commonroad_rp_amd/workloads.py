@@ -113,7 +113,7 @@ def _with_d0(D: np.ndarray, d0: float) -> np.ndarray:
 
 
 def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired_speed=None, extra_obstacles=0,
-                       flags=0, description="", extra_jitter=1.5, extra_lane=4.0) -> Workload:
+                       flags=0, description="", extra_jitter=1.5, extra_lane=4.0, road_boundary=False) -> Workload:
     sc = _load_scenario(scen_name)
     dt = float(sc["dt"])
     co = CoordinateSystem(smooth_ref_path(sc["centre"]))
@@ -144,7 +144,12 @@ def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired
                 kk = min(int(np.searchsorted(co.ref_pos, s, side="right")) - 1, len(co.ref_pos) - 2)
                 ext[dyn.shape[0] + j, k] = (p[0], p[1], co.ref_theta[kk], 2.25, 1.0)
         dyn = ext
-    obstacles = ObstacleTables(static_obb=sc["static_obb"], dyn_obb=dyn, dyn_t0=int(sc["dyn_t0"]))
+    static_obb = sc["static_obb"]
+    if road_boundary:   # thin rectangles along the outer border of the lanelet network (collision.road_boundary_obb)
+        from .collision import road_boundary_obb, lanelets_from_arrays
+        lls = lanelets_from_arrays(sc["ll_ids"], sc["ll_left"], sc["ll_right"], sc["ll_offsets"], sc["ll_flags"])
+        static_obb = np.concatenate((np.asarray(static_obb, dtype=float).reshape(-1, 5), road_boundary_obb(lls)))
+    obstacles = ObstacleTables(static_obb=static_obb, dyn_obb=dyn, dyn_t0=int(sc["dyn_t0"]))
     params = make_params(dt=dt, N=N, x0_lon=x0_lon, x0_lat=x0_lat, x0_orientation=th, low_vel_mode=low,
                          time_step0=int(sc["init_time_step"]), flags=flags, **VEHICLE2)
     cost = make_cost(desired_speed=v0 if desired_speed is None else desired_speed)
@@ -162,30 +167,33 @@ def cfg1(level: int = 3) -> Workload:
                               description=f"ZAM_Over-1_1, sampling level {level}, N=20")
 
 
-def cfg2(flags: int = 0) -> Workload:
+def cfg2(flags: int = 0, road_boundary: bool = False) -> Workload:
     """ZAM_Tjunction-1_42_T-1, 15 x 15 x 31 grid, N = 30, 5 dynamic obstacles."""
     dt, N = 0.1, 30
     T = [dt * (16 + k) for k in range(15)]
     return _scenario_workload("cfg2", "ZAM_Tjunction-1_42_T-1", N, T, 31, 15, low_vel_threshold=2.0, flags=flags,
-                              description="ZAM_Tjunction-1_42_T-1, 15(d)x15(T)x31(v) grid, N=30, 5 dynamic obstacles")
+                              road_boundary=road_boundary,
+                              description="ZAM_Tjunction-1_42_T-1, 15(d)x15(T)x31(v) grid, N=30, 5 dynamic obstacles"
+                                          + (", road boundary (122 rectangles)" if road_boundary else ""))
 
 
-def cfg3(flags: int = 0) -> Workload:
+def cfg3(flags: int = 0, road_boundary: bool = False) -> Workload:
     """DEU_Test-1_1_T-1, 31 x 31 x 63 grid, N = 60, 1 static + 1 dynamic + 49 synthetic obstacles."""
     dt, N = 0.1, 60
     T = [dt * (30 + k) for k in range(31)]
     # synthetic boxes 5 m either side of the route (+- 1.5 m): at 4 m every candidate collides with something
     # within the 6 s horizon and no replanning step has a winner; at 5 m ~1.5 % of the feasible candidates survive
     return _scenario_workload("cfg3", "DEU_Test-1_1_T-1", N, T, 63, 31, low_vel_threshold=4.0, extra_obstacles=49,
-                              flags=flags, extra_lane=5.0,
+                              flags=flags, extra_lane=5.0, road_boundary=road_boundary,
                               description="DEU_Test-1_1_T-1, 31x31x63 grid, N=60, 51 obstacles (49 synthetic, seed 0)")
 
 
-def cfg4(flags: int = 0) -> Workload:
+def cfg4(flags: int = 0, road_boundary: bool = False) -> Workload:
     """ZAM_Tjunction-1_42_T-1, 63 x 63 x 127 grid, N = 100."""
     dt, N = 0.1, 100
     T = [dt * (38 + k) for k in range(63)]
     return _scenario_workload("cfg4", "ZAM_Tjunction-1_42_T-1", N, T, 127, 63, low_vel_threshold=2.0, flags=flags,
+                              road_boundary=road_boundary,
                               description="ZAM_Tjunction-1_42_T-1, 63x63x127 grid, N=100, 5 dynamic obstacles")
 
 

@@ -191,6 +191,15 @@ __device__ __forceinline__ bool obb_obb(const Obb &a, const Obb &b) {
     return !sep;
 }
 
+// cheap conservative rejection for long thin rectangles (road-boundary strips), where a bounding circle says
+// nothing: the ego rectangle lies inside the circle (ego centre, ego_r), so it cannot reach b if that centre is
+// farther than ego_r from b's slab along either of b's axes (these are two of the four separating axes with the
+// ego's extent over-estimated)
+__device__ __forceinline__ bool obb_slab_far(const Obb &b, double ex, double ey, double ego_r) {
+    const double tx = ex - b.cx, ty = ey - b.cy;
+    return fabs(tx * b.ux + ty * b.uy) > (b.hl + ego_r) * 1.000001 || fabs(ty * b.ux - tx * b.uy) > (b.hw + ego_r) * 1.000001;
+}
+
 __device__ __forceinline__ bool obb_tri(const Obb &a, const double *t) {
     double vx = -a.uy, vy = a.ux;
     double lx[3], ly[3];
@@ -231,10 +240,16 @@ struct ObsTables {
     const double *tri;      // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
     const double *circ;     // [n_circ][4]  cx, cy, r, -
     const double *dyn;      // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent)
-    int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0;
+    // static shapes in table order, grouped into at most 63 clusters of consecutive shapes of one kind (boundary
+    // rectangles come as polylines, so consecutive shapes are neighbours): bounding circle + member range
+    const double *clus;        // [n_clus][4]  cx, cy, r, -
+    const int32_t *clus_info;  // [n_clus][4]  kind (0 obb, 1 triangle, 2 circle), first, count, -
+    int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0, n_clus, clus_per;   // clus_per: members per cluster (upper bound)
 };
+typedef const int32_t __attribute__((address_space(4))) *gcint;
 
-typedef const double __attribute__((address_space(1))) *gcdouble;   // the tables live in global memory
+typedef const double __attribute__((address_space(4))) *gcdouble;   // the tables are read-only for the kernels: constant address
+                                                                    // space, so that wave-uniform rows come through scalar loads
 
 // ---- wave-level culling --------------------------------------------------------------------------
 // All lanes of a wavefront hold poses that are close in space (a few candidates x consecutive time steps).
@@ -258,6 +273,23 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 }
 __device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {   // lanes without a valid source keep their own value
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+    v |= dpp_u32<DPP_ROW_SHR1, 0xf>(v);
+    v |= dpp_u32<DPP_ROW_SHR2, 0xf>(v);
+    v |= dpp_u32<DPP_ROW_SHR4, 0xf>(v);
+    v |= dpp_u32<DPP_ROW_SHR8, 0xf>(v);
+    v |= dpp_u32<DPP_ROW_BCAST15, 0xa>(v);
+    v |= dpp_u32<DPP_ROW_BCAST31, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {   // OR over the 64 lanes, wave-uniform result
+    return ((uint64_t)wave_or_u32((uint32_t)(v >> 32)) << 32) | wave_or_u32((uint32_t)v);
+}
+
 struct WaveBound { double mx, my, R; };   // every ego rectangle of a querying lane lies within R of (mx, my)
 
 __device__ __forceinline__ WaveBound ego_wave_bound(bool want, double cx, double cy, double ego_r) {
@@ -280,25 +312,57 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 }
 
 // cc.collide(ego pose at scenario time index t)  (reactive_planner.py:1040-1042).
-// `want`: this lane asks; `masked` (wave-uniform): `near` holds this lane's (pair, step) mask of dynamic obstacles
-// (rp_kernels.h: near_mask_step), otherwise every dynamic obstacle is tested.
+// `want`: this lane asks; `masked` (wave-uniform): `near` / `near_static` hold this lane's (pair, step) masks of dynamic
+// obstacles / static-shape clusters (rp_kernels.h: near_mask_step); otherwise every shape is tested (static shapes
+// after a wave-level bounding-circle rejection).
 // Per lane, a bounding-circle rejection comes before the exact test (conservative: a small relative margin keeps
 // it from ever rejecting a pair the exact test would accept).
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, bool masked,
-                                              uint64_t near) {
+                                              uint64_t near, uint64_t near_static) {
     bool hit = false;
+    const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
+    if (masked) {
+        // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
+        // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
+        // per-lane gathers, no dependent vector-memory round trips), every lane runs the cheap rejection test
+        uint64_t mu = wave_or_u64(want ? near_static : 0);
+        mu &= ob.n_clus >= 64 ? ~0ull : (1ull << ob.n_clus) - 1ull;
+        const gcint info = (gcint)ob.clus_info;
+        while (mu != 0) {
+            const int c = __ffsll((unsigned long long)mu) - 1;
+            mu &= mu - 1;
+            const int kind = info[4 * c], first = info[4 * c + 1], count = info[4 * c + 2];
+            if (kind == 0) {
+                for (int q = 0; q < count; ++q) {
+                    const gcdouble o = sobb + (size_t)(first + q) * OB_ROW;
+                    const Obb b = {o[OB_CX], o[OB_CY], o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
+                    if (want && !obb_slab_far(b, ego.cx, ego.cy, ego_r)) hit |= obb_obb(ego, b);
+                }
+            } else if (kind == 1) {
+                for (int q = 0; q < count; ++q) {
+                    const gcdouble o = tri + (size_t)(first + q) * 10;
+                    const double dx = o[6] - ego.cx, dy = o[7] - ego.cy, rr = ego_r + o[8];
+                    if (want && dx * dx + dy * dy <= rr * rr * 1.000001) {
+                        const double tv[6] = {o[0], o[1], o[2], o[3], o[4], o[5]};
+                        hit |= obb_tri(ego, tv);
+                    }
+                }
+            } else {
+                for (int q = 0; q < count; ++q) {
+                    const gcdouble o = circ + (size_t)(first + q) * 4;
+                    if (want) hit |= obb_circ(ego, o[0], o[1], o[2]);
+                }
+            }
+        }
+    } else {
     WaveBound wb = {0.0, 0.0, 0.0};
     if (ob.n_sobb + ob.n_tri + ob.n_circ > 0) wb = ego_wave_bound(want, ego.cx, ego.cy, ego_r);   // wave-uniform
-    const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
     for (int j = 0; j < ob.n_sobb; ++j) {
         const gcdouble o = sobb + j * OB_ROW;
         const double cx = o[OB_CX], cy = o[OB_CY], r = o[OB_R];
         if (!coarse_near(wb, cx, cy, r)) continue;   // wave-uniform
-        const double dx = cx - ego.cx, dy = cy - ego.cy, rr = ego_r + r;
-        if (want && dx * dx + dy * dy <= rr * rr * 1.000001) {
-            Obb b = {cx, cy, o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
-            hit |= obb_obb(ego, b);
-        }
+        const Obb b = {cx, cy, o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
+        if (want && !obb_slab_far(b, ego.cx, ego.cy, ego_r)) hit |= obb_obb(ego, b);
     }
     for (int j = 0; j < ob.n_tri; ++j) {
         const gcdouble o = tri + j * 10;
@@ -315,6 +379,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         const double cx = o[0], cy = o[1], r = o[2];
         if (!coarse_near(wb, cx, cy, r)) continue;   // wave-uniform
         if (want) hit |= obb_circ(ego, cx, cy, r);
+    }
     }
     // dynamic obstacles: only those whose bit is set in the (pair, step) mask of the longitudinal profile
     const int k = t - ob.dyn_t0;

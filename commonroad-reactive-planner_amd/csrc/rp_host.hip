@@ -47,7 +47,8 @@ struct rp_ctx {
     double bucket_inv_h = 0.0;
     double proj_d_limit = 20.0;
     // obstacles
-    double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr;
+    double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr;
+    int32_t *d_clus_info = nullptr;
     ObsTables obs{};
 
     // per-call staging (pinned host + device mirror)
@@ -170,9 +171,9 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
-    // reference tables + profile rows + pair headers + pre-filter votes
+    // reference tables + profile rows + pair headers + pre-filter votes + per-item bounds of the collision broad phase
     const size_t bytes = (size_t)ka.table_words * sizeof(double) +
-                         (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int));
+                         (size_t)P * ((size_t)(PF_FIELDS + 4) * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int)) + 8;
     if (bytes > kFusedLonLdsLimit) return 0;
     *pairs = P;
     return (bytes + 15) & ~(size_t)15;
@@ -518,7 +519,7 @@ void rp_destroy(rp_ctx *c) {
                      c->t_calls, c->t_sum[0] / c->t_calls, c->t_sum[1] / c->t_calls, c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_stage, c->d_status, c->d_cost, c->d_user,
+    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
                    c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
@@ -645,7 +646,38 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
             e[4 * plane + at] = o[3]; e[5 * plane + at] = o[4];
             e[6 * plane + at] = std::sqrt(o[3] * o[3] + o[4] * o[4]);
         }
+    // clusters of consecutive static shapes of one kind (at most 63: one bit each in the (pair, step) masks)
+    std::vector<double> cl;
+    std::vector<int32_t> ci;
+    {
+        const int n_static = n_sobb + n_tri + n_circ;
+        const int per = std::max(1, (n_static + 59) / 60);
+        auto add = [&](int kind, int count, auto centre) {
+            for (int first = 0; first < count; first += per) {
+                const int cnt = std::min(per, count - first);
+                double mx = 0.0, my = 0.0;
+                for (int q = 0; q < cnt; ++q) { double x, y, r; centre(first + q, x, y, r); mx += x; my += y; }
+                mx /= cnt; my /= cnt;
+                double rad = 0.0;
+                for (int q = 0; q < cnt; ++q) { double x, y, r; centre(first + q, x, y, r); rad = std::max(rad, std::hypot(x - mx, y - my) + r); }
+                cl.insert(cl.end(), {mx, my, rad * (1.0 + 1e-12) + 1e-12, 0.0});
+                ci.insert(ci.end(), {kind, first, cnt, 0});
+            }
+        };
+        add(0, n_sobb, [&](int j, double &x, double &y, double &r) { x = a[(size_t)j * OB_ROW + OB_CX]; y = a[(size_t)j * OB_ROW + OB_CY]; r = a[(size_t)j * OB_ROW + OB_R]; });
+        add(1, n_tri, [&](int j, double &x, double &y, double &r) { x = b[(size_t)j * 10 + 6]; y = b[(size_t)j * 10 + 7]; r = b[(size_t)j * 10 + 8]; });
+        add(2, n_circ, [&](int j, double &x, double &y, double &r) { x = d[(size_t)j * 4]; y = d[(size_t)j * 4 + 1]; r = d[(size_t)j * 4 + 2]; });
+    }
+    const int n_clus = (int)(ci.size() / 4);
+    const int clus_per = std::max(1, (n_sobb + n_tri + n_circ + 59) / 60);
+    if (n_clus > 63) return fail(c, RP_EINVAL, "rp_set_obstacles: internal error, more than 63 static clusters");
     int rc;
+    if ((rc = upload(c, c->d_clus, cl)) != RP_OK) return rc;
+    if (c->d_clus_info) { HIP_TRY(c, hipFree(c->d_clus_info)); c->d_clus_info = nullptr; }
+    if (n_clus) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_clus_info, ci.size() * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_clus_info, ci.data(), ci.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     if ((rc = upload(c, c->d_sobb, a)) != RP_OK) return rc;
     if ((rc = upload(c, c->d_tri, b)) != RP_OK) return rc;
     if ((rc = upload(c, c->d_circ, d)) != RP_OK) return rc;
@@ -653,6 +685,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.sobb = c->d_sobb; c->obs.tri = c->d_tri; c->obs.circ = c->d_circ; c->obs.dyn = c->d_dyn;
     c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
+    c->obs.clus = c->d_clus; c->obs.clus_info = c->d_clus_info; c->obs.n_clus = n_clus; c->obs.clus_per = clus_per;
     c->have_last = false;
     return RP_OK;
 }
@@ -709,7 +742,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     for (int i = 1; i < g->nD; ++i) { ka.lat_dmin = std::min(ka.lat_dmin, g->D[i]); ka.lat_dmax = std::max(ka.lat_dmax, g->D[i]); }
     ka.lat_abs_d = std::max(std::fabs(p->x0_lat[0]), std::max(std::fabs(ka.lat_dmin), std::fabs(ka.lat_dmax)));
     if (!(ka.lat_abs_d < 1e300)) ka.use_near_mask = 0;   // NaN / inf samples: no bound
-    if (c->obs.n_dyn <= kNearMaskMinObstacles) ka.use_near_mask = 0;
+    if (c->obs.n_dyn <= kNearMaskMinObstacles && c->obs.n_clus == 0) ka.use_near_mask = 0;
     c->have_last = false;
     rc = run_pipeline(c, ka, mat, false, false, result, best_states);
     if (rc != RP_OK) return rc;

@@ -75,9 +75,9 @@ struct KArgs {
 };
 
 // fields of one step of a longitudinal profile
-enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_FIELDS };
+enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_NEAR_S, PF_FIELDS };
 // PF_NEAR: bit pattern of a 64-bit mask, bit j = dynamic obstacle j can touch SOME candidate of the pair at this step
-// (bit 63: one of the obstacles 63, 64, ... can), see near_mask_step
+// (bit 63: one of the obstacles 63, 64, ... can); PF_NEAR_S: the same for the clusters of static shapes; see near_mask_step
 
 struct PairHdr {
     double lat_T;        // delta_tau of the lateral polynomials of this pair (sampling.py:229-237)
@@ -524,21 +524,17 @@ __device__ __forceinline__ double ext_travel(double v, double acc, int m, double
     return c;
 }
 
+// circle (cx, cy, R) that contains the ego rectangle of every candidate of the pair at step i; false: no bound
 template <bool COEFFS_IN>
-__device__ __forceinline__ double near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, const double *f) {
-    const uint64_t all = ~0ull;
-    if (COEFFS_IN || !a.use_near_mask || !a.has_obstacles) return mask_as_double(0);   // masks unused: every obstacle is tested
-    const ObsTables &ob = a.obs;
-    if (ob.n_dyn <= 0) return mask_as_double(0);
-    const int k = a.time_step0 + i * a.factor - ob.dyn_t0;
-    if (k < 0 || k >= ob.n_steps) return mask_as_double(0);   // no dynamic obstacle exists at this scenario step
+__device__ __forceinline__ bool pair_step_bound(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, const double *f,
+                                                double &cx, double &cy, double &R) {
+    if (COEFFS_IN) return false;
     const int L = lp.L;
-    if (!(fabs((double)(L - 1) * a.dt - lp.T) <= 1e-9 * lp.T)) return mask_as_double(all);   // T is not the last valid step
+    if (!(fabs((double)(L - 1) * a.dt - lp.T) <= 1e-9 * lp.T)) return false;   // T is not the last valid step
     const double wb = fabs(a.wb_rear_axle);
-    double cx, cy, R;
     if (i < L) {
         const double tau = a.low_vel_mode ? f[PF_S] - lp.lon.c0 : (double)i * a.dt;
-        if (!(tau >= 0.0 && tau <= lp.lat_T * (1.0 + 1e-12))) return mask_as_double(all);
+        if (!(tau >= 0.0 && tau <= lp.lat_T * (1.0 + 1e-12))) return false;
         const double dmax = a.lat_abs_d + 0.2 * fabs(a.x0_lat[1]) * lp.lat_T + 0.0173 * fabs(a.x0_lat[2]) * lp.lat_T * lp.lat_T;
         cx = f[PF_PX]; cy = f[PF_PY];
         R = dmax + wb + a.ego_radius;
@@ -546,7 +542,7 @@ __device__ __forceinline__ double near_mask_step(const KArgs &a, const RefTab &r
         double g[PF_FIELDS];
         lon_step(a, rt, lp.lon, L - 1, g);
         const bool moving = g[PF_INV_SD] > 0.0 || a.low_vel_mode;
-        if (!moving) return mask_as_double(all);   // orientation of the last valid step is carried, not theta_ref
+        if (!moving) return false;   // orientation of the last valid step is carried, not theta_ref
         const double sd = g[PF_SD], sdd = g[PF_SDD], kr = g[PF_KR], krd = g[PF_KRD];
         const double d0 = a.lat_dmin, d1 = a.lat_dmax;
         const double v0 = sd * (1.0 - kr * d0), v1 = sd * (1.0 - kr * d1);                       // v = s' (1 - k_r d) / cos(0)
@@ -560,15 +556,63 @@ __device__ __forceinline__ double near_mask_step(const KArgs &a, const RefTab &r
         R = 0.5 * (c_hi - c_lo) + fmax(fabs(d0), fabs(d1)) + a.ego_radius;
     }
     R = R * (1.0 + 1e-9) + 1e-6;
-    const gcdouble dyn = (gcdouble)ob.dyn;
-    const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
-    uint64_t m = 0;
-    for (int j = 0; j < ob.n_dyn; ++j) {
-        const gcdouble o = dyn + (size_t)j * ob.n_steps + k;
-        const double dx = o[0] - cx, dy = o[plane] - cy, rr = R + o[6 * plane];   // NaN centre: absent, no bit
-        if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (j < 63 ? j : 63);
+    return cx == cx && cy == cy && R == R;   // (NaN foot point: no bound)
+}
+
+// can static shape (kind, idx) reach the circle (cx, cy, R)?  Rectangles by their two slabs (tight for the long thin
+// strips of a road boundary, where a bounding circle says nothing), triangles and circles by their bounding circle
+__device__ __forceinline__ bool static_shape_near(const ObsTables &ob, int kind, int idx, double cx, double cy, double R) {
+    if (kind == 0) {
+        const gcdouble o = (gcdouble)ob.sobb + (size_t)idx * OB_ROW;
+        const Obb b = {o[OB_CX], o[OB_CY], o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
+        return !obb_slab_far(b, cx, cy, R);
     }
-    return mask_as_double(m);
+    const gcdouble o = kind == 1 ? (gcdouble)ob.tri + (size_t)idx * 10 + 6 : (gcdouble)ob.circ + (size_t)idx * 4;
+    const double ex = o[0] - cx, ey = o[1] - cy, er = R + o[2];
+    return ex * ex + ey * ey <= er * er * 1.000001;
+}
+
+// f[PF_NEAR], f[PF_NEAR_S] of step i
+template <bool COEFFS_IN>
+__device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, double *f) {
+    f[PF_NEAR] = f[PF_NEAR_S] = mask_as_double(0);
+    if (COEFFS_IN || !a.use_near_mask || !a.has_obstacles) return;   // masks unused: every shape is tested
+    const ObsTables &ob = a.obs;
+    double cx = 0.0, cy = 0.0, R = 0.0;
+    const bool bounded = pair_step_bound<COEFFS_IN>(a, rt, lp, i, f, cx, cy, R);
+    const int k = a.time_step0 + i * a.factor - ob.dyn_t0;
+    if (ob.n_dyn > 0 && k >= 0 && k < ob.n_steps) {   // (outside: no dynamic obstacle exists at this scenario step)
+        uint64_t m = ~0ull;
+        if (bounded) {
+            const gcdouble dyn = (gcdouble)ob.dyn;
+            const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+            m = 0;
+            for (int j = 0; j < ob.n_dyn; ++j) {
+                const gcdouble o = dyn + (size_t)j * ob.n_steps + k;
+                const double dx = o[0] - cx, dy = o[plane] - cy, rr = R + o[6 * plane];   // NaN centre: absent, no bit
+                if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (j < 63 ? j : 63);
+            }
+        }
+        f[PF_NEAR] = mask_as_double(m);
+    }
+    if (ob.n_clus > 0) {
+        uint64_t m = ~0ull;
+        if (bounded) {
+            // cluster bit = some member can be reached
+            const gcdouble cl = (gcdouble)ob.clus;
+            const gcint info = (gcint)ob.clus_info;
+            m = 0;
+            for (int c = 0; c < ob.n_clus; ++c) {
+                const double dx = cl[4 * c] - cx, dy = cl[4 * c + 1] - cy, rr = R + cl[4 * c + 2];
+                if (!(dx * dx + dy * dy <= rr * rr * 1.000001)) continue;
+                const int kind = info[4 * c], first = info[4 * c + 1], count = info[4 * c + 2];
+                bool any = false;
+                for (int q = 0; q < count; ++q) any |= static_shape_near(ob, kind, first + q, cx, cy, R);
+                if (any) m |= 1ull << c;
+            }
+        }
+        f[PF_NEAR_S] = mask_as_double(m);
+    }
 }
 
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
@@ -613,7 +657,8 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
             const int i = c * G + gl;
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
-            f[PF_NEAR] = i <= N ? near_mask_step<COEFFS_IN>(a, rt, lp, i, f) : 0.0;
+            if (i <= N) near_mask_step<COEFFS_IN>(a, rt, lp, i, f);
+            else f[PF_NEAR] = f[PF_NEAR_S] = 0.0;
             bad_a |= (i < L) && (fabs(f[PF_SDD]) > a.a_max);   // pre-filter, :798
             bad_v |= (i < L) && (f[PF_SD] < -RP_EPS);          // pre-filter, :802
             if (i <= N) {
@@ -744,12 +789,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     CandIn cin;
     ProfStep pf0;        // first step block of this lane group's candidate
     if (LON_FUSED) {
-        // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes
+        // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes |
+        //              per-item bounds of the collision broad phase [lds_pairs * n][4]
         const int n0 = a.N + 1;
         double *const lds_tab = lds_out;
         double *const lds_prof = lds_tab + a.table_words;   // table_words is even: 16-byte aligned
         PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_FIELDS * (size_t)n0);
         int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
+        double *const lds_bound = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs * n][4]
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
         const int64_t s_first = (int64_t)blockIdx.x * GPB;
         const int64_t s_last = (s_first + GPB <= count ? s_first + GPB : count) - 1;
@@ -788,7 +835,19 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             const LonPair lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
-            f[PF_NEAR] = near_mask_step<COEFFS_IN>(a, rt, lp, i, f);
+            {   // broad phase of the collision query: this item's bound now, the (item, shape) tests spread over the
+                // whole workgroup after the barrier (one lane per item would walk every shape on the critical path)
+                const ObsTables &ob = a.obs;
+                double bx = 0.0, by = 0.0, bR = 0.0;
+                const bool masks = !COEFFS_IN && a.use_near_mask && a.has_obstacles;
+                const bool bd = masks && pair_step_bound<COEFFS_IN>(a, rt, lp, i, f, bx, by, bR);
+                const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
+                const bool dyn_here = masks && ob.n_dyn > 0 && kk >= 0 && kk < ob.n_steps;
+                f[PF_NEAR] = mask_as_double(dyn_here && !bd ? ~0ull : 0ull);
+                f[PF_NEAR_S] = mask_as_double(masks && ob.n_clus > 0 && !bd ? ~0ull : 0ull);
+                double *q = lds_bound + 4 * (size_t)j;
+                q[0] = bx; q[1] = by; q[2] = bR; q[3] = bd ? 1.0 : 0.0;
+            }
             double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
 #pragma unroll
             for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n0] = f[k];
@@ -800,6 +859,37 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
         }
         __syncthreads();
+        if (!COEFFS_IN && a.use_near_mask && a.has_obstacles) {
+            const ObsTables &ob = a.obs;
+            const gcdouble dyn = (gcdouble)ob.dyn;
+            const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+            for (int t = tid; t < items * ob.n_dyn; t += RP_BLOCK) {   // (item, dynamic obstacle)
+                const int it = (int)((uint32_t)t / (uint32_t)ob.n_dyn), jo = t - it * ob.n_dyn;
+                const double *q = lds_bound + 4 * (size_t)it;
+                const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
+                const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
+                if (q[3] == 0.0 || kk < 0 || kk >= ob.n_steps) continue;
+                const gcdouble o = dyn + (size_t)jo * ob.n_steps + kk;
+                const double dx = o[0] - q[0], dy = o[plane] - q[1], rr = q[2] + o[6 * plane];   // NaN centre: absent, no bit
+                if (dx * dx + dy * dy <= rr * rr * 1.000001)
+                    atomicOr(reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + PF_NEAR) * (size_t)n0 + i),
+                             1ull << (jo < 63 ? jo : 63));
+            }
+            const gcint info = (gcint)ob.clus_info;
+            const int per = ob.clus_per > 0 ? ob.clus_per : 1;   // members per cluster (the last cluster of a kind may hold fewer)
+            const int slots = ob.n_clus * per;
+            for (int t = tid; t < items * slots; t += RP_BLOCK) {      // (item, cluster, member)
+                const int it = (int)((uint32_t)t / (uint32_t)slots), r = t - it * slots;
+                const int c = (int)((uint32_t)r / (uint32_t)per), m = r - c * per;
+                const double *q = lds_bound + 4 * (size_t)it;
+                if (q[3] == 0.0 || m >= info[4 * c + 2]) continue;
+                if (static_shape_near(ob, info[4 * c], info[4 * c + 1] + m, q[0], q[1], q[2])) {
+                    const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
+                    atomicOr(reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + PF_NEAR_S) * (size_t)n0 + i), 1ull << c);
+                }
+            }
+            __syncthreads();
+        }
         RP_STAMP(10);   // single-launch prologue: profile rows in LDS
         prof_base = lds_prof;
         hdr_base = lds_hdr;
@@ -1114,7 +1204,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         const ObsTables &ob = a.obs;
                         const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
                         hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, want, !COEFFS_IN && a.use_near_mask != 0,
-                                            double_as_mask(pf.f[PF_NEAR])) && want;
+                                            double_as_mask(pf.f[PF_NEAR]), double_as_mask(pf.f[PF_NEAR_S])) && want;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }

@@ -74,12 +74,23 @@ def main():
             rect = ob.find("shape").find("rectangle")
             x, y, th, _t, _v = state(ob.find("initialState"))
             sobb.append((x, y, th, 0.5 * float(rect.find("length").text), 0.5 * float(rect.find("width").text)))
+        # the whole lanelet network (road-boundary generator, collision.road_boundary_obb): vertices + which
+        # neighbours exist
+        ll_left, ll_right, ll_off, ll_flags, ll_ids = [], [], [0], [], []
+        for lid, ll in lanelets.items():
+            left, right = pts(ll.find("leftBound")), pts(ll.find("rightBound"))
+            assert len(left) == len(right)
+            ll_left.append(left); ll_right.append(right); ll_off.append(ll_off[-1] + len(left)); ll_ids.append(int(lid))
+            ll_flags.append([ll.find("adjacentLeft") is not None, ll.find("adjacentRight") is not None,
+                             ll.find("predecessor") is not None, ll.find("successor") is not None])
         ini = root.find("planningProblem").find("initialState")
         x, y, th, t0, v = state(ini)
         out = os.path.join(HERE, "scenario_" + name + ".npz")
         np.savez_compressed(out, centre=centre, left_bound=left_b, right_bound=right_b, dyn_obb=dyn, dyn_t0=0,
                             static_obb=np.array(sobb).reshape(-1, 5), init=np.array([x, y, th, v]), init_time_step=t0,
-                            dt=float(root.attrib["timeStepSize"]))
+                            dt=float(root.attrib["timeStepSize"]),
+                            ll_ids=np.array(ll_ids), ll_left=np.concatenate(ll_left), ll_right=np.concatenate(ll_right),
+                            ll_offsets=np.array(ll_off), ll_flags=np.array(ll_flags, dtype=bool))
         print(name, "centre", centre.shape, "dyn", dyn.shape, "static", len(sobb), "init", (x, y, th, v),
               f"{os.path.getsize(out) / 1024:.0f}KB")
 

@@ -343,14 +343,21 @@ def test_horizon_lengths_around_lane_group_boundaries(ctx, N):
 
 @pytest.mark.parametrize("name,lo,count,low_vel", [("cfg2", 0, 7440, False), ("cfg3", 0, 4000, False), ("cfg3", 30000, 4000, False),
                                                    ("cfg3", 58000, 2543, False), ("cfg4", 250000, 3000, False),
-                                                   ("cfg5obs", 500000, 3000, False), ("cfg3", 12000, 3000, True)])
+                                                   ("cfg5obs", 500000, 3000, False), ("cfg3", 12000, 3000, True),
+                                                   ("cfg2rb", 0, 7440, False), ("cfg3rb", 20000, 3000, False),
+                                                   ("cfg4rb", 100000, 3000, False), ("cfg2rb", 0, 7440, True)])
 def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
     """The benchmark workloads (many dynamic obstacles, extended horizons, curved routes): labels -- in particular
     INFEASIBLE_COLLISION -- exact against the oracle's brute-force query, in production and in draw mode.  This is
     what pins the (pair, step) broad phase of the collision query (csrc/rp_kernels.h: near_mask_step)."""
     from oracle import oracle
     from commonroad_rp_amd import workloads as W
-    w = W.cfg5(obstacles=50) if name == "cfg5obs" else W.WORKLOADS[name]()
+    if name == "cfg5obs":
+        w = W.cfg5(obstacles=50)
+    elif name.endswith("rb"):   # with the road boundary: 122 / 304 thin rectangles (collision.road_boundary_obb)
+        w = getattr(W, name[:-2])(road_boundary=True)
+    else:
+        w = W.WORKLOADS[name]()
     w.setup(ctx)
     tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
     for extra in (0, FLAG_DRAW_ALL):
