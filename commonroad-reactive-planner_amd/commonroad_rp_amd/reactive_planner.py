@@ -95,6 +95,16 @@ class GpuTrajectoryBundle:
         return _CostView(np.float64(np.nanmax(c))) if c is not None and np.any(~np.isnan(c)) else None
 
 
+def _tables_from_scenario(scenario, road_boundary_obstacle=None) -> ObstacleTables:
+    """What ``set_collision_checker(scenario=...)`` puts into the checker (reactive_planner.py:234-251): the
+    obstacles and the road boundary -- the caller's ((n, 6) triangles), or generated from the lanelet network when
+    none is given, as the reference calls ``create_road_boundary_obstacle(scenario)`` (:246-248)."""
+    tri = road_boundary_obstacle if isinstance(road_boundary_obstacle, (np.ndarray, list, tuple)) else None
+    net = getattr(scenario, "lanelet_network", None)
+    generate = tri is None and road_boundary_obstacle is None and net is not None and len(getattr(net, "lanelets", [])) > 0
+    return ObstacleTables.from_scenario(scenario, tri, road_boundary=generate)
+
+
 class GpuBackendMixin:
     """Routes the per-level hot path of ``plan()`` through the HIP library."""
 
@@ -128,7 +138,7 @@ class GpuBackendMixin:
         if parent is not None:
             parent(scenario=scenario, collision_checker=collision_checker, road_boundary_obstacle=road_boundary_obstacle)
         if scenario is not None:
-            self.set_obstacle_tables(ObstacleTables.from_scenario(scenario))
+            self.set_obstacle_tables(_tables_from_scenario(scenario, road_boundary_obstacle))
 
     def set_obstacle_tables(self, tables: Optional[ObstacleTables]):
         """Obstacle content for the GPU collision check (what the reference keeps inside the opaque
@@ -369,7 +379,7 @@ class ReactivePlanner(GpuBackendMixin):
         checker); from a scenario the tables are extracted as ``set_collision_checker`` feeds pycrcc
         (reactive_planner.py:234-251); ``road_boundary_obstacle``: (n, 6) triangles."""
         if collision_checker is None:
-            tables = ObstacleTables.from_scenario(scenario, road_boundary_obstacle) if scenario is not None else ObstacleTables()
+            tables = _tables_from_scenario(scenario, road_boundary_obstacle) if scenario is not None else ObstacleTables()
         else:
             assert isinstance(collision_checker, ObstacleTables), "pass commonroad_rp_amd.collision.ObstacleTables"
             tables = collision_checker
