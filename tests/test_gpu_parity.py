@@ -371,3 +371,76 @@ def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
         _compare_status(status, cost, orun)
         assert out.n_collision == orun.out.n_collision and out.best_index == orun.out.best_index
         assert out.n_collision_before_best == orun.out.n_collision_before_best
+
+
+def _dense_traffic(co, n_dyn, n_steps, seed=3, dt=0.1):
+    """n_dyn constant-velocity boxes on and beside the route (some cross the ego's corridor)."""
+    rng = np.random.default_rng(seed)
+    dyn = np.full((n_dyn, n_steps, 5), np.nan)
+    s_max = co.ref_pos[-1] - 2.0
+    for j in range(n_dyn):
+        s0, vel, off = rng.uniform(5.0, s_max), rng.uniform(-4.0, 12.0), rng.uniform(-6.0, 6.0)
+        k0, k1 = (0, n_steps) if j % 5 else (int(rng.integers(0, 20)), int(rng.integers(25, n_steps)))   # some appear / vanish
+        for k in range(k0, k1):
+            s = s0 + vel * dt * k
+            if not (1.0 < s < s_max):
+                continue
+            x, y = co.convert_to_cartesian_coords(s, off)
+            kk = min(int(np.searchsorted(co.ref_pos, s, side="right")) - 1, len(co.ref_pos) - 2)
+            dyn[j, k] = (x, y, co.ref_theta[kk] + rng.uniform(-0.3, 0.3), rng.uniform(1.0, 3.0), rng.uniform(0.5, 1.2))
+    return dyn
+
+
+@pytest.mark.parametrize("kind", ["more_than_63_dynamic", "stopping_mode", "lateral_start_velocity", "explicit_polynomials",
+                                  "many_static_clusters"])
+def test_collision_mask_edge_paths(ctx, kind):
+    """Branches of the (pair, step) broad phase that the benchmark workloads do not reach: the overflow bit for
+    dynamic obstacles 63, 64, ...; stopping trajectories (standstill at the last valid step: extended steps are not
+    bounded, every bit is set); a lateral start velocity (Hermite overshoot bound); explicit polynomials (no masks at
+    all); more static shapes than cluster bits."""
+    from oracle import oracle
+    from commonroad_rp_amd.collision import ObstacleTables
+    from commonroad_rp_amd._capi import LON_STOPPING
+    s = np.arange(0.0, 300.0, 1.0)
+    path = np.stack((s, 18.0 * np.sin(s / 45.0)), axis=1)
+    co, inp = _synthetic_case(path, N=40)
+    n_dyn = {"more_than_63_dynamic": 90, "stopping_mode": 40}.get(kind, 12)
+    tables = ObstacleTables(dyn_obb=_dense_traffic(co, n_dyn, 60), dyn_t0=0)
+    if kind == "many_static_clusters":
+        rng = np.random.default_rng(11)
+        boxes, tris, circs = [], [], []
+        for k in range(150):   # 150 + 60 + 40 shapes -> 5 per cluster
+            sx = rng.uniform(5.0, 290.0)
+            x, y = co.convert_to_cartesian_coords(sx, rng.choice([-1, 1]) * rng.uniform(1.5, 6.0))
+            boxes.append([x, y, rng.uniform(-3, 3), rng.uniform(0.3, 6.0), rng.uniform(0.05, 0.6)])
+            if k < 60:
+                tris.append([x + 1, y + 1, x + 2.5, y + 1.2, x + 1.5, y + 2.6])
+            if k < 40:
+                circs.append([x - 2.0, y + 1.0, rng.uniform(0.2, 0.7)])
+        tables = ObstacleTables(static_obb=boxes, static_tri=tris, static_circ=circs, dyn_obb=tables.dyn_obb, dyn_t0=0)
+    p = copy_params(inp.params)
+    if kind == "stopping_mode":
+        p.lon_mode = LON_STOPPING
+        inp = PlanInputs(p, inp.cost, inp.T, inp.traj_len, np.linspace(p.x0_lon[0] + 10.0, p.x0_lon[0] + 40.0, 7), inp.D)
+    if kind == "lateral_start_velocity":
+        p.x0_lat[1], p.x0_lat[2] = 0.9, -0.4
+        inp = PlanInputs(p, inp.cost, inp.T, inp.traj_len, inp.L, inp.D)
+    ctx.set_coordinate_system(co)
+    ctx.set_obstacles(tables)
+    tb = oracle.OracleTables.from_coordinate_system(co, tables)
+    for extra in (0, FLAG_DRAW_ALL):
+        i2 = _with_flags(inp, extra)
+        if kind == "explicit_polynomials":
+            oc = oracle.plan(i2, tb)   # coefficients of every candidate from the oracle, then the coefficient entry
+            lon_T = np.repeat(i2.T, len(i2.L) * len(i2.D))
+            tl = np.repeat(i2.traj_len, len(i2.L) * len(i2.D))
+            orun = oracle.plan_coeffs(i2.params, i2.cost, tb, oc.coeffs[:, 0:6], oc.coeffs[:, 6:12], tl)
+            out = ctx.plan_coeffs(i2.params, i2.cost, oc.coeffs[:, 0:6], oc.coeffs[:, 6:12], lon_T, tl)
+        else:
+            orun = oracle.plan(i2, tb)
+            out = ctx.plan(i2)
+        status, cost = ctx.fetch_status()
+        _compare_status(status, cost, orun)
+        assert out.n_collision == orun.out.n_collision and out.best_index == orun.out.best_index
+        assert out.n_collision_before_best == orun.out.n_collision_before_best
+    assert orun.out.n_collision > 0
