@@ -181,7 +181,8 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 // (no separate memset / count / copy operations on the stream).
 // ------------------------------------------------------------------------------------------------
 #define RP_FIN_THREADS 256
-#define RP_FINALIZE_MAX (1 << 17)
+#define RP_FINALIZE_MAX (1 << 14)   // above: the count of colliding samples before the winner runs as its own many-workgroup
+                                    // kernel (one workgroup walking 60 000 status words took 139 us on cfg3)
 
 struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
     rp_result r;
