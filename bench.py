@@ -95,7 +95,7 @@ def run():
 
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import (RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL)
-    from commonroad_rp_amd.distributed import shard_range, exchange_winner, close_exchanges
+    from commonroad_rp_amd.distributed import shard_range, make_exchange, close_exchanges
 
     flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[args.mode]
     base = W.WORKLOADS[args.workload](road_boundary=True) if args.road_boundary else W.WORKLOADS[args.workload]()
@@ -113,10 +113,12 @@ def run():
     # stream time on this 20-us kernel; profiles/host_overhead.py), the average is over the sampled launches
     ctx.set_profiling(4)
 
+    exchange = make_exchange(dist, torch.device("cuda", local_rank), N + 1) if dist is not None else None
+
     def step():
         out = ctx.plan(inp, lo, hi)
-        if dist is not None:
-            return exchange_winner(ctx, out, dist, torch.device("cuda", local_rank)), out
+        if exchange is not None:
+            return exchange(ctx, out), out
         return out, out
 
     for _ in range(args.warmup):

@@ -198,6 +198,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
         "rp_count_collisions_before": (C.c_int, [ctx, C.c_double, C.c_int64, C.POINTER(C.c_int64)]),
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
+        "rp_mailbox_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+        "rp_mailbox_exchange": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(RpResult), dp,
+                                          C.POINTER(RpResult), dp, ip]),
+        "rp_mailbox_sum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int64,
+                                     C.POINTER(C.c_int64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export the header's symbol
@@ -211,7 +216,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
-                    "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select")
+                    "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
+                    "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
 
 
 class RpContext:
@@ -283,6 +289,7 @@ class RpContext:
             self._check(rc, "rp_plan")
         self._N = inp.params.N
         self._last_count = res.n_candidates
+        self._last_best = best        # (raw result of the last plan: what the intra-node exchange posts)
         return PlanOutput.from_c(res, best)
 
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,

@@ -82,19 +82,20 @@ def combine_results(msgs: np.ndarray, n: int):
 
 
 class MailboxExchange:
-    """Shared-memory mailbox of the ranks of one node.  Slot layout per (parity, rank), 64-byte aligned:
-    ``[seq u64 | 7 pad][HEAD + 14 n doubles][cnt_seq u64][cnt i64][6 pad]``.  Two parities alternate between
-    consecutive steps: a rank can run at most one step ahead of the slowest reader (it cannot finish step k+1
-    before every peer has published k+1, which a peer does only after it has read step k), so the buffer a rank
-    overwrites at step k+2 has been read by everyone."""
+    """Shared-memory mailbox of the ranks of one node, driven by the library's host-only entry points
+    ``rp_mailbox_exchange`` / ``rp_mailbox_sum`` (include/rp_amd.h, csrc/rp_host.hip): every rank posts its
+    ``rp_result`` + winner state block into its slot, spins on the peers' sequence words and combines.  Two slot
+    parities alternate between consecutive steps: a rank can run at most one step ahead of the slowest reader,
+    so the slot it overwrites two steps later has been read by everyone."""
 
     def __init__(self, dist, n: int, name_hint: str = ""):
         from multiprocessing import shared_memory
+        from . import _capi
+        self._capi = _capi
+        self._lib = _capi.load_library()
         self.dist, self.n = dist, n
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.words = 8 + HEAD + N_ARRAYS * n + 8          # doubles per slot
-        self.words = (self.words + 7) & ~7                 # 64-byte multiple
-        size = 2 * self.world * self.words * 8
+        size = int(self._lib.rp_mailbox_bytes(self.world, n))
         names = [None]
         if self.rank == 0:
             self.shm = shared_memory.SharedMemory(create=True, size=size)
@@ -108,45 +109,66 @@ class MailboxExchange:
                 resource_tracker.unregister(self.shm._name, "shared_memory")
             except Exception:
                 pass
-        self.box = np.ndarray((2, self.world, self.words), dtype=np.float64, buffer=self.shm.buf)
-        self.ibox = self.box.view(np.int64)
+        import ctypes as C
+        tmp = C.c_char.from_buffer(self.shm.buf)      # (only to learn the mapping's address: a lasting ctypes export
+        self._region = C.c_void_p(C.addressof(tmp))   #  would keep SharedMemory.close() from releasing the buffer)
+        del tmp
         self.seq = 0
-        self._msgs = np.zeros((self.world, HEAD + N_ARRAYS * n), dtype=np.float64)
+        self._local, self._glob = _capi.RpResult(), _capi.RpResult()
+        self._states = np.empty((N_ARRAYS, n))
+        self._owner = C.c_int32(0)
+        self._total = C.c_int64(0)
         dist.barrier()   # everyone is attached before the first post
 
     def close(self):
         try:
-            self.box = self.ibox = None
+            self._region = None
             self.shm.close()
             if self.rank == 0:
                 self.shm.unlink()
         except Exception:
             pass
 
-    def _wait(self, par: int, word: int, value: int):
-        col = self.ibox[par, :, word]
-        spins = 0
-        while not (col == value).all():
-            spins += 1
-            if spins > 50_000_000:
-                raise TimeoutError("MailboxExchange: a peer rank did not post its result")
-
     def __call__(self, ctx, out: PlanOutput) -> PlanOutput:
+        import ctypes as C
         self.seq += 1
-        k, par, r = self.seq, self.seq & 1, self.rank
-        pack_result(out, self.n, self.box[par, r, 8:8 + HEAD + N_ARRAYS * self.n])
-        self.ibox[par, r, 0] = k                       # publish (x86: stores are not reordered with older stores)
-        self._wait(par, 0, k)
-        np.copyto(self._msgs, self.box[par, :, 8:8 + HEAD + N_ARRAYS * self.n])
-        glob, _owner = combine_results(self._msgs, self.n)
-        glob.kernel_ms = out.kernel_ms
+        lo, dp = self._local, self._capi.dptr
+        raw = getattr(ctx, "_res", None)
+        if raw is not None and int(raw.best_index) == out.best_index and int(raw.n_candidates) == out.n_candidates:
+            # the context still holds the C result of this very plan: post it as it is
+            raw_states = getattr(ctx, "_last_best", None) if out.best_index >= 0 else None
+            rc = self._lib.rp_mailbox_exchange(self._region, self.world, self.rank, self.seq, self.n, C.byref(raw),
+                                               dp(raw_states) if raw_states is not None else None, C.byref(self._glob),
+                                               dp(self._states), C.byref(self._owner))
+            return self._finish(ctx, rc)
+        lo.best_index, lo.best_cost = out.best_index, out.best_cost
+        lo.n_candidates, lo.n_feasible, lo.n_collision = out.n_candidates, out.n_feasible, out.n_collision
+        lo.n_collision_before_best = 0
+        lo.kernel_ms = out.kernel_ms
+        lo.best_lat_T = out.best_lat_T
+        for k in range(8):
+            lo.reason_counts[k] = int(out.reason_counts[k])
+        if out.best_index >= 0:
+            for k in range(6):
+                lo.best_lon_coeffs[k] = out.best_lon_coeffs[k]
+                lo.best_lat_coeffs[k] = out.best_lat_coeffs[k]
+        st = out.best_states if (out.best_index >= 0 and out.best_states is not None) else None
+        rc = self._lib.rp_mailbox_exchange(self._region, self.world, self.rank, self.seq, self.n, C.byref(lo),
+                                           dp(np.ascontiguousarray(st)) if st is not None else None, C.byref(self._glob),
+                                           dp(self._states), C.byref(self._owner))
+        return self._finish(ctx, rc)
+
+    def _finish(self, ctx, rc: int) -> PlanOutput:
+        import ctypes as C
+        if rc != 0:
+            raise TimeoutError(f"rp_mailbox_exchange -> {rc}: a peer rank did not post its result")
+        glob = PlanOutput.from_c(self._glob, self._states.copy() if self._glob.best_index >= 0 else None)
         if glob.n_collision > 0:   # second pass only when some rank saw a colliding candidate
-            c0 = 8 + HEAD + N_ARRAYS * self.n
             n_before = ctx.count_collisions_before(glob.best_cost if glob.best_index >= 0 else 0.0, glob.best_index)
-            self.ibox[par, r, c0 + 1] = int(n_before)
-            self.ibox[par, r, c0] = k
-            self._wait(par, c0, k)
-            glob.n_collision_before_best = int(self.ibox[par, :, c0 + 1].sum())
+            rc = self._lib.rp_mailbox_sum(self._region, self.world, self.rank, self.seq, self.n, int(n_before), C.byref(self._total))
+            if rc != 0:
+                raise TimeoutError(f"rp_mailbox_sum -> {rc}: a peer rank did not post its count")
+            glob.n_collision_before_best = int(self._total.value)
         return glob
 
 
@@ -204,14 +226,19 @@ def exchange_winner(ctx, out: PlanOutput, dist, device, transport: str = "auto")
     ``ctx`` must still hold the rank's last plan (for the optional second pass).
     ``transport``: "mailbox" (ranks of one node), "collective" (``torch.distributed``), or "auto".
     The choice is collective on first use (all ranks must pass the same value)."""
-    import os
     n = (out.best_states.shape[1] if out.best_states is not None else ctx._N + 1)
+    return make_exchange(dist, device, n, transport)(ctx, out)
+
+
+def make_exchange(dist, device, n: int, transport: str = "auto"):
+    """The exchange object itself (callable ``ex(ctx, out) -> PlanOutput``), for loops that should not pay the
+    lookup of ``exchange_winner`` per step.  Collective: every rank must call it with the same arguments."""
+    import os
     transport = os.environ.get("RP_AMD_EXCHANGE", transport)
     key = (id(dist), str(device), n, dist.get_world_size(), transport)
     ex = _exchanges.get(key)
     if ex is None:
-        use_mailbox = transport == "mailbox" or (transport == "auto" and same_host(dist))
-        if use_mailbox:
+        if transport == "mailbox" or (transport == "auto" and same_host(dist)):
             try:
                 ex = MailboxExchange(dist, n)
             except (OSError, ImportError):
@@ -220,7 +247,7 @@ def exchange_winner(ctx, out: PlanOutput, dist, device, transport: str = "auto")
         if ex is None:
             ex = CollectiveExchange(dist, device, n)
         _exchanges[key] = ex
-    return ex(ctx, out)
+    return ex
 
 
 def close_exchanges():

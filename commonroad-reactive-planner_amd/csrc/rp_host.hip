@@ -892,3 +892,100 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------------
+// Intra-node winner exchange through a shared-memory mailbox (include/rp_amd.h).  Slot layout per
+// (parity, rank), 64-byte aligned: [seq][7 pad][rp_result][14 n doubles][cnt_seq][cnt][pad].
+// Two parities alternate between consecutive exchanges: a rank can run at most one exchange ahead of the
+// slowest reader, so the slot it overwrites two exchanges later has been read by everyone.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct MailboxLayout {
+    size_t slot_bytes, result_off, states_off, cnt_off;
+};
+MailboxLayout mailbox_layout(int n_steps) {
+    MailboxLayout l;
+    l.result_off = 64;
+    l.states_off = l.result_off + ((sizeof(rp_result) + 63) & ~(size_t)63);
+    l.cnt_off = l.states_off + ((sizeof(double) * RP_N_ARRAYS * (size_t)n_steps + 63) & ~(size_t)63);
+    l.slot_bytes = l.cnt_off + 64;
+    return l;
+}
+inline char *mailbox_slot(void *region, const MailboxLayout &l, int world, uint64_t seq, int rank) {
+    return static_cast<char *>(region) + ((size_t)(seq & 1) * (size_t)world + (size_t)rank) * l.slot_bytes;
+}
+bool mailbox_wait(void *region, const MailboxLayout &l, int world, uint64_t seq, size_t off) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < world; ++r) {
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(mailbox_slot(region, l, world, seq, r) + off);
+        for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return false;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+size_t rp_mailbox_bytes(int32_t world, int32_t n_steps) {
+    if (world < 1 || n_steps < 1) return 0;
+    return 2 * (size_t)world * mailbox_layout(n_steps).slot_bytes;
+}
+
+int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, const rp_result *local,
+                        const double *local_best_states, rp_result *global, double *global_best_states, int32_t *owner_rank) {
+    if (!region || !local || !global || world < 1 || rank < 0 || rank >= world || n_steps < 1 || seq == 0) return RP_EINVAL;
+    const MailboxLayout l = mailbox_layout(n_steps);
+    const size_t sbytes = sizeof(double) * RP_N_ARRAYS * (size_t)n_steps;
+    char *mine = mailbox_slot(region, l, world, seq, rank);
+    std::memcpy(mine + l.result_off, local, sizeof(rp_result));
+    if (local->best_index >= 0 && local_best_states) std::memcpy(mine + l.states_off, local_best_states, sbytes);
+    __atomic_store_n(reinterpret_cast<uint64_t *>(mine), seq, __ATOMIC_RELEASE);
+    if (!mailbox_wait(region, l, world, seq, 0)) return RP_ESTATE;
+    rp_result g;
+    std::memset(&g, 0, sizeof(g));
+    g.best_index = -1;
+    g.best_cost = std::nan("");
+    g.best_lat_T = std::nan("");
+    for (int k = 0; k < 6; ++k) g.best_lon_coeffs[k] = g.best_lat_coeffs[k] = std::nan("");
+    int owner = -1;
+    for (int r = 0; r < world; ++r) {
+        rp_result q;
+        std::memcpy(&q, mailbox_slot(region, l, world, seq, r) + l.result_off, sizeof(q));
+        g.n_candidates += q.n_candidates;
+        g.n_feasible += q.n_feasible;
+        g.n_collision += q.n_collision;
+        for (int k = 0; k < 8; ++k) g.reason_counts[k] += q.reason_counts[k];
+        if (q.best_index >= 0 && (owner < 0 || q.best_cost < g.best_cost || (q.best_cost == g.best_cost && q.best_index < g.best_index))) {
+            owner = r;
+            g.best_index = q.best_index;
+            g.best_cost = q.best_cost;
+            std::memcpy(g.best_lon_coeffs, q.best_lon_coeffs, sizeof(g.best_lon_coeffs));
+            std::memcpy(g.best_lat_coeffs, q.best_lat_coeffs, sizeof(g.best_lat_coeffs));
+            g.best_lat_T = q.best_lat_T;
+        }
+    }
+    g.kernel_ms = local->kernel_ms;
+    *global = g;
+    if (owner >= 0 && global_best_states) std::memcpy(global_best_states, mailbox_slot(region, l, world, seq, owner) + l.states_off, sbytes);
+    if (owner_rank) *owner_rank = owner;
+    return RP_OK;
+}
+
+int rp_mailbox_sum(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, int64_t value, int64_t *total) {
+    if (!region || !total || world < 1 || rank < 0 || rank >= world || n_steps < 1 || seq == 0) return RP_EINVAL;
+    const MailboxLayout l = mailbox_layout(n_steps);
+    char *mine = mailbox_slot(region, l, world, seq, rank);
+    *reinterpret_cast<int64_t *>(mine + l.cnt_off + 8) = value;
+    __atomic_store_n(reinterpret_cast<uint64_t *>(mine + l.cnt_off), seq, __ATOMIC_RELEASE);
+    if (!mailbox_wait(region, l, world, seq, l.cnt_off)) return RP_ESTATE;
+    int64_t t = 0;
+    for (int r = 0; r < world; ++r) t += *reinterpret_cast<const int64_t *>(mailbox_slot(region, l, world, seq, r) + l.cnt_off + 8);
+    *total = t;
+    return RP_OK;
+}
+
+}  // extern "C"

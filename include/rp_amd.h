@@ -199,6 +199,21 @@ int rp_count_collisions_before(rp_ctx *ctx, double cost, int64_t index, int64_t 
  * redo the selection (argmin + collision counters) on the device. */
 int rp_select(rp_ctx *ctx, const double *costs, int64_t count, rp_result *result, double *best_states);
 
+/* ---- intra-node winner exchange (host only; no GPU involved) -----------------------------------
+   Replaces the reference's only "communication backend", the multiprocessing.Queue fan-out of
+   ReactivePlanner._get_optimal_trajectory (commonroad_rp/reactive_planner.py:1084-1111), for candidate ranges
+   sharded over the GPUs of one node.  Every rank's rp_plan result already sits in host memory, so the ranks
+   post it to a shared-memory region (POSIX shm mapped by every rank; the caller creates, zero-fills and maps
+   it) and combine: global (cost, index) min-loc, summed counters, the winner's coefficients and state block.
+   `seq` must increase by one per exchange, the same on every rank.  rp_mailbox_sum is the second pass
+   (colliding candidates before the global winner).  Both spin until every rank has posted; return RP_OK, or
+   RP_ESTATE after ~10 s without progress. */
+size_t rp_mailbox_bytes(int32_t world, int32_t n_steps /* N + 1 */);
+int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, const rp_result *local,
+                        const double *local_best_states /* [14][n_steps] or NULL */, rp_result *global,
+                        double *global_best_states /* [14][n_steps] or NULL */, int32_t *owner_rank);
+int rp_mailbox_sum(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, int64_t value, int64_t *total);
+
 #ifdef __cplusplus
 }
 #endif
