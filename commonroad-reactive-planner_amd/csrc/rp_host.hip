@@ -171,9 +171,9 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
-    // reference tables + profile rows + pair headers + pre-filter votes + per-item bounds of the collision broad phase
+    // reference tables + profile rows + pair headers + pre-filter votes + time sample per pair
     const size_t bytes = (size_t)ka.table_words * sizeof(double) +
-                         (size_t)P * ((size_t)(PF_FIELDS + 4) * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int)) + 8;
+                         (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 8;
     if (bytes > kFusedLonLdsLimit) return 0;
     *pairs = P;
     return (bytes + 15) & ~(size_t)15;

@@ -515,49 +515,78 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
 __device__ __forceinline__ double mask_as_double(uint64_t m) { return __longlong_as_double((long long)m); }
 __device__ __forceinline__ uint64_t double_as_mask(double d) { return (uint64_t)__double_as_longlong(d); }
 
-// dt * sum_{t=1..m} max(0, v + t dt a): distance covered by the extension after m steps (trajectories.py:182-196)
+// dt * sum_{t=1..m} max(0, v + t dt a): distance covered by the extension after m steps (trajectories.py:182-196),
+// in closed form (the terms are an arithmetic progression clipped at zero); callers add a relative slack
 __device__ __forceinline__ double ext_travel(double v, double acc, int m, double dt) {
-    double c = 0.0;
-    for (int t = 1; t <= m; ++t) {
-        const double vt = v + ((double)t * dt) * acc;
-        c += dt * (vt >= 0.0 ? vt : 0.0);
+    const double h = dt * acc;   // increment of the progression v + t h
+    double t0 = 1.0, t1 = (double)m;   // the range of t whose terms are positive
+    if (h < 0.0) {
+        if (!(v > 0.0)) return 0.0;
+        t1 = fmin(t1, floor(v / -h));             // v + t h >= 0  <=>  t <= v / -h
+    } else if (v < 0.0) {
+        if (!(h > 0.0)) return 0.0;
+        t0 = fmax(t0, floor(-v / h) + 1.0);       // v + t h > 0   <=>  t > -v / h
     }
-    return c;
+    if (t1 < t0) return 0.0;
+    const double cnt = t1 - t0 + 1.0;
+    return dt * (cnt * v + h * 0.5 * (t0 + t1) * cnt);
 }
 
+// what pair_step_bound reads of the pair, of step i and of the last valid step L - 1
+struct BoundIn {
+    int L;
+    double T, lat_T, s0;                                   // pair
+    double s_i, px_i, py_i;                                // step i (used when i < L)
+    double sd1, sdd1, kr1, krd1, px1, py1, th1, inv_sd1;   // step L - 1 (used when i >= L)
+};
+
 // circle (cx, cy, R) that contains the ego rectangle of every candidate of the pair at step i; false: no bound
-template <bool COEFFS_IN>
-__device__ __forceinline__ bool pair_step_bound(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, const double *f,
-                                                double &cx, double &cy, double &R) {
-    if (COEFFS_IN) return false;
-    const int L = lp.L;
-    if (!(fabs((double)(L - 1) * a.dt - lp.T) <= 1e-9 * lp.T)) return false;   // T is not the last valid step
+__device__ __forceinline__ bool pair_step_bound(const KArgs &a, int i, const BoundIn &in, double &cx, double &cy, double &R) {
+    const int L = in.L;
+    if (!(fabs((double)(L - 1) * a.dt - in.T) <= 1e-9 * in.T)) return false;   // T is not the last valid step
     const double wb = fabs(a.wb_rear_axle);
     if (i < L) {
-        const double tau = a.low_vel_mode ? f[PF_S] - lp.lon.c0 : (double)i * a.dt;
-        if (!(tau >= 0.0 && tau <= lp.lat_T * (1.0 + 1e-12))) return false;
-        const double dmax = a.lat_abs_d + 0.2 * fabs(a.x0_lat[1]) * lp.lat_T + 0.0173 * fabs(a.x0_lat[2]) * lp.lat_T * lp.lat_T;
-        cx = f[PF_PX]; cy = f[PF_PY];
+        const double tau = a.low_vel_mode ? in.s_i - in.s0 : (double)i * a.dt;
+        if (!(tau >= 0.0 && tau <= in.lat_T * (1.0 + 1e-12))) return false;
+        const double dmax = a.lat_abs_d + 0.2 * fabs(a.x0_lat[1]) * in.lat_T + 0.0173 * fabs(a.x0_lat[2]) * in.lat_T * in.lat_T;
+        cx = in.px_i; cy = in.py_i;
         R = dmax + wb + a.ego_radius;
     } else {
-        double g[PF_FIELDS];
-        lon_step(a, rt, lp.lon, L - 1, g);
-        const bool moving = g[PF_INV_SD] > 0.0 || a.low_vel_mode;
+        const bool moving = in.inv_sd1 > 0.0 || a.low_vel_mode;
         if (!moving) return false;   // orientation of the last valid step is carried, not theta_ref
-        const double sd = g[PF_SD], sdd = g[PF_SDD], kr = g[PF_KR], krd = g[PF_KRD];
+        const double sd = in.sd1, sdd = in.sdd1, kr = in.kr1, krd = in.krd1;
         const double d0 = a.lat_dmin, d1 = a.lat_dmax;
         const double v0 = sd * (1.0 - kr * d0), v1 = sd * (1.0 - kr * d1);                       // v = s' (1 - k_r d) / cos(0)
         const double a0 = sdd * (1.0 - kr * d0) - sd * sd * krd * d0, a1 = sdd * (1.0 - kr * d1) - sd * sd * krd * d1;
         const int m = i - L + 1;
-        const double c_lo = ext_travel(fmin(v0, v1), fmin(a0, a1), m, a.dt), c_hi = ext_travel(fmax(v0, v1), fmax(a0, a1), m, a.dt);
+        const double c_lo = ext_travel(fmin(v0, v1), fmin(a0, a1), m, a.dt) * (1.0 - 1e-9);
+        const double c_hi = ext_travel(fmax(v0, v1), fmax(a0, a1), m, a.dt) * (1.0 + 1e-9);
         double sn, cs;
-        rp_sincos(g[PF_TH_REF], &sn, &cs);
+        rp_sincos(in.th1, &sn, &cs);
         const double along = 0.5 * (c_lo + c_hi) + wb;
-        cx = g[PF_PX] + along * cs; cy = g[PF_PY] + along * sn;
+        cx = in.px1 + along * cs; cy = in.py1 + along * sn;
         R = 0.5 * (c_hi - c_lo) + fmax(fabs(d0), fabs(d1)) + a.ego_radius;
     }
     R = R * (1.0 + 1e-9) + 1e-6;
     return cx == cx && cy == cy && R == R;   // (NaN foot point: no bound)
+}
+
+// the same from the profile fields of step i (and of step L - 1, recomputed, for extended steps)
+template <bool COEFFS_IN>
+__device__ __forceinline__ bool pair_step_bound_fields(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, const double *f,
+                                                       double &cx, double &cy, double &R) {
+    if (COEFFS_IN) return false;
+    BoundIn in;
+    in.L = lp.L; in.T = lp.T; in.lat_T = lp.lat_T; in.s0 = lp.lon.c0;
+    in.s_i = f[PF_S]; in.px_i = f[PF_PX]; in.py_i = f[PF_PY];
+    in.sd1 = in.sdd1 = in.kr1 = in.krd1 = in.px1 = in.py1 = in.th1 = in.inv_sd1 = 0.0;
+    if (i >= lp.L) {
+        double g[PF_FIELDS];
+        lon_step(a, rt, lp.lon, lp.L - 1, g);
+        in.sd1 = g[PF_SD]; in.sdd1 = g[PF_SDD]; in.kr1 = g[PF_KR]; in.krd1 = g[PF_KRD];
+        in.px1 = g[PF_PX]; in.py1 = g[PF_PY]; in.th1 = g[PF_TH_REF]; in.inv_sd1 = g[PF_INV_SD];
+    }
+    return pair_step_bound(a, i, in, cx, cy, R);
 }
 
 // can static shape (kind, idx) reach the circle (cx, cy, R)?  Rectangles by their two slabs (tight for the long thin
@@ -580,7 +609,7 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
     if (COEFFS_IN || !a.use_near_mask || !a.has_obstacles) return;   // masks unused: every shape is tested
     const ObsTables &ob = a.obs;
     double cx = 0.0, cy = 0.0, R = 0.0;
-    const bool bounded = pair_step_bound<COEFFS_IN>(a, rt, lp, i, f, cx, cy, R);
+    const bool bounded = pair_step_bound_fields<COEFFS_IN>(a, rt, lp, i, f, cx, cy, R);
     const int k = a.time_step0 + i * a.factor - ob.dyn_t0;
     if (ob.n_dyn > 0 && k >= 0 && k < ob.n_steps) {   // (outside: no dynamic obstacle exists at this scenario step)
         uint64_t m = ~0ull;
@@ -791,13 +820,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     ProfStep pf0;        // first step block of this lane group's candidate
     if (LON_FUSED) {
         // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes |
-        //              per-item bounds of the collision broad phase [lds_pairs * n][4]
+        //              time sample of each pair [lds_pairs]
         const int n0 = a.N + 1;
         double *const lds_tab = lds_out;
         double *const lds_prof = lds_tab + a.table_words;   // table_words is even: 16-byte aligned
         PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_FIELDS * (size_t)n0);
         int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
-        double *const lds_bound = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs * n][4]
+        double *const lds_T = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs] time sample of the pair
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
         const int64_t s_first = (int64_t)blockIdx.x * GPB;
         const int64_t s_last = (s_first + GPB <= count ? s_first + GPB : count) - 1;
@@ -836,19 +865,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             const LonPair lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
-            {   // broad phase of the collision query: this item's bound now, the (item, shape) tests spread over the
-                // whole workgroup after the barrier (one lane per item would walk every shape on the critical path)
-                const ObsTables &ob = a.obs;
-                double bx = 0.0, by = 0.0, bR = 0.0;
-                const bool masks = !COEFFS_IN && a.use_near_mask && a.has_obstacles;
-                const bool bd = masks && pair_step_bound<COEFFS_IN>(a, rt, lp, i, f, bx, by, bR);
-                const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
-                const bool dyn_here = masks && ob.n_dyn > 0 && kk >= 0 && kk < ob.n_steps;
-                f[PF_NEAR] = mask_as_double(dyn_here && !bd ? ~0ull : 0ull);
-                f[PF_NEAR_S] = mask_as_double(masks && ob.n_clus > 0 && !bd ? ~0ull : 0ull);
-                double *q = lds_bound + 4 * (size_t)j;
-                q[0] = bx; q[1] = by; q[2] = bR; q[3] = bd ? 1.0 : 0.0;
-            }
+            f[PF_NEAR] = f[PF_NEAR_S] = mask_as_double(0);   // filled by the whole workgroup after the barrier
+            if (i == 0) lds_T[p] = lp.T;
             double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
 #pragma unroll
             for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n0] = f[k];
@@ -861,33 +879,60 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         }
         __syncthreads();
         if (!COEFFS_IN && a.use_near_mask && a.has_obstacles) {
+            // Broad phase of the collision query (near_mask_step), spread over the whole workgroup: one lane per
+            // (item, shape) test; every lane derives its item's bound from the profile rows in LDS (one lane per item
+            // walking every shape would sit on the critical path of the workgroup).
             const ObsTables &ob = a.obs;
+            auto item_bound = [&](int it, double &bx, double &by, double &bR) -> bool {
+                const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
+                const double *row = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0;
+                BoundIn in;
+                in.L = lds_hdr[p].L; in.T = lds_T[p]; in.lat_T = lds_hdr[p].lat_T; in.s0 = lds_hdr[p].s0;
+                in.s_i = row[(size_t)PF_S * n0 + i]; in.px_i = row[(size_t)PF_PX * n0 + i]; in.py_i = row[(size_t)PF_PY * n0 + i];
+                const int l1 = in.L - 1;
+                in.sd1 = row[(size_t)PF_SD * n0 + l1]; in.sdd1 = row[(size_t)PF_SDD * n0 + l1];
+                in.kr1 = row[(size_t)PF_KR * n0 + l1]; in.krd1 = row[(size_t)PF_KRD * n0 + l1];
+                in.px1 = row[(size_t)PF_PX * n0 + l1]; in.py1 = row[(size_t)PF_PY * n0 + l1];
+                in.th1 = row[(size_t)PF_TH_REF * n0 + l1]; in.inv_sd1 = row[(size_t)PF_INV_SD * n0 + l1];
+                return pair_step_bound(a, i, in, bx, by, bR);
+            };
+            auto mask_word = [&](int it, int field) -> unsigned long long * {
+                const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
+                return reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + field) * (size_t)n0 + i);
+            };
             const gcdouble dyn = (gcdouble)ob.dyn;
             const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
-            for (int t = tid; t < items * ob.n_dyn; t += RP_BLOCK) {   // (item, dynamic obstacle)
-                const int it = (int)((uint32_t)t / (uint32_t)ob.n_dyn), jo = t - it * ob.n_dyn;
-                const double *q = lds_bound + 4 * (size_t)it;
-                const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
-                const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
-                if (q[3] == 0.0 || kk < 0 || kk >= ob.n_steps) continue;
-                const gcdouble o = dyn + (size_t)jo * ob.n_steps + kk;
-                const double dx = o[0] - q[0], dy = o[plane] - q[1], rr = q[2] + o[6 * plane];   // NaN centre: absent, no bit
-                if (dx * dx + dy * dy <= rr * rr * 1.000001)
-                    atomicOr(reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + PF_NEAR) * (size_t)n0 + i),
-                             1ull << (jo < 63 ? jo : 63));
-            }
             const gcint info = (gcint)ob.clus_info;
             const int per = ob.clus_per > 0 ? ob.clus_per : 1;   // members per cluster (the last cluster of a kind may hold fewer)
             const int slots = ob.n_clus * per;
-            for (int t = tid; t < items * slots; t += RP_BLOCK) {      // (item, cluster, member)
-                const int it = (int)((uint32_t)t / (uint32_t)slots), r = t - it * slots;
-                const int c = (int)((uint32_t)r / (uint32_t)per), m = r - c * per;
-                const double *q = lds_bound + 4 * (size_t)it;
-                if (q[3] == 0.0 || m >= info[4 * c + 2]) continue;
-                if (static_shape_near(ob, info[4 * c], info[4 * c + 1] + m, q[0], q[1], q[2])) {
-                    const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
-                    atomicOr(reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + PF_NEAR_S) * (size_t)n0 + i), 1ull << c);
+            // lanes_per_item lanes share an item: each works the bound out once and takes every lanes_per_item-th shape
+            const int lanes_per_item = items >= RP_BLOCK ? 1 : RP_BLOCK / items;
+            const int sub = tid % lanes_per_item;
+            for (int it = tid / lanes_per_item; it < items; it += RP_BLOCK / lanes_per_item) {
+                const int i = it - (int)((uint32_t)it / (uint32_t)n0) * n0;
+                const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
+                const bool dyn_here = ob.n_dyn > 0 && kk >= 0 && kk < ob.n_steps;   // else: no dynamic obstacle at this scenario step
+                double bx, by, bR;
+                if (!item_bound(it, bx, by, bR)) {   // no bound: every bit
+                    if (sub == 0 && dyn_here) atomicOr(mask_word(it, PF_NEAR), ~0ull);
+                    if (sub == 0 && slots > 0) atomicOr(mask_word(it, PF_NEAR_S), ~0ull);
+                    continue;
                 }
+                if (dyn_here) {
+                    uint64_t m = 0;
+                    for (int jo = sub; jo < ob.n_dyn; jo += lanes_per_item) {
+                        const gcdouble o = dyn + (size_t)jo * ob.n_steps + kk;
+                        const double dx = o[0] - bx, dy = o[plane] - by, rr = bR + o[6 * plane];   // NaN centre: absent, no bit
+                        if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (jo < 63 ? jo : 63);
+                    }
+                    if (m) atomicOr(mask_word(it, PF_NEAR), m);
+                }
+                uint64_t ms = 0;
+                for (int r = sub; r < slots; r += lanes_per_item) {
+                    const int c = (int)((uint32_t)r / (uint32_t)per), mem = r - c * per;
+                    if (mem < info[4 * c + 2] && static_shape_near(ob, info[4 * c], info[4 * c + 1] + mem, bx, by, bR)) ms |= 1ull << c;
+                }
+                if (ms) atomicOr(mask_word(it, PF_NEAR_S), ms);
             }
             __syncthreads();
         }
