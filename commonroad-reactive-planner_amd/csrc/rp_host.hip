@@ -24,6 +24,7 @@ namespace {
 constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
 constexpr int kFoldThreshold = 2048;
+constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass
 constexpr int kNearMaskMinObstacles = 0;  // (pair, step) broad phase of the collision query above this many dynamic obstacles
                                           // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
@@ -705,7 +706,12 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
         if (!(g->T[i] > 0.0) || g->traj_len[i] < 1) return fail(c, RP_EINVAL, "rp_plan: T must be positive, traj_len >= 1");
     const int64_t count = cand_end - cand_begin;
     const int n = p->N + 1;
-    const bool mat = (p->flags & RP_FLAG_MATERIALIZE_ALL) != 0 || cost->kind == RP_COST_EXTERNAL;
+    bool mat = (p->flags & RP_FLAG_MATERIALIZE_ALL) != 0 || cost->kind == RP_COST_EXTERNAL;
+    // Small batches whose winner block is wanted: write every candidate's state rows anyway.  The alternative -- a
+    // second launch that re-evaluates the winner -- costs 12.6 us on cfg2, the rows of 7 440 candidates 2-3 us.
+    if (!mat && best_states && (size_t)count * RP_N_ARRAYS * (size_t)n * sizeof(double) <= kAutoMaterializeBytes &&
+        !std::getenv("RP_AMD_NO_AUTO_MATERIALIZE"))
+        mat = true;
     HIP_TRY(c, hipSetDevice(c->device));
 
     // stage grids: [T | L | D | traj_len]
