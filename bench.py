@@ -62,6 +62,8 @@ def run():
     ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed region (no production-mode leg, no plan() latency leg, no cpu_baseline): counter passes")
     ap.add_argument("--road-boundary", action="store_true",
                     help="scenario workloads: add the road boundary (thin rectangles, collision.road_boundary_obb) to the obstacle tables")
     args = ap.parse_args()
@@ -184,7 +186,7 @@ def run():
                      "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.main_only:
         # production-mode rate beside the headline (same workload, early exits, 12 B / candidate)
         if args.mode != "fused":
             pf = copy_params(w.inputs.params)

@@ -6,6 +6,6 @@ set -e
 WL=${1:-cfg2}; STEPS=${2:-20}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/pmc_$WL
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/r -- python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -- python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 3 --main-only > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/r -- python3 $ROOT/bench.py --workload $WL --steps $STEPS --warmup 3 --main-only > /dev/null 2>&1
 cd $ROOT && python3 profiles/pmc_summary.py $WL $OUT
