@@ -2,8 +2,10 @@
 //
 // Host side of the boundary: owns the device tables and work buffers of one rp_ctx, stages the
 // (tiny) per-call inputs through pinned memory, launches
-//     rp_eval_kernel -> rp_reduce_kernel -> rp_count_before_kernel -> rp_eval_kernel<single winner>
-// on the context's stream and reads one small result block back.  No torch types, no exceptions
+//     small batches:  rp_eval_kernel<.., LON_FUSED> -> rp_finalize_kernel
+//     large batches:  rp_lon_kernel -> rp_eval_kernel -> [rp_fold_partials_kernel] -> rp_finalize_kernel
+//                     -> [rp_count_before_kernel] -> [rp_eval_kernel<single winner>]
+// on the context's stream; the result block arrives in pinned host memory straight from the kernels.  No torch types, no exceptions
 // across the ABI, no CPU fallback: if HIP fails the call returns RP_EHIP.
 #include <hip/hip_runtime.h>
 
@@ -21,7 +23,7 @@
 
 namespace {
 
-constexpr int kBlocksPerCU = 4;           // persistent workgroups per CU for the evaluation kernel
+constexpr int kBlocksPerCU = 4;           // workgroups per CU of the grid-stride helper kernels (longitudinal profiles, counts)
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
 constexpr int kFoldThreshold = 2048;
 constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass

@@ -1409,49 +1409,6 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *s
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Final reduction of the block partials -> DevResult (one workgroup).  TrajectoryBundle.sort +
-// "first collision-free sample" (trajectories.py:502-510, reactive_planner.py:1031-1063) is the
-// lexicographic (cost, list index) minimum over feasible, collision-free candidates.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(RP_BLOCK) void rp_reduce_kernel(const BlockPartial *partials, int n_partials, int64_t count,
-                                                             rp_result *res) {
-    __shared__ double sh_cost[RP_BLOCK];
-    __shared__ int64_t sh_idx[RP_BLOCK];
-    __shared__ unsigned long long sh_cnt[10];
-    double bc = 0.0;
-    int64_t bi = -1;
-    unsigned long long c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int k = threadIdx.x; k < n_partials; k += RP_BLOCK) {
-        const BlockPartial p = partials[k];
-        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, bi)) { bc = p.best_cost; bi = p.best_index; }
-        c[0] += (unsigned long long)p.n_feasible;
-        c[1] += (unsigned long long)p.n_collision;
-        for (int r = 0; r < 8; ++r) c[2 + r] += (unsigned long long)p.reasons[r];
-    }
-    if (threadIdx.x < 10) sh_cnt[threadIdx.x] = 0;
-    sh_cost[threadIdx.x] = bc;
-    sh_idx[threadIdx.x] = bi;
-    __syncthreads();
-    for (int r = 0; r < 10; ++r)
-        if (c[r]) atomicAdd(&sh_cnt[r], c[r]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double fc = 0.0;
-        int64_t fi = -1;
-        for (int k = 0; k < RP_BLOCK; ++k)
-            if (sh_idx[k] >= 0 && better(sh_cost[k], sh_idx[k], fc, fi)) { fc = sh_cost[k]; fi = sh_idx[k]; }
-        res->best_index = fi;
-        res->best_cost = fi >= 0 ? fc : __builtin_nan("");
-        res->n_candidates = count;
-        res->n_feasible = (int64_t)sh_cnt[0];
-        res->n_collision = (int64_t)sh_cnt[1];
-        res->n_collision_before_best = 0;
-        for (int r = 0; r < 8; ++r) res->reason_counts[r] = (int64_t)sh_cnt[2 + r];
-        res->kernel_ms = 0.0;
-    }
-}
-
 // infeasible_count_collision: colliding feasible samples that precede the winner in cost order
 // (the lazy loop of reactive_planner.py:1031-1046 touches exactly those).  out += count.
 __global__ __launch_bounds__(RP_BLOCK) void rp_count_before_kernel(const uint32_t *status, const double *cost, int64_t count,
