@@ -545,15 +545,30 @@ class ReactivePlanner(GpuBackendMixin):
         th, v, a, ka = theta.tolist(), np.asarray(ca.v).tolist(), np.asarray(ca.a).tolist(), np.asarray(ca.kappa).tolist()
         yawl, steerl = yaw.tolist(), steer.tolist()
         yawl[0] = self.x_0.yaw_rate
-        cart_list = [ReactivePlannerState(t0 + factor * i, pos[i], th[i], v[i], steerl[i], a[i], yawl[i]) for i in range(n)]
-        cl_list = [CustomState(t0 + factor * i, sd[i], th[i], v[i], a[i], ka[i]) for i in range(n)]
+        # shift_orientation (utility/general.py:49-55) on the Cartesian trajectory only; the curvilinear states keep theta
+        lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
+        th_c = th
+        if np.any((theta < lo) | (theta > hi)):
+            th_c = list(th)
+            for i, o in enumerate(th_c):
+                while o < lo:
+                    o += 2 * np.pi
+                while o > hi:
+                    o -= 2 * np.pi
+                th_c[i] = o
+        # (states are filled through __dict__: 2 x (N+1) dataclass __init__ calls are a third of this function)
+        new_state, RS, CS = object.__new__, ReactivePlannerState, CustomState
+        cart_list, cl_list = [], []
+        for i in range(n):
+            ts = t0 + factor * i
+            st = new_state(RS)
+            st.__dict__ = {"time_step": ts, "position": pos[i], "orientation": th_c[i], "velocity": v[i],
+                           "steering_angle": steerl[i], "acceleration": a[i], "yaw_rate": yawl[i]}
+            cart_list.append(st)
+            sc = new_state(CS)
+            sc.__dict__ = {"time_step": ts, "position": sd[i], "orientation": th[i], "velocity": v[i], "acceleration": a[i],
+                           "yaw_rate": ka[i]}
+            cl_list.append(sc)
         lon_list = np.stack((cu.s, cu.s_dot, cu.s_ddot), axis=1).tolist()
         lat_list = np.stack((cu.d, cu.d_dot, cu.d_ddot), axis=1).tolist()
-        cart = Trajectory(self.x_0.time_step, cart_list)
-        lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
-        for st in cart.state_list:   # shift_orientation, utility/general.py:49-55
-            while st.orientation < lo:
-                st.orientation += 2 * np.pi
-            while st.orientation > hi:
-                st.orientation -= 2 * np.pi
-        return cart, Trajectory(self.x_0.time_step, cl_list), lon_list, lat_list
+        return Trajectory(self.x_0.time_step, cart_list), Trajectory(self.x_0.time_step, cl_list), lon_list, lat_list
