@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "rp_kernels.h"
@@ -79,9 +80,10 @@ struct rp_ctx {
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
+    std::unordered_map<const void *, hipFunction_t> functions;   // kernel symbol -> function handle (launch_kargs)
     // RP_AMD_TIMING=1: host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
     bool timing = false;
-    double t_sum[4] = {0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack
+    double t_sum[6] = {0, 0, 0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack | evaluation launch | epilogue launch
     unsigned long long t_calls = 0;
     std::chrono::steady_clock::time_point t_entry;
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
@@ -153,10 +155,30 @@ int ensure_stage(rp_ctx *c, size_t need) {
 
 constexpr size_t kStageOutLimit = 65536;   // LDS bytes per workgroup up to which state rows are staged for linear copy-out
 
+// Launch of a kernel whose only parameter is the KArgs block, through hipModuleLaunchKernel with the argument
+// buffer handed over as it is (no per-launch symbol look-up and argument marshalling of hipLaunchKernelGGL).
+void launch_kargs(rp_ctx *c, const void *kernel, int grid, int block, size_t lds, const KArgs &ka) {
+    hipFunction_t f = nullptr;
+    auto it = c->functions.find(kernel);
+    if (it == c->functions.end()) {
+        if (hipGetFuncBySymbol(&f, kernel) != hipSuccess || !f) f = nullptr;
+        c->functions.emplace(kernel, f);
+    } else {
+        f = it->second;
+    }
+    size_t bytes = sizeof(KArgs);
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<KArgs *>(&ka), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    if (!f || hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, c->stream, nullptr, extra) != hipSuccess) {
+        (void)hipGetLastError();
+        void *args[] = {const_cast<KArgs *>(&ka)};
+        (void)hipLaunchKernel(kernel, dim3(grid), dim3(block), args, lds, c->stream);   // error, if any, surfaces through hipGetLastError
+    }
+}
+
 template <int G, bool MAT, bool CIN, bool COLL, bool STAGE>
 void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
-    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE, false>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
-    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE, false>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE, false>, grid, RP_BLOCK, lds, ka);
+    else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE, false>, grid, RP_BLOCK, lds, ka);
 }
 
 // ---- single-launch variant (longitudinal profiles computed by each workgroup into LDS) ---------------------
@@ -185,8 +207,8 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
 template <bool MAT, bool CIN, bool COLL>
 void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
     constexpr int G = kFusedLonG;
-    if (ka.N + 1 <= G) hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, true, false, true>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
-    else hipLaunchKernelGGL((rp_eval_kernel<G, MAT, CIN, COLL, false, false, true>), dim3(grid), dim3(RP_BLOCK), lds, c->stream, ka);
+    if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
+    else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, false, true>, grid, RP_BLOCK, lds, ka);
 }
 
 template <bool MAT, bool CIN>
@@ -247,9 +269,9 @@ template <int G, bool CIN>
 void launch_lon_t(rp_ctx *c, const KArgs &ka, int grid) {
     const size_t tbytes = (size_t)ka.table_words * sizeof(double);
     if (tbytes <= kLdsTableLimit)
-        hipLaunchKernelGGL((rp_lon_kernel<G, CIN, true>), dim3(grid), dim3(RP_BLOCK), tbytes, c->stream, ka);
+        launch_kargs(c, (const void *)rp_lon_kernel<G, CIN, true>, grid, RP_BLOCK, tbytes, ka);
     else
-        hipLaunchKernelGGL((rp_lon_kernel<G, CIN, false>), dim3(grid), dim3(RP_BLOCK), 0, c->stream, ka);
+        launch_kargs(c, (const void *)rp_lon_kernel<G, CIN, false>, grid, RP_BLOCK, 0, ka);
 }
 
 // longitudinal profiles of the pairs [ka.pair_begin, ka.pair_begin + ka.pair_count)
@@ -371,8 +393,10 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) {
+            const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds);
             else launch_eval(c, ka, grid, mat, cin, G);
+            if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
         }
         if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
         if (count == 0) n_partials = 0;
@@ -392,8 +416,10 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             fin_in = folded;
             n_partials = kFoldPartials;
         }
+        const auto tf0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, fin_in, n_partials,
                            small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, fin_seq);
+        if (c->timing) c->t_sum[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count();
     }
     if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
         const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
@@ -518,8 +544,9 @@ int rp_create(rp_ctx **out, int device) {
 void rp_destroy(rp_ctx *c) {
     if (!c) return;
     if (c->timing && c->t_calls)
-        std::fprintf(stderr, "rp_plan host phases over %llu calls (us): entry->launch %.2f | launches %.2f | wait %.2f | unpack %.2f\n",
-                     c->t_calls, c->t_sum[0] / c->t_calls, c->t_sum[1] / c->t_calls, c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
+        std::fprintf(stderr, "rp_plan host phases over %llu calls (us): entry->launch %.2f | launches %.2f (evaluation %.2f, epilogue %.2f) | wait %.2f | unpack %.2f\n",
+                     c->t_calls, c->t_sum[0] / c->t_calls, c->t_sum[1] / c->t_calls, c->t_sum[4] / c->t_calls, c->t_sum[5] / c->t_calls,
+                     c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
