@@ -338,6 +338,53 @@ int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result
     return RP_OK;
 }
 
+// The winner's polynomial coefficients (sampling.py:253-270, polynomial_trajectory.py:292-360) from its index and the
+// grids staged by this call -- the closed forms of rp_device.h with plain divisions.
+void host_winner_coeffs(const rp_ctx *c, const KArgs &ka, bool cin, rp_result *r) {
+    const double nan = std::nan("");
+    for (int k = 0; k < 6; ++k) r->best_lon_coeffs[k] = r->best_lat_coeffs[k] = nan;
+    r->best_lat_T = nan;
+    const int64_t w = r->best_index;
+    if (w < 0) return;
+    if (cin) {
+        if ((size_t)(6 * w + 6) > c->last_lon.size()) return;
+        for (int k = 0; k < 6; ++k) { r->best_lon_coeffs[k] = c->last_lon[6 * w + k]; r->best_lat_coeffs[k] = c->last_lat[6 * w + k]; }
+        return;
+    }
+    const size_t need = sizeof(double) * ((size_t)ka.nT + ka.nL + ka.nD);
+    if (c->staged.size() < need || ka.nL <= 0 || ka.nD <= 0) return;
+    const double *T_ = reinterpret_cast<const double *>(c->staged.data()), *L_ = T_ + ka.nT, *D_ = L_ + ka.nL;
+    const int64_t nLD = (int64_t)ka.nL * ka.nD;
+    const int iT = (int)(w / nLD), rem = (int)(w - (int64_t)iT * nLD), iL = rem / ka.nD, iD = rem - iL * ka.nD;
+    if (iT >= ka.nT) return;
+    auto quintic = [](double p0, double v0, double a0, double pf, double T, double *o) {
+        const double T2 = T * T, bp = pf - (p0 + v0 * T + 0.5 * a0 * T2), bv = -(v0 + a0 * T), ba = -a0;
+        const double Tbv = T * bv, T2ba = T2 * ba, T3 = T2 * T;
+        o[0] = p0; o[1] = v0; o[2] = 0.5 * a0;
+        o[3] = (20.0 * bp - 8.0 * Tbv + T2ba) / (2.0 * T3);
+        o[4] = (-30.0 * bp + 14.0 * Tbv - 2.0 * T2ba) / (2.0 * T3 * T);
+        o[5] = (12.0 * bp - 6.0 * Tbv + T2ba) / (2.0 * T3 * T2);
+    };
+    const double T = T_[iT];
+    double *lon = r->best_lon_coeffs;
+    if (ka.lon_mode == RP_LON_STOPPING) {
+        quintic(ka.x0_lon[0], ka.x0_lon[1], ka.x0_lon[2], L_[iL], T, lon);
+    } else {   // quartic to (v_d, 0)
+        const double bv = L_[iL] - ka.x0_lon[1] - ka.x0_lon[2] * T, ba = -ka.x0_lon[2];
+        lon[0] = ka.x0_lon[0]; lon[1] = ka.x0_lon[1]; lon[2] = 0.5 * ka.x0_lon[2];
+        lon[3] = (3.0 * bv - T * ba) / (3.0 * T * T);
+        lon[4] = (T * ba - 2.0 * bv) / (4.0 * T * T * T);
+        lon[5] = 0.0;
+    }
+    double lat_T = T;
+    if (ka.low_vel_mode) {
+        const double sg = ((((lon[5] * T + lon[4]) * T + lon[3]) * T + lon[2]) * T + lon[1]) * T + lon[0] - ka.x0_lon[0];
+        lat_T = sg <= 0.0 ? T : sg;
+    }
+    quintic(ka.x0_lat[0], ka.x0_lat[1], ka.x0_lat[2], D_[iD], lat_T, r->best_lat_coeffs);
+    r->best_lat_T = lat_T;
+}
+
 // eval -> finalize (-> count for huge batches) (-> winner re-evaluation when nothing was materialised).
 // The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
 int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
@@ -461,6 +508,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
     *result = hrb->r;
     result->n_collision_before_best = (int64_t)hrb->n_before;
+    host_winner_coeffs(c, ka, cin, result);
     if (result->best_index >= 0 && best_states)
         std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
 #ifdef RP_STAMPS

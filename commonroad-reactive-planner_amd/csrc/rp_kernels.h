@@ -288,37 +288,9 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
         o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
         for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
         o.seq = 0;
-        if (widx >= 0) {
-            // the winner's polynomials, recomputed with the evaluation kernel's own formulas
-            Poly lon, lat;
-            double lat_T = 0.0;
-            if (a.lon_coeffs) {
-                const double *pl = a.lon_coeffs + 6 * widx, *pt = a.lat_coeffs + 6 * widx;
-                lon = {pl[0], pl[1], pl[2], pl[3], pl[4], pl[5]};
-                lat = {pt[0], pt[1], pt[2], pt[3], pt[4], pt[5]};
-            } else {
-                const int64_t nLD = (int64_t)a.nL * a.nD;
-                const int iT = (int)(widx / nLD);
-                const int rem = (int)(widx - (int64_t)iT * nLD);
-                const int iL = rem / a.nD, iD = rem - iL * a.nD;
-                const double T = a.T[iT];
-                if (a.lon_mode == RP_LON_STOPPING) lon = quintic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], a.L[iL], 0.0, 0.0, T);
-                else lon = quartic_coeffs(a.x0_lon[0], a.x0_lon[1], a.x0_lon[2], T, a.L[iL]);
-                lat_T = T;
-                if (a.low_vel_mode) {
-                    const double sg = lon.pos(T) - a.x0_lon[0];
-                    lat_T = sg <= 0.0 ? T : sg;
-                }
-                lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], a.D[iD], 0.0, 0.0, lat_T);
-            }
-            o.w_coeffs[0] = lon.c0; o.w_coeffs[1] = lon.c1; o.w_coeffs[2] = lon.c2; o.w_coeffs[3] = lon.c3;
-            o.w_coeffs[4] = lon.c4; o.w_coeffs[5] = lon.c5;
-            o.w_coeffs[6] = lat.c0; o.w_coeffs[7] = lat.c1; o.w_coeffs[8] = lat.c2; o.w_coeffs[9] = lat.c3;
-            o.w_coeffs[10] = lat.c4; o.w_coeffs[11] = lat.c5; o.w_coeffs[12] = lat_T;
-            for (int k = 0; k < 6; ++k) { o.r.best_lon_coeffs[k] = o.w_coeffs[k]; o.r.best_lat_coeffs[k] = o.w_coeffs[6 + k]; }
-            o.r.best_lat_T = a.lon_coeffs ? __builtin_nan("") : lat_T;
-            o.w_status = a.status[widx - a.cand_begin];
-        }
+        // (the winner's polynomial coefficients are filled in by the host from best_index and the grids it staged:
+        //  computing them here cost a dependent round trip for T, L, D plus ~60 serial FP64 instructions)
+        if (widx >= 0) o.w_status = RP_LABEL_FEASIBLE;
     }
     __syncthreads();
     {   // result header: cooperative copy (8-byte words), everything except the ticket
