@@ -194,14 +194,32 @@ struct FinalizeOut {          // layout shared with the host (rp_host.hip: Resul
     // followed by best_states[14][n]
 };
 
-// lexicographic (cost, index) minimum over a wavefront, result in every lane
+// lexicographic (cost, index) minimum over a wavefront, result in every lane.  DPP row shifts / broadcasts (plain
+// VALU) instead of a ds_bpermute butterfly: 24 LDS-crossbar round trips in series were ~3 000 cycles.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void min_pair_step(double &c, long long &i) {
+    int cl = __double2loint(c), ch = __double2hiint(c);
+    int il = (int)(unsigned int)((unsigned long long)i & 0xffffffffull), ih = (int)(unsigned int)((unsigned long long)i >> 32);
+    const int ocl = __builtin_amdgcn_update_dpp(cl, cl, CTRL, ROW_MASK, 0xf, false);   // lanes without a source keep their own
+    const int och = __builtin_amdgcn_update_dpp(ch, ch, CTRL, ROW_MASK, 0xf, false);
+    const int oil = __builtin_amdgcn_update_dpp(il, il, CTRL, ROW_MASK, 0xf, false);
+    const int oih = __builtin_amdgcn_update_dpp(ih, ih, CTRL, ROW_MASK, 0xf, false);
+    const double oc = __hiloint2double(och, ocl);
+    const long long oi = (long long)(((unsigned long long)(unsigned int)oih << 32) | (unsigned long long)(unsigned int)oil);
+    if (oi >= 0 && better(oc, (int64_t)oi, c, (int64_t)i)) { c = oc; i = oi; }
+}
 __device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double oc = __shfl_xor(c, o, 64);
-        const long long oi = __shfl_xor(i, o, 64);
-        if (oi >= 0 && better(oc, (int64_t)oi, c, (int64_t)i)) { c = oc; i = oi; }
-    }
+    min_pair_step<DPP_ROW_SHR1, 0xf>(c, i);
+    min_pair_step<DPP_ROW_SHR2, 0xf>(c, i);
+    min_pair_step<DPP_ROW_SHR4, 0xf>(c, i);
+    min_pair_step<DPP_ROW_SHR8, 0xf>(c, i);        // lane 15 of every row: minimum of the row
+    min_pair_step<DPP_ROW_BCAST15, 0xa>(c, i);     // rows 1, 3 also see row 0, 2
+    min_pair_step<DPP_ROW_BCAST31, 0xc>(c, i);     // rows 2, 3 also see rows 0 + 1: lane 63 holds the wavefront's minimum
+    const int cl = __builtin_amdgcn_readlane(__double2loint(c), 63), ch = __builtin_amdgcn_readlane(__double2hiint(c), 63);
+    const unsigned int il = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)i & 0xffffffffull), 63);
+    const unsigned int ih = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)i >> 32), 63);
+    c = __hiloint2double(ch, cl);
+    i = (long long)(((unsigned long long)ih << 32) | il);
 }
 
 // Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).
@@ -227,12 +245,19 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
         for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned long long)p.reasons[r];
     }
     wave_min_pair(bc, bi);
-    // counters: wavefront sums through DPP (exact in double: counts are far below 2^53), one LDS add per wave
+    // counters: wavefront sums through 32-bit DPP adds (a thread holds at most a few partials of at most 2^23
+    // candidates each: the sum over 64 lanes stays below 2^32), one LDS word per wave and counter
     __shared__ double sh_wcnt[RP_FIN_THREADS / 64][10];
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const double t = group_sum_last<64>((double)cnt[r]);
-        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = t;
+        unsigned int t = (unsigned int)cnt[r];
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);      // lane 15 of every row: row total
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);   // rows 1, 3 += row 0, 2
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);   // lane 63: wavefront total
+        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = (double)t;
     }
     if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
     __syncthreads();
