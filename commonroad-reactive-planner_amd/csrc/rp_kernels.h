@@ -16,6 +16,9 @@
 #include "rp_device.h"
 
 #define RP_BLOCK 256  // 4 wavefronts per workgroup
+#ifndef RP_WRITE_THROUGH
+#define RP_WRITE_THROUGH 1   // single-launch variant: agent-scope write-through stores of the state rows (see st_row)
+#endif
 #ifndef RP_WAVES_PER_SIMD
 #define RP_WAVES_PER_SIMD 3  // register budget of the evaluation kernel: 512 / 3 -> 168 VGPRs.  One wavefront issues
                              // an instruction only every ~10-13 cycles (profiles/r01_instruction_costs.txt), so the
@@ -706,6 +709,17 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
     }
 }
 
+// Store of one state-row element.  WT (single-launch variant): agent-scope write-through store.  The rows of a small
+// batch then do not sit dirty in the L2s until the end-of-kernel write-back: measured 23.2 -> 21.8 us on cfg2
+// (profiles/r01_dead_ends.txt also records what did NOT pay: running the selection epilogue in the last workgroup on
+// top of such stores).
+template <bool WT>
+__device__ __forceinline__ void st_row(double *p, double v) {
+    if (WT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // one step of a longitudinal profile in registers
 struct ProfStep { double f[PF_FIELDS]; };
 
@@ -784,6 +798,7 @@ template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
+    constexpr bool RP_WT = LON_FUSED && RP_WRITE_THROUGH;
     touch_kernargs<10>();
     const int tid = threadIdx.x;
     RP_STAMP(0);
@@ -1057,12 +1072,12 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (fabs(dd) < RP_EPS) dd = 0.0;
                 if (store_ok && act) {   // curvilinear rows of valid steps are final here
                     double *o = orow + i;
-                    o[(size_t)RP_S * n] = s;
-                    o[(size_t)RP_S_DOT * n] = sd;
-                    o[(size_t)RP_S_DDOT * n] = sdd;
-                    o[(size_t)RP_D * n] = d;
-                    o[(size_t)RP_D_DOT * n] = dd;
-                    o[(size_t)RP_D_DDOT * n] = ddd;
+                    st_row<RP_WT>(&o[(size_t)RP_S * n], s);
+                    st_row<RP_WT>(&o[(size_t)RP_S_DOT * n], sd);
+                    st_row<RP_WT>(&o[(size_t)RP_S_DDOT * n], sdd);
+                    st_row<RP_WT>(&o[(size_t)RP_D * n], d);
+                    st_row<RP_WT>(&o[(size_t)RP_D_DOT * n], dd);
+                    st_row<RP_WT>(&o[(size_t)RP_D_DDOT * n], ddd);
                 }
                 RP_STAMP(3);   // profile loads + polynomial evaluation
 
@@ -1158,14 +1173,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (act) {   // Cartesian rows of valid steps are final here
                     if (store_ok) {
                         double *o = orow + i;
-                        o[(size_t)RP_X * n] = x;
-                        o[(size_t)RP_Y * n] = y;
-                        o[(size_t)RP_THETA * n] = th_gl;
-                        o[(size_t)RP_V * n] = v;
-                        o[(size_t)RP_A * n] = acc;
-                        o[(size_t)RP_KAPPA * n] = kappa;
-                        o[(size_t)RP_KAPPA_DOT * n] = kdot;
-                        o[(size_t)RP_THETA_CL * n] = th_cl;
+                        st_row<RP_WT>(&o[(size_t)RP_X * n], x);
+                        st_row<RP_WT>(&o[(size_t)RP_Y * n], y);
+                        st_row<RP_WT>(&o[(size_t)RP_THETA * n], th_gl);
+                        st_row<RP_WT>(&o[(size_t)RP_V * n], v);
+                        st_row<RP_WT>(&o[(size_t)RP_A * n], acc);
+                        st_row<RP_WT>(&o[(size_t)RP_KAPPA * n], kappa);
+                        st_row<RP_WT>(&o[(size_t)RP_KAPPA_DOT * n], kdot);
+                        st_row<RP_WT>(&o[(size_t)RP_THETA_CL * n], th_cl);
                     }
                     cost_acc += cost_terms(i, acc, v, s, d, th_cl);
                 }
@@ -1212,20 +1227,20 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         if (live) {
                             if (store_ok) {
                                 double *w = orow + i;
-                                w[(size_t)RP_X * n] = x;
-                                w[(size_t)RP_Y * n] = y;
-                                w[(size_t)RP_THETA * n] = th_gl;
-                                w[(size_t)RP_V * n] = vt;
-                                w[(size_t)RP_A * n] = o[4];            // :179
-                                w[(size_t)RP_KAPPA * n] = o[5];        // :190
-                                w[(size_t)RP_KAPPA_DOT * n] = o[6];    // :192
-                                w[(size_t)RP_S * n] = e_s;
-                                w[(size_t)RP_D * n] = e_d;
-                                w[(size_t)RP_THETA_CL * n] = o[9];     // :327
-                                w[(size_t)RP_S_DOT * n] = e_sd;
-                                w[(size_t)RP_S_DDOT * n] = o[11];      // :323
-                                w[(size_t)RP_D_DOT * n] = e_dd;
-                                w[(size_t)RP_D_DDOT * n] = o[13];      // :324
+                                st_row<RP_WT>(&w[(size_t)RP_X * n], x);
+                                st_row<RP_WT>(&w[(size_t)RP_Y * n], y);
+                                st_row<RP_WT>(&w[(size_t)RP_THETA * n], th_gl);
+                                st_row<RP_WT>(&w[(size_t)RP_V * n], vt);
+                                st_row<RP_WT>(&w[(size_t)RP_A * n], o[4]);            // :179
+                                st_row<RP_WT>(&w[(size_t)RP_KAPPA * n], o[5]);        // :190
+                                st_row<RP_WT>(&w[(size_t)RP_KAPPA_DOT * n], o[6]);    // :192
+                                st_row<RP_WT>(&w[(size_t)RP_S * n], e_s);
+                                st_row<RP_WT>(&w[(size_t)RP_D * n], e_d);
+                                st_row<RP_WT>(&w[(size_t)RP_THETA_CL * n], o[9]);     // :327
+                                st_row<RP_WT>(&w[(size_t)RP_S_DOT * n], e_sd);
+                                st_row<RP_WT>(&w[(size_t)RP_S_DDOT * n], o[11]);      // :323
+                                st_row<RP_WT>(&w[(size_t)RP_D_DOT * n], e_dd);
+                                st_row<RP_WT>(&w[(size_t)RP_D_DDOT * n], o[13]);      // :324
                             }
                             cost_acc += cost_terms(i, o[4], vt, e_s, e_d, o[9]);
                         }
