@@ -66,6 +66,7 @@ class RpResult(C.Structure):
                 ("best_lat_coeffs", C.c_double * 6), ("best_lat_T", C.c_double), ("kernel_ms", C.c_double)]
 
 
+assert C.sizeof(RpResult) == 28 * 8
 _DP = C.POINTER(C.c_double)
 
 
@@ -123,10 +124,12 @@ class PlanOutput:
 
     @classmethod
     def from_c(cls, r: RpResult, best_states):
-        return cls(int(r.best_index), float(r.best_cost), int(r.n_candidates), int(r.n_feasible),
-                   int(r.n_collision_before_best), int(r.n_collision), np.array(r.reason_counts[:], dtype=np.int64),
-                   np.array(r.best_lon_coeffs[:]), np.array(r.best_lat_coeffs[:]), float(r.best_lat_T),
-                   float(r.kernel_ms), best_states if r.best_index >= 0 else None)
+        # one copy of the 28 eight-byte words of rp_result, read as doubles and as integers
+        f = np.frombuffer(r, dtype=np.float64, count=28).copy()
+        i = f.view(np.int64)
+        bi = int(i[0])
+        return cls(bi, float(f[1]), int(i[2]), int(i[3]), int(i[4]), int(i[5]), i[6:14], f[14:20], f[20:26], float(f[26]),
+                   float(f[27]), best_states if bi >= 0 else None)
 
     @property
     def n_infeasible_kinematics(self) -> int:
