@@ -1053,9 +1053,17 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             double kappa_carry = 0.0;
             double cumx = 0.0, cumy = 0.0;
             const bool store_ok = MAT && valid && pre_reason == RP_REASON_NONE;
-            double *const orow = !MAT ? nullptr
-                                 : (STAGE_OUT ? lds_out + (size_t)grp * RP_N_ARRAYS * (size_t)n
-                                              : a.states + ((size_t)slot * RP_N_ARRAYS) * (size_t)n);
+            // Row addresses: a wave-uniform base (the first candidate of this wavefront) plus a 32-bit byte offset per
+            // lane; each row then costs one 32-bit add with a scalar operand (row * n * 8) instead of a 64-bit
+            // address per (lane, row) formed from 14 hoisted -- and spilled -- row pointers.
+            char *const obase = !MAT ? nullptr
+                                : (STAGE_OUT ? reinterpret_cast<char *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n)
+                                             : reinterpret_cast<char *>(a.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n));
+            const uint32_t n8 = (uint32_t)n * 8u;
+            const uint32_t lane_off8 = (uint32_t)group_in_wave * RP_N_ARRAYS * n8;   // this group's candidate inside the wavefront
+            auto row_at = [&](uint32_t off8, int row) -> double * {
+                return reinterpret_cast<double *>(obase + (size_t)(off8 + (uint32_t)row * n8));
+            };
 
 #pragma nounroll
             for (int c = 0; c < nchunks; ++c) {   // wave-uniform
@@ -1078,13 +1086,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 double d = poly_pos(gs_poly, tau), dd = poly_vel(gs_poly, tau), ddd = poly_acc(gs_poly, tau);
                 if (fabs(dd) < RP_EPS) dd = 0.0;
                 if (store_ok && act) {   // curvilinear rows of valid steps are final here
-                    double *o = orow + i;
-                    st_row<RP_WT>(&o[(size_t)RP_S * n], s);
-                    st_row<RP_WT>(&o[(size_t)RP_S_DOT * n], sd);
-                    st_row<RP_WT>(&o[(size_t)RP_S_DDOT * n], sdd);
-                    st_row<RP_WT>(&o[(size_t)RP_D * n], d);
-                    st_row<RP_WT>(&o[(size_t)RP_D_DOT * n], dd);
-                    st_row<RP_WT>(&o[(size_t)RP_D_DDOT * n], ddd);
+                    const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                    st_row<RP_WT>(row_at(off8, RP_S), s);
+                    st_row<RP_WT>(row_at(off8, RP_S_DOT), sd);
+                    st_row<RP_WT>(row_at(off8, RP_S_DDOT), sdd);
+                    st_row<RP_WT>(row_at(off8, RP_D), d);
+                    st_row<RP_WT>(row_at(off8, RP_D_DOT), dd);
+                    st_row<RP_WT>(row_at(off8, RP_D_DDOT), ddd);
                 }
                 RP_STAMP(3);   // profile loads + polynomial evaluation
 
@@ -1179,15 +1187,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 }
                 if (act) {   // Cartesian rows of valid steps are final here
                     if (store_ok) {
-                        double *o = orow + i;
-                        st_row<RP_WT>(&o[(size_t)RP_X * n], x);
-                        st_row<RP_WT>(&o[(size_t)RP_Y * n], y);
-                        st_row<RP_WT>(&o[(size_t)RP_THETA * n], th_gl);
-                        st_row<RP_WT>(&o[(size_t)RP_V * n], v);
-                        st_row<RP_WT>(&o[(size_t)RP_A * n], acc);
-                        st_row<RP_WT>(&o[(size_t)RP_KAPPA * n], kappa);
-                        st_row<RP_WT>(&o[(size_t)RP_KAPPA_DOT * n], kdot);
-                        st_row<RP_WT>(&o[(size_t)RP_THETA_CL * n], th_cl);
+                        const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                        st_row<RP_WT>(row_at(off8, RP_X), x);
+                        st_row<RP_WT>(row_at(off8, RP_Y), y);
+                        st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
+                        st_row<RP_WT>(row_at(off8, RP_V), v);
+                        st_row<RP_WT>(row_at(off8, RP_A), acc);
+                        st_row<RP_WT>(row_at(off8, RP_KAPPA), kappa);
+                        st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), kdot);
+                        st_row<RP_WT>(row_at(off8, RP_THETA_CL), th_cl);
                     }
                     cost_acc += cost_terms(i, acc, v, s, d, th_cl);
                 }
@@ -1233,21 +1241,21 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         const double e_d = o[8] + tk * o[12];          // :331
                         if (live) {
                             if (store_ok) {
-                                double *w = orow + i;
-                                st_row<RP_WT>(&w[(size_t)RP_X * n], x);
-                                st_row<RP_WT>(&w[(size_t)RP_Y * n], y);
-                                st_row<RP_WT>(&w[(size_t)RP_THETA * n], th_gl);
-                                st_row<RP_WT>(&w[(size_t)RP_V * n], vt);
-                                st_row<RP_WT>(&w[(size_t)RP_A * n], o[4]);            // :179
-                                st_row<RP_WT>(&w[(size_t)RP_KAPPA * n], o[5]);        // :190
-                                st_row<RP_WT>(&w[(size_t)RP_KAPPA_DOT * n], o[6]);    // :192
-                                st_row<RP_WT>(&w[(size_t)RP_S * n], e_s);
-                                st_row<RP_WT>(&w[(size_t)RP_D * n], e_d);
-                                st_row<RP_WT>(&w[(size_t)RP_THETA_CL * n], o[9]);     // :327
-                                st_row<RP_WT>(&w[(size_t)RP_S_DOT * n], e_sd);
-                                st_row<RP_WT>(&w[(size_t)RP_S_DDOT * n], o[11]);      // :323
-                                st_row<RP_WT>(&w[(size_t)RP_D_DOT * n], e_dd);
-                                st_row<RP_WT>(&w[(size_t)RP_D_DDOT * n], o[13]);      // :324
+                                const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                                st_row<RP_WT>(row_at(off8, RP_X), x);
+                                st_row<RP_WT>(row_at(off8, RP_Y), y);
+                                st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
+                                st_row<RP_WT>(row_at(off8, RP_V), vt);
+                                st_row<RP_WT>(row_at(off8, RP_A), o[4]);            // :179
+                                st_row<RP_WT>(row_at(off8, RP_KAPPA), o[5]);        // :190
+                                st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), o[6]);    // :192
+                                st_row<RP_WT>(row_at(off8, RP_S), e_s);
+                                st_row<RP_WT>(row_at(off8, RP_D), e_d);
+                                st_row<RP_WT>(row_at(off8, RP_THETA_CL), o[9]);     // :327
+                                st_row<RP_WT>(row_at(off8, RP_S_DOT), e_sd);
+                                st_row<RP_WT>(row_at(off8, RP_S_DDOT), o[11]);      // :323
+                                st_row<RP_WT>(row_at(off8, RP_D_DOT), e_dd);
+                                st_row<RP_WT>(row_at(off8, RP_D_DDOT), o[13]);      // :324
                             }
                             cost_acc += cost_terms(i, o[4], vt, e_s, e_d, o[9]);
                         }
