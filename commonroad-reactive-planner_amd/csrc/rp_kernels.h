@@ -730,11 +730,11 @@ __device__ __forceinline__ void st_row(double *p, double v) {
 // one step of a longitudinal profile in registers
 struct ProfStep { double f[PF_FIELDS]; };
 
-__device__ __forceinline__ ProfStep load_profile(const double *prow, int n, int il) {
-    const double *pr = prow + il;
+// rows of one profile step: wave-uniform base + 32-bit byte offset per lane (one scalar-operand add per row)
+__device__ __forceinline__ ProfStep load_profile(const char *base, uint32_t off8, uint32_t n8) {
     ProfStep p;
 #pragma unroll
-    for (int k = 0; k < PF_FIELDS; ++k) p.f[k] = pr[(size_t)k * n];
+    for (int k = 0; k < PF_FIELDS; ++k) p.f[k] = *reinterpret_cast<const double *>(base + (size_t)(off8 + (uint32_t)k * n8));
     return p;
 }
 
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         //    this lane's candidate input, the grid values of its first item, the table block
         {
             const int64_t slot0 = wave_first + group_in_wave;
-            const int64_t g0 = a.single_index ? g_first : a.cand_begin + (slot0 < count ? slot0 : s_first);
+            const int64_t g0 = a.single_index ? g_first : a.cand_begin + (slot0 < count ? slot0 : (wave_first < count ? wave_first : s_first));
             fetch_lateral<COEFFS_IN>(a, g0, cin, p_first);
         }
         int j = tid;
@@ -968,15 +968,19 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             cin.L = h.L;
             cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
                              : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
-            pf0 = load_profile(lds_prof + ((size_t)cin.pair_slot * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+            pf0 = load_profile(reinterpret_cast<const char *>(lds_prof), (uint32_t)cin.pair_slot * PF_FIELDS * (uint32_t)n0 * 8u + (uint32_t)(gl <= a.N ? gl : a.N) * 8u,
+                               (uint32_t)n0 * 8u);
         }
     } else {
+        // (lanes without a candidate shadow the first candidate of their wavefront: its profile rows exist and are close)
         const int64_t slot0 = wave_first + group_in_wave;
-        const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : 0);
+        const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : (wave_first < count ? wave_first : 0));
         cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
-        const int64_t ps0 = (COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0;
-        const int n0 = a.N + 1;
-        pf0 = load_profile(prof_base + ((size_t)ps0 * PF_FIELDS) * (size_t)n0, n0, gl <= a.N ? gl : a.N);
+        const int32_t ps0 = (int32_t)((COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0);
+        const int32_t pw0 = __builtin_amdgcn_readfirstlane(ps0);   // pair of the wavefront's first candidate (wave-uniform)
+        const uint32_t n80 = (uint32_t)(a.N + 1) * 8u;
+        pf0 = load_profile(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
+                           (uint32_t)(ps0 - pw0) * PF_FIELDS * n80 + (uint32_t)(gl <= a.N ? gl : a.N) * 8u, n80);
     }
 
     if (!LON_FUSED) {
@@ -1021,17 +1025,19 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int64_t w0 = wave_first;
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
         const bool valid = slot < count;
-        // (lanes without a candidate shadow one whose profile rows exist: slot 0, or the workgroup's first)
-        const int64_t gidx = a.single_index ? *a.single_index
-                                            : a.cand_begin + (valid ? slot : (LON_FUSED ? (int64_t)blockIdx.x * GPB : (int64_t)0));
+        // (lanes without a candidate shadow the first candidate of their wavefront, whose profile rows exist)
+        const int64_t gidx = a.single_index ? *a.single_index : a.cand_begin + (valid ? slot : w0);
 
         // ---- lateral polynomial: sampling.py:226-238, 268-270
         const int L = cin.L;
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
-        const int64_t pair_slot_ = (COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - pair0;
-        const double *const prow = prof_base + ((size_t)pair_slot_ * PF_FIELDS) * (size_t)n;
+        const int32_t pair_slot_ = (int32_t)((COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - pair0);
+        const int32_t pair_w = __builtin_amdgcn_readfirstlane(pair_slot_);   // wavefront's first candidate: wave-uniform base
+        const uint32_t n8p = (uint32_t)n * 8u;
+        const char *const pbase = reinterpret_cast<const char *>(prof_base + ((size_t)pair_w * PF_FIELDS) * (size_t)n);
+        const uint32_t poff8 = (uint32_t)(pair_slot_ - pair_w) * PF_FIELDS * n8p;
         ProfStep pf = pf0;
         {
             Poly lat;
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const bool act = i < L;
 
                 // -- this step of the pair's longitudinal profile (coalesced: lanes = consecutive steps)
-                if (!ONE_CHUNK && c > 0) pf = load_profile(prow, n, live ? i : N);   // dead lanes clamp into the rows
+                if (!ONE_CHUNK && c > 0) pf = load_profile(pbase, poff8 + (uint32_t)(live ? i : N) * 8u, n8p);   // dead lanes clamp into the rows
                 double s = pf.f[PF_S], sd = pf.f[PF_SD], sdd = pf.f[PF_SDD];
                 const double inv_sd = pf.f[PF_INV_SD], th_ref = pf.f[PF_TH_REF];
                 const double k_r = pf.f[PF_KR], k_r_d = pf.f[PF_KRD];
