@@ -444,3 +444,25 @@ def test_collision_mask_edge_paths(ctx, kind):
         assert out.n_collision == orun.out.n_collision and out.best_index == orun.out.best_index
         assert out.n_collision_before_best == orun.out.n_collision_before_best
     assert orun.out.n_collision > 0
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
+def test_full_size_workloads(ctx, name):
+    """BASELINE.json's cfg3 / cfg4 at full size (62 496 and 512 064 candidates): every label, first-failure reason and
+    cost, the counters and the winner against the oracle (OpenMP over candidates); profiles/full_scale_parity.py does
+    the same for all workloads including cfg5 with 50 obstacles."""
+    from oracle import oracle
+    from commonroad_rp_amd import workloads as W
+    w = W.WORKLOADS[name]()
+    w.setup(ctx)
+    tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+    orun = oracle.plan(w.inputs, tb, want_states=False, nthreads=8)
+    out = ctx.plan(w.inputs)
+    status, cost = ctx.fetch_status()
+    _compare_status(status, cost, orun)
+    assert out.best_index == orun.out.best_index and out.n_feasible == orun.out.n_feasible
+    assert out.n_collision == orun.out.n_collision and out.n_collision_before_best == orun.out.n_collision_before_best
+    np.testing.assert_array_equal(out.reason_counts[1:7], orun.out.reason_counts[1:7])
+    if out.best_index >= 0:   # the winner's states, re-evaluated by the oracle
+        one = oracle.plan(w.inputs, tb, out.best_index, out.best_index + 1)
+        np.testing.assert_allclose(out.best_states, one.states[0], rtol=0, atol=STATE_ATOL)
