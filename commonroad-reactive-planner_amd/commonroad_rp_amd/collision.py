@@ -165,14 +165,14 @@ def _points_in_polygon(pts: np.ndarray, poly: np.ndarray) -> np.ndarray:
 
 
 def road_boundary_obb(lanelets: Iterable, thickness: float = 0.1, inside_margin: float = 0.05,
-                      merge_tol: float = 1e-6) -> np.ndarray:
+                      simplify_tol: float = 0.02) -> np.ndarray:
     """Rectangles ``(cx, cy, theta, half_length, half_width)`` along the outer border of a lanelet network.
 
     Candidate segments: the left border of every lanelet without a left neighbour, the right border of every
     lanelet without a right neighbour, and the start / end edge of lanelets without predecessor / successor.
     A segment is dropped when its midpoint, moved ``inside_margin`` to either side, lies inside some lanelet on
-    BOTH sides -- i.e. it runs through drivable area (overlapping lanelets of an intersection).  Connected
-    collinear segments (sine of the angle between them <= ``merge_tol``) are merged into one rectangle."""
+    BOTH sides -- i.e. it runs through drivable area (overlapping lanelets of an intersection).  Chains of
+    connected segments are simplified (Douglas-Peucker, ``simplify_tol`` metres; negative: keep every segment)."""
     lls = list(lanelets)
     polys = [np.concatenate((np.asarray(l.left_vertices, dtype=float), np.asarray(l.right_vertices, dtype=float)[::-1])) for l in lls]
     segs, owner = [], []
@@ -203,21 +203,43 @@ def road_boundary_obb(lanelets: Iterable, thickness: float = 0.1, inside_margin:
         inside_a |= _points_in_polygon(mid + inside_margin * nrm, poly)
         inside_b |= _points_in_polygon(mid - inside_margin * nrm, poly)
     keep = ~(inside_a & inside_b)
-    # merge runs of connected, collinear segments (straight borders are often given in 1 m pieces)
-    out = []
-    run_p = run_q = None
+    # chains of connected kept segments, each simplified (Douglas-Peucker): straight borders are often given in 1 m
+    # pieces, curved ones in centimetre pieces; no vertex of the original border ends up farther than simplify_tol
+    # from the simplified one (well inside the rectangles' thickness)
+    chains, cur = [], None
     for k in np.flatnonzero(keep):
         p, q = P[k], Q[k]
-        if run_p is not None and np.allclose(run_q, p, atol=1e-9):
-            u, v = run_q - run_p, q - p
-            if abs(u[0] * v[1] - u[1] * v[0]) <= merge_tol * np.hypot(*u) * np.hypot(*v) and u @ v > 0:
-                run_q = q
-                continue
-        if run_p is not None:
-            out.append((run_p, run_q))
-        run_p, run_q = p, q
-    if run_p is not None:
-        out.append((run_p, run_q))
+        if cur is not None and np.allclose(cur[-1], p, atol=1e-9):
+            cur.append(q)
+        else:
+            if cur is not None:
+                chains.append(np.array(cur))
+            cur = [p, q]
+    if cur is not None:
+        chains.append(np.array(cur))
+
+    def simplify(pts):
+        if len(pts) <= 2:
+            return pts
+        a, b = pts[0], pts[-1]
+        ab = b - a
+        L = np.hypot(*ab)
+        rel = pts[1:-1] - a
+        if L < 1e-12:
+            dist = np.hypot(rel[:, 0], rel[:, 1])
+        else:
+            t = np.clip((rel @ ab) / (L * L), 0.0, 1.0)
+            dist = np.hypot(*(rel - t[:, None] * ab).T)
+        j = int(np.argmax(dist))
+        if dist[j] <= simplify_tol:
+            return np.stack((a, b))
+        left, right = simplify(pts[:j + 2]), simplify(pts[j + 1:])
+        return np.concatenate((left[:-1], right))
+
+    out = []
+    for ch in chains:
+        sp = simplify(ch) if simplify_tol >= 0 else ch
+        out.extend(zip(sp[:-1], sp[1:]))
     P2 = np.array([o[0] for o in out]).reshape(-1, 2); Q2 = np.array([o[1] for o in out]).reshape(-1, 2)
     d2 = Q2 - P2
     return np.stack((0.5 * (P2[:, 0] + Q2[:, 0]), 0.5 * (P2[:, 1] + Q2[:, 1]), np.arctan2(d2[:, 1], d2[:, 0]),

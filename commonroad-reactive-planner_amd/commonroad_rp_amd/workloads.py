@@ -174,7 +174,7 @@ def cfg2(flags: int = 0, road_boundary: bool = False) -> Workload:
     return _scenario_workload("cfg2", "ZAM_Tjunction-1_42_T-1", N, T, 31, 15, low_vel_threshold=2.0, flags=flags,
                               road_boundary=road_boundary,
                               description="ZAM_Tjunction-1_42_T-1, 15(d)x15(T)x31(v) grid, N=30, 5 dynamic obstacles"
-                                          + (", road boundary (122 rectangles)" if road_boundary else ""))
+                                          + (", road boundary (85 rectangles)" if road_boundary else ""))
 
 
 def cfg3(flags: int = 0, road_boundary: bool = False) -> Workload:

@@ -354,7 +354,7 @@ def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
     from commonroad_rp_amd import workloads as W
     if name == "cfg5obs":
         w = W.cfg5(obstacles=50)
-    elif name.endswith("rb"):   # with the road boundary: 122 / 304 thin rectangles (collision.road_boundary_obb)
+    elif name.endswith("rb"):   # with the road boundary: 85 / 8 thin rectangles (collision.road_boundary_obb)
         w = getattr(W, name[:-2])(road_boundary=True)
     else:
         w = W.WORKLOADS[name]()

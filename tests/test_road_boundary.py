@@ -25,7 +25,7 @@ def test_two_adjacent_lanes_keep_only_the_outer_border():
     assert len(obb) == 6 and np.allclose(obb[:, 4], 0.1)
     assert not np.any(ys == 3.5)           # the shared border is drivable
     # without merging: one rectangle per polyline segment
-    assert len(road_boundary_obb([a, b], merge_tol=-1.0)) == 12
+    assert len(road_boundary_obb([a, b], simplify_tol=-1.0)) == 12
 
 
 def test_successor_and_predecessor_remove_end_caps():
@@ -45,7 +45,7 @@ def test_crossing_lanelets_drop_borders_inside_the_other_lanelet():
     inside = (np.abs(obb[:, 0]) < 1.7) & (np.abs(obb[:, 1]) < 1.7)
     assert not inside.any()
     # and the borders outside the crossing survive: 2 borders x (40 - 4 crossing segments) per lanelet + 4 caps
-    assert len(road_boundary_obb([a, b], merge_tol=-1.0)) == 2 * 2 * 36 + 4
+    assert len(road_boundary_obb([a, b], simplify_tol=-1.0)) == 2 * 2 * 36 + 4
     # merged: every border is cut into two runs by the crossing
     assert len(obb) == 2 * 2 * 2 + 4 and np.isclose(np.sum(2 * obb[:, 3]), 2 * 2 * 36 + 4 * 3.5)
 
@@ -57,7 +57,7 @@ def test_fixture_networks_and_tables():
     lls = lanelets_from_arrays(z["ll_ids"], z["ll_left"], z["ll_right"], z["ll_offsets"], z["ll_flags"])
     obb = road_boundary_obb(lls)
     assert len(lls) == 12 and 60 < len(obb) < 400 and np.all(obb[:, 3] > 0)
-    assert len(obb) <= len(road_boundary_obb(lls, merge_tol=-1.0))
+    assert len(obb) <= len(road_boundary_obb(lls, simplify_tol=-1.0))
 
     class _Net: lanelets = lls
     class _Sc: static_obstacles = []; dynamic_obstacles = []; lanelet_network = _Net()
