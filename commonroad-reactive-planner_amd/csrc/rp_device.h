@@ -337,15 +337,28 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         uint64_t mu = wave_or_u64(want ? near_static : 0);
         mu &= ob.n_clus >= 64 ? ~0ull : (1ull << ob.n_clus) - 1ull;
         const gcint info = (gcint)ob.clus_info;
-        while (mu != 0) {
-            const int c = __ffsll((unsigned long long)mu) - 1;
+        // The walk is a chain of scalar loads (cluster descriptor -> member rows -> test); the descriptor of the NEXT
+        // cluster is requested before the rows of the current one are waited for, and two member rows are in flight
+        // at a time, so that the round trips overlap instead of adding up.
+        int kind = 0, first = 0, count = 0;
+        if (mu != 0) {
+            const int c0 = __ffsll((unsigned long long)mu) - 1;
             mu &= mu - 1;
-            const int kind = info[4 * c], first = info[4 * c + 1], count = info[4 * c + 2];
+            kind = info[4 * c0]; first = info[4 * c0 + 1]; count = info[4 * c0 + 2];
+        }
+        while (count > 0) {
+            const bool more = mu != 0;
+            const int cn = more ? __ffsll((unsigned long long)mu) - 1 : 0;
+            if (more) mu &= mu - 1;
+            const int nkind = info[4 * cn], nfirst = info[4 * cn + 1], ncount = more ? info[4 * cn + 2] : 0;   // next descriptor
             if (kind == 0) {
-                for (int q = 0; q < count; ++q) {
-                    const gcdouble o = sobb + (size_t)(first + q) * OB_ROW;
-                    const Obb b = {o[OB_CX], o[OB_CY], o[OB_UX], o[OB_UY], o[OB_HL], o[OB_HW]};
-                    if (want && !obb_sep_on_b_axes(ego, b)) hit |= !obb_sep_on_a_axes(ego, b);   // strip's own axes first
+                for (int q = 0; q < count; q += 2) {
+                    const gcdouble o0 = sobb + (size_t)(first + q) * OB_ROW;
+                    const gcdouble o1 = sobb + (size_t)(first + (q + 1 < count ? q + 1 : q)) * OB_ROW;
+                    const Obb b0 = {o0[OB_CX], o0[OB_CY], o0[OB_UX], o0[OB_UY], o0[OB_HL], o0[OB_HW]};
+                    const Obb b1 = {o1[OB_CX], o1[OB_CY], o1[OB_UX], o1[OB_UY], o1[OB_HL], o1[OB_HW]};
+                    if (want && !obb_sep_on_b_axes(ego, b0)) hit |= !obb_sep_on_a_axes(ego, b0);   // strip's own axes first
+                    if (want && q + 1 < count && !obb_sep_on_b_axes(ego, b1)) hit |= !obb_sep_on_a_axes(ego, b1);
                 }
             } else if (kind == 1) {
                 for (int q = 0; q < count; ++q) {
@@ -362,6 +375,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
                     if (want) hit |= obb_circ(ego, o[0], o[1], o[2]);
                 }
             }
+            kind = nkind; first = nfirst; count = ncount;
         }
     } else {
     WaveBound wb = {0.0, 0.0, 0.0};
