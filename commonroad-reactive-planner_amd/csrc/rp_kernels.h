@@ -522,23 +522,6 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
 __device__ __forceinline__ double mask_as_double(uint64_t m) { return __longlong_as_double((long long)m); }
 __device__ __forceinline__ uint64_t double_as_mask(double d) { return (uint64_t)__double_as_longlong(d); }
 
-// dt * sum_{t=1..m} max(0, v + t dt a): distance covered by the extension after m steps (trajectories.py:182-196),
-// in closed form (the terms are an arithmetic progression clipped at zero); callers add a relative slack
-__device__ __forceinline__ double ext_travel(double v, double acc, int m, double dt) {
-    const double h = dt * acc;   // increment of the progression v + t h
-    double t0 = 1.0, t1 = (double)m;   // the range of t whose terms are positive
-    if (h < 0.0) {
-        if (!(v > 0.0)) return 0.0;
-        t1 = fmin(t1, floor(v / -h));             // v + t h >= 0  <=>  t <= v / -h
-    } else if (v < 0.0) {
-        if (!(h > 0.0)) return 0.0;
-        t0 = fmax(t0, floor(-v / h) + 1.0);       // v + t h > 0   <=>  t > -v / h
-    }
-    if (t1 < t0) return 0.0;
-    const double cnt = t1 - t0 + 1.0;
-    return dt * (cnt * v + h * 0.5 * (t0 + t1) * cnt);
-}
-
 // what pair_step_bound reads of the pair, of step i and of the last valid step L - 1
 struct BoundIn {
     int L;

@@ -90,3 +90,21 @@ __device__ __forceinline__ void rp_sincos(double x, double *s, double *c) {
     *s = (q & 2) ? -ss : ss;
     *c = ((q + 1) & 2) ? -cc : cc;
 }
+
+// dt * sum_{t=1..m} max(0, v + t dt a): distance covered by the extension after m steps (trajectories.py:182-196),
+// in closed form (the terms are an arithmetic progression clipped at zero); callers add a relative slack
+__device__ __forceinline__ double ext_travel(double v, double acc, int m, double dt) {
+    const double h = dt * acc;   // increment of the progression v + t h
+    double t0 = 1.0, t1 = (double)m;   // the range of t whose terms are positive
+    if (h < 0.0) {
+        if (!(v > 0.0)) return 0.0;
+        t1 = fmin(t1, floor(v / -h));             // v + t h >= 0  <=>  t <= v / -h
+    } else if (v < 0.0) {
+        if (!(h > 0.0)) return 0.0;
+        t0 = fmax(t0, floor(-v / h) + 1.0);       // v + t h > 0   <=>  t > -v / h
+    }
+    if (t1 < t0) return 0.0;
+    const double cnt = t1 - t0 + 1.0;
+    return dt * (cnt * v + h * 0.5 * (t0 + t1) * cnt);
+}
+

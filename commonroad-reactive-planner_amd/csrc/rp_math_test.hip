@@ -11,15 +11,19 @@ __global__ void k_math(int kind, int n, const double *in, double *out, double *o
     else if (kind == 1) rp_sincos(x, &a, &b);
     else if (kind == 2) a = rp_rcp(x);
     else if (kind == 3) a = rp_rsqrt(x);
+    else if (kind == 4) {   // ext_travel(v, a, m, dt) with in = [v | a | m | dt] packed in four planes of n
+        a = ext_travel(x, i < n ? in[n + i] : 0.0, i < n ? (int)in[2 * n + i] : 0, i < n ? in[3 * n + i] : 0.1);
+    }
     if (i < n) { out[i] = a; if (out2) out2[i] = b; }
 }
 
 extern "C" int rpt_math(int kind, int n, const double *in, double *out, double *out2) {
     double *d_in = nullptr, *d_out = nullptr, *d_out2 = nullptr;
-    if (hipMalloc((void **)&d_in, sizeof(double) * n) != hipSuccess) return -1;
+    const int planes = kind == 4 ? 4 : 1;
+    if (hipMalloc((void **)&d_in, sizeof(double) * n * planes) != hipSuccess) return -1;
     if (hipMalloc((void **)&d_out, sizeof(double) * n) != hipSuccess) return -1;
     if (hipMalloc((void **)&d_out2, sizeof(double) * n) != hipSuccess) return -1;
-    hipMemcpy(d_in, in, sizeof(double) * n, hipMemcpyHostToDevice);
+    hipMemcpy(d_in, in, sizeof(double) * n * planes, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_math, dim3((n + 255) / 256), dim3(256), 0, 0, kind, n, d_in, d_out, d_out2);
     hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost);
     if (out2) hipMemcpy(out2, d_out2, sizeof(double) * n, hipMemcpyDeviceToHost);

@@ -21,6 +21,16 @@ def _run(kind, x):
     return a, b
 
 
+def _run_n(kind, packed, n):
+    lib = C.CDLL(LIB)
+    dp = C.POINTER(C.c_double)
+    lib.rpt_math.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+    packed = np.ascontiguousarray(packed, dtype=np.float64)
+    a, b = np.empty(n), np.empty(n)
+    assert lib.rpt_math(kind, n, packed.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp)) == 0
+    return a, b
+
+
 def _ulp(got, ref):
     return np.abs(got - ref) / np.spacing(np.abs(ref))
 
@@ -60,3 +70,24 @@ def test_rcp_rsqrt():
     assert _ulp(r, -1.0 / x).max() <= 1.0
     q, _ = _run(3, x)
     assert _ulp(q, 1.0 / np.sqrt(x)).max() <= 2.0
+
+
+def test_extension_travel_closed_form():
+    """ext_travel (closed form of dt * sum_{t=1..m} max(0, v + t dt a), used by the bounds of the collision broad
+    phase) against the loop it replaces (CartesianSample.enlarge, trajectories.py:182-196)."""
+    rng = np.random.default_rng(5)
+    n = 200000
+    v = np.concatenate([rng.uniform(-3, 25, n // 2), rng.uniform(-0.01, 0.01, n // 4), np.zeros(n // 4)])
+    a = np.concatenate([rng.uniform(-12, 12, n // 2), rng.uniform(-1e-3, 1e-3, n // 4), rng.uniform(-12, 12, n // 8), np.zeros(n // 8)])
+    m = rng.integers(0, 130, n).astype(float)
+    dt = rng.choice([0.05, 0.1, 0.2], n)
+    packed = np.concatenate([v, a, m, dt])
+    got, _ = _run_n(4, packed, n)
+    ref = np.zeros(n)
+    for t in range(1, 130):
+        vt = v + (t * dt) * a
+        ref += np.where(t <= m, dt * np.maximum(vt, 0.0), 0.0)
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+    # monotone in (v, a): what pair_step_bound relies on when it evaluates the extremes of the pair
+    got2, _ = _run_n(4, np.concatenate([v + 0.3, a + 0.2, m, dt]), n)
+    assert np.all(got2 >= got - 1e-12)
