@@ -180,7 +180,7 @@ class GpuBackendMixin:
     # ---- the two overridden methods ----------------------------------------------------------------
     def _create_trajectory_bundle(self, x_0_lon, x_0_lat, samp_level: int) -> GpuTrajectoryBundle:
         logger.info("===== Sampling trajectories ... =====")
-        logger.info(f"Sampling density {samp_level + 1} of {self.sampling_level}")
+        logger.info("Sampling density %d of %d", samp_level + 1, self.sampling_level)   # (lazy formatting: hot path)
         sp = self.sampling_space
         if hasattr(sp, "grids_at_level"):
             grids = sp.grids_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode)
@@ -191,7 +191,7 @@ class GpuBackendMixin:
             if self.config.sampling.longitudinal_mode == "stopping":
                 samples = [t for t in samples if t.trajectory_long.x_0[0] < t.trajectory_long.x_d[0]]
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, samples=samples)
-        logger.info(f"Number of trajectory samples: {bundle.n_candidates}")
+        logger.info("Number of trajectory samples: %d", bundle.n_candidates)
         return bundle
 
     def _get_optimal_trajectory(self, bundle: GpuTrajectoryBundle) -> Optional[TrajectorySample]:
@@ -225,7 +225,7 @@ class GpuBackendMixin:
             lon_T = np.array([t.trajectory_long.delta_tau for t in samples], dtype=float)
             tl = np.array([len(np.arange(0, np.round(tt + self.dt, 5), self.dt)) for tt in lon_T], dtype=np.int32)
             out = ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl)
-        logger.info(f"Kinematic checks took:  \t{time.time() - t0:.7f}s")
+        logger.info("Kinematic checks took:  \t%.7fs", time.time() - t0)
 
         if external:   # plug-in CostFunction: states from the device, evaluate() in Python, argmin on the device
             out = self._gpu_external_costs(ctx, bundle, out)
