@@ -180,7 +180,9 @@ def run():
                    "candidates_per_gpu": C_loc, "horizon_steps": N,
                    "n_obstacles": int(w.obstacles.dyn_obb.shape[0] + len(w.obstacles.static_obb)),
                    "parallelism": f"candidate-range sharding x{world}",
-                   "exchange": (os.environ.get("RP_AMD_EXCHANGE", "auto") if dist is not None else "none")},
+                   "exchange": ({"MailboxExchange": "shared-memory mailbox (ranks of one node; RP_AMD_EXCHANGE=collective for RCCL)",
+                                 "CollectiveExchange": "torch.distributed collectives (RCCL)"}.get(type(exchange).__name__, "?")
+                                if exchange is not None else "none")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rp_eval_kernel",
                      "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
