@@ -201,6 +201,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
         "rp_count_collisions_before": (C.c_int, [ctx, C.c_double, C.c_int64, C.POINTER(C.c_int64)]),
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
+        "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
         "rp_mailbox_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
         "rp_mailbox_exchange": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(RpResult), dp,
                                           C.POINTER(RpResult), dp, ip]),
@@ -220,7 +221,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
+                    "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
 
 
 class RpContext:
@@ -337,6 +338,18 @@ class RpContext:
         self._check(self._lib.rp_count_collisions_before(self._h, float(cost), int(index), C.byref(n)),
                     "rp_count_collisions_before")
         return int(n.value)
+
+    def check_swept(self, params: RpParams, x, y, theta, want_boxes: bool = False):
+        """Continuous collision check of one trajectory (reactive_planner.py:1049-1058): first colliding segment
+        or -1 (with ``want_boxes``: also the segments' rectangles, [n - 1][6])."""
+        x, y, theta = f64(x), f64(y), f64(theta)
+        if not (len(x) == len(y) == len(theta)):
+            raise ValueError("check_swept: x, y, theta differ in length")
+        first = C.c_int32(-1)
+        boxes = np.empty((max(len(x) - 1, 0), 6)) if want_boxes else None
+        self._check(self._lib.rp_check_swept(self._h, C.byref(params), len(x), dptr(x), dptr(y), dptr(theta),
+                                             C.byref(first), dptr(boxes)), "rp_check_swept")
+        return (int(first.value), boxes) if want_boxes else int(first.value)
 
     def select(self, costs, want_best_states: bool = True) -> PlanOutput:
         costs = f64(costs)

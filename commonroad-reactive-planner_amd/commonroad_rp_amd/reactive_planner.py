@@ -242,6 +242,14 @@ class GpuBackendMixin:
             self.stored_trajectories = self._gpu_stored_trajectories(ctx, bundle, status, costs)
         if out.best_index < 0:
             return None
+        if self.config.planning.continuous_collision_check:
+            # second test of _check_collisions (reactive_planner.py:1049-1058), applied to the first sample of the
+            # sorted list that passed the per-pose test.  A hit there `break`s out of the loop over the sorted list
+            # (:1058): the level ends without a result, the counter goes up by one.
+            st = out.best_states
+            if ctx.check_swept(params, st[0], st[1], st[2]) >= 0:
+                self._infeasible_count_collision += 1
+                return None
         return self._gpu_winner_sample(bundle, out)
 
     def _wants_costs(self) -> bool:

@@ -240,6 +240,42 @@ __device__ __forceinline__ bool obb_circ(const Obb &a, double cx, double cy, dou
     return dx * dx + dy * dy <= r * r;
 }
 
+// Tight rectangle around two rectangles: the occupancy between two consecutive poses for the continuous collision
+// check (reactive_planner.py:1049-1052, commonroad-dc's trajectory_preprocess_obb_sum -- source absent; this is the
+// "OBB sum" of the FCL library commonroad-dc builds on, OBB::operator+, restated in the plane).  Orientation: the
+// bisector of the two headings (a rectangle is the same set with its axis flipped, so the second heading is flipped
+// when the two point apart), or the line through the centres when they are farther apart than twice the sum of the
+// larger half extents; extents: both rectangles projected on the two axes.  Same formulas as oracle/rp_oracle.c.
+__device__ __forceinline__ Obb merge_swept(const Obb &a, const Obb &b) {
+    const double dx = b.cx - a.cx, dy = b.cy - a.cy;
+    const double lim = 2.0 * (fmax(a.hl, a.hw) + fmax(b.hl, b.hw));
+    double nx, ny;
+    if (dx * dx + dy * dy > lim * lim) { nx = dx; ny = dy; }
+    else {
+        const double s = (a.ux * b.ux + a.uy * b.uy) < 0.0 ? -1.0 : 1.0;
+        nx = a.ux + s * b.ux; ny = a.uy + s * b.uy;
+    }
+    const double nrm = sqrt(nx * nx + ny * ny);
+    nx = nx / nrm; ny = ny / nrm;
+    const double mx = -ny, my = nx;
+    // projections relative to a's centre: centre +- (hl |u.n| + hw |v.n|)
+    const double ea0 = a.hl * fabs(a.ux * nx + a.uy * ny) + a.hw * fabs(a.uy * nx - a.ux * ny);
+    const double ea1 = a.hl * fabs(a.ux * mx + a.uy * my) + a.hw * fabs(a.uy * mx - a.ux * my);
+    const double eb0 = b.hl * fabs(b.ux * nx + b.uy * ny) + b.hw * fabs(b.uy * nx - b.ux * ny);
+    const double eb1 = b.hl * fabs(b.ux * mx + b.uy * my) + b.hw * fabs(b.uy * mx - b.ux * my);
+    const double pb0 = dx * nx + dy * ny, pb1 = dx * mx + dy * my;
+    const double lo0 = fmin(-ea0, pb0 - eb0), hi0 = fmax(ea0, pb0 + eb0);
+    const double lo1 = fmin(-ea1, pb1 - eb1), hi1 = fmax(ea1, pb1 + eb1);
+    const double c0 = 0.5 * (lo0 + hi0), c1 = 0.5 * (lo1 + hi1);
+    Obb m;
+    m.cx = a.cx + (c0 * nx + c1 * mx);
+    m.cy = a.cy + (c0 * ny + c1 * my);
+    m.ux = nx; m.uy = ny;
+    m.hl = 0.5 * (hi0 - lo0);
+    m.hw = 0.5 * (hi1 - lo1);
+    return m;
+}
+
 // Obstacle tables on the device.  Static shapes: array-of-structs rows of 8 doubles, every lane
 // reads the same row (broadcast).  Dynamic OBBs: struct-of-arrays [7][n_dyn][n_steps] so that the
 // lanes of a group (consecutive time steps) read consecutive addresses.

@@ -974,6 +974,34 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
     return run_pipeline(c, ka, c->last_mat, c->last_coeffs, true, result, best_states);
 }
 
+int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double *x, const double *y, const double *theta,
+                   int32_t *first_hit, double *boxes) {
+    if (!c) return RP_EINVAL;
+    if (!p || !first_hit || n_poses < 0 || (n_poses > 0 && (!x || !y || !theta))) return fail(c, RP_EINVAL, "rp_check_swept: arguments");
+    *first_hit = -1;
+    if (n_poses < 2) return RP_OK;   // no segment
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_poses;
+    int rc;
+    if ((rc = grow(c, c->d_user, c->cap_user, 9 * n + 2)) != RP_OK) return rc;
+    double *d_poses = c->d_user, *d_boxes = c->d_user + 3 * n;
+    int *d_hit = reinterpret_cast<int *>(c->d_user + 9 * n);
+    HIP_TRY(c, hipMemcpyAsync(d_poses, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_poses + n, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_poses + 2 * n, theta, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_hit, 0x7f, sizeof(int), c->stream));   // 0x7f7f7f7f: larger than any segment index
+    const int grid = (n_poses - 1 + 63) / 64;
+    hipLaunchKernelGGL(rp_swept_kernel, dim3(grid), dim3(64), 0, c->stream, c->obs, (const double *)d_poses, (int)n_poses, p->wb_rear_axle,
+                       0.5 * p->length, 0.5 * p->width, (int)p->time_step0, d_hit, boxes ? d_boxes : (double *)nullptr);
+    HIP_TRY(c, hipGetLastError());
+    int hit = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hit, d_hit, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (boxes) HIP_TRY(c, hipMemcpyAsync(boxes, d_boxes, sizeof(double) * 6 * (n - 1), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *first_hit = hit < n_poses - 1 ? hit : -1;
+    return RP_OK;
+}
+
 }  // extern "C"
 
 

@@ -1380,6 +1380,33 @@ __global__ __launch_bounds__(64) void rp_fold_partials_kernel(const BlockPartial
 }
 
 // ------------------------------------------------------------------------------------------------
+// Continuous collision check of one trajectory (reactive_planner.py:1049-1058): segment i = the tight rectangle
+// around the ego rectangles of poses i and i + 1 (merge_swept), tested against the obstacles of scenario time index
+// t0 + i -- the reference's ego object starts at x_0.time_step and advances one index per pose, planning.factor does
+// not enter (:1050).  One lane per segment; first_hit receives the smallest colliding segment (atomicMin).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rp_swept_kernel(ObsTables ob, const double *poses /* [3][n]: x, y, theta */, int n, double wb_rear_axle,
+                                                      double hl, double hw, int t0, int *first_hit, double *boxes /* [n-1][6] or null */) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool want = i < n - 1;
+    const int ic = want ? i : 0;
+    double s0, c0, s1, c1;
+    sincos(poses[2 * n + ic], &s0, &c0);
+    sincos(poses[2 * n + ic + 1], &s1, &c1);
+    const Obb a = {poses[ic] + wb_rear_axle * c0, poses[n + ic] + wb_rear_axle * s0, c0, s0, hl, hw};
+    const Obb b = {poses[ic + 1] + wb_rear_axle * c1, poses[n + ic + 1] + wb_rear_axle * s1, c1, s1, hl, hw};
+    const Obb m = merge_swept(a, b);
+    if (want && boxes) {
+        double *o = boxes + (size_t)i * 6;
+        o[0] = m.cx; o[1] = m.cy; o[2] = m.ux; o[3] = m.uy; o[4] = m.hl; o[5] = m.hw;
+    }
+    // one radius for the wavefront (the rejection tests of pose_collides take a wave-uniform bound)
+    const double r = (double)wave_max_f32(want ? (float)sqrt(m.hl * m.hl + m.hw * m.hw) : 0.f) * 1.000001;
+    const bool hit = pose_collides(ob, m, r, t0 + i, want, false, 0, 0);
+    if (want && hit) atomicMin(first_hit, i);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block partials from the status / cost arrays (plug-in cost path, rp_select).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *status, const double *cost, int64_t count,

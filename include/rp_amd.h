@@ -33,6 +33,7 @@
 #ifndef RP_AMD_H
 #define RP_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -198,6 +199,20 @@ int rp_count_collisions_before(rp_ctx *ctx, double cost, int64_t index, int64_t 
 /* Plug-in cost functions (RP_COST_EXTERNAL): upload one cost per local candidate (NaN = skip) and
  * redo the selection (argmin + collision counters) on the device. */
 int rp_select(rp_ctx *ctx, const double *costs, int64_t count, rp_result *result, double *best_states);
+
+/* Continuous collision check of ONE trajectory -- the second test of ReactivePlanner._check_collisions
+ * (commonroad_rp/reactive_planner.py:1049-1058, planning.continuous_collision_check), which the reference applies
+ * to the first candidate of the sorted list that passed the per-pose test: the ego rectangles (half extents
+ * length/2, width/2, centre = (x, y) moved by wb_rear_axle along theta, :1033-1035,1052) of poses i and i + 1 are
+ * replaced by the tight rectangle around both (commonroad-dc's trajectory_preprocess_obb_sum; see DESIGN.md for
+ * the definition used) and segment i is tested against the obstacle tables at scenario time index
+ * params->time_step0 + i (the reference's ego object starts at x_0.time_step and holds one shape per index;
+ * planning.factor does not enter, :1050).
+ * x, y, theta: [n_poses] rear-axle poses (cartesian.x / .y / .theta of the sample).  first_hit: smallest colliding
+ * segment, -1 if none (also for n_poses < 2).  boxes (optional): [n_poses - 1][6] = cx, cy, ux, uy, half length,
+ * half width of every segment's rectangle.  Uses the obstacle tables of rp_set_obstacles. */
+int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const double *x, const double *y,
+                   const double *theta, int32_t *first_hit, double *boxes);
 
 /* ---- intra-node winner exchange (host only; no GPU involved) -----------------------------------
    Replaces the reference's only "communication backend", the multiprocessing.Queue fan-out of

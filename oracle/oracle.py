@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
                                                dp, dp, ip, up, dp, dp, C.POINTER(RpResult), dp, C.c_int]
         _lib.rp_oracle_count_collisions_before.restype = C.c_int64
         _lib.rp_oracle_count_collisions_before.argtypes = [C.c_int64, C.c_int64, up, dp, C.c_double, C.c_int64]
+        _lib.rp_oracle_check_swept.restype = C.c_int
+        _lib.rp_oracle_check_swept.argtypes = [C.POINTER(RpParams), C.POINTER(RpoTables), C.c_int, dp, dp, dp, dp]
         _lib.rpo_np_sum.restype = C.c_double
         _lib.rpo_np_sum.argtypes = [dp, C.c_long]
         _lib.rpo_quintic_coeffs.restype = None
@@ -148,3 +150,14 @@ def count_collisions_before(status, cost, base, wcost, windex) -> int:
     cost = f64(cost)
     return int(lib().rp_oracle_count_collisions_before(len(status), base, status.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                        dptr(cost), float(wcost), int(windex)))
+
+
+def check_swept(params, tables: OracleTables, x, y, theta, want_boxes: bool = False):
+    """Continuous collision check of one trajectory: (first colliding segment or -1, boxes [n-1][6] or None)."""
+    x, y, theta = f64(x), f64(y), f64(theta)
+    n = len(x)
+    boxes = np.zeros((max(n - 1, 0), 6)) if want_boxes else None
+    tb = tables.c_struct()
+    first = lib().rp_oracle_check_swept(C.byref(params), C.byref(tb), n, dptr(x), dptr(y), dptr(theta),
+                                        dptr(boxes) if want_boxes else None)
+    return int(first), boxes

@@ -571,6 +571,62 @@ int64_t rp_oracle_count_collisions_before(int64_t C, int64_t base, const uint32_
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* continuous collision check of one trajectory, commonroad_rp/reactive_planner.py:1049-1058.   */
+/* trajectory_preprocess_obb_sum belongs to commonroad-dc 2024.1 (absent): the tight rectangle   */
+/* around two consecutive ego rectangles is DEFINED here as the planar form of FCL's OBB sum     */
+/* (OBB::operator+: bisector orientation, or the centre line when the centres are farther apart  */
+/* than twice the sum of the larger half extents; extents from projecting both rectangles) --    */
+/* same definition as tests/golden/_ref_shims.py, which the reference's own _check_collisions is */
+/* run with for the fixtures.  Parity with the real commonroad-dc routine: unpinned.            */
+/* ------------------------------------------------------------------------------------------- */
+static obb_t merge_swept(const obb_t *a, const obb_t *b) {
+    double dx = b->cx - a->cx, dy = b->cy - a->cy;
+    double lim = 2.0 * (fmax(a->hl, a->hw) + fmax(b->hl, b->hw));
+    double nx, ny;
+    if (dx * dx + dy * dy > lim * lim) { nx = dx; ny = dy; }
+    else {
+        double s = (a->ux * b->ux + a->uy * b->uy) < 0.0 ? -1.0 : 1.0;
+        nx = a->ux + s * b->ux; ny = a->uy + s * b->uy;
+    }
+    double nrm = sqrt(nx * nx + ny * ny);
+    nx = nx / nrm; ny = ny / nrm;
+    double mx = -ny, my = nx;
+    double ea0 = a->hl * fabs(a->ux * nx + a->uy * ny) + a->hw * fabs(a->uy * nx - a->ux * ny);
+    double ea1 = a->hl * fabs(a->ux * mx + a->uy * my) + a->hw * fabs(a->uy * mx - a->ux * my);
+    double eb0 = b->hl * fabs(b->ux * nx + b->uy * ny) + b->hw * fabs(b->uy * nx - b->ux * ny);
+    double eb1 = b->hl * fabs(b->ux * mx + b->uy * my) + b->hw * fabs(b->uy * mx - b->ux * my);
+    double pb0 = dx * nx + dy * ny, pb1 = dx * mx + dy * my;
+    double lo0 = fmin(-ea0, pb0 - eb0), hi0 = fmax(ea0, pb0 + eb0);
+    double lo1 = fmin(-ea1, pb1 - eb1), hi1 = fmax(ea1, pb1 + eb1);
+    double c0 = 0.5 * (lo0 + hi0), c1 = 0.5 * (lo1 + hi1);
+    obb_t m = {a->cx + (c0 * nx + c1 * mx), a->cy + (c0 * ny + c1 * my), nx, ny, 0.5 * (hi0 - lo0), 0.5 * (hi1 - lo1)};
+    return m;
+}
+
+/* first colliding segment or -1; boxes: optional [n-1][6] (cx, cy, ux, uy, hl, hw).  Segment i is tested at scenario
+ * time index time_step0 + i: the ego object of :1050 starts at x_0.time_step, one shape per index, no factor. */
+int rp_oracle_check_swept(const rp_params *p, const rpo_tables *tb, int n, const double *x, const double *y,
+                          const double *theta, double *boxes) {
+    double hl = 0.5 * p->length, hw = 0.5 * p->width;
+    int first = -1;
+    for (int i = 0; i + 1 < n; ++i) {
+        double c0 = cos(theta[i]), s0 = sin(theta[i]), c1 = cos(theta[i + 1]), s1 = sin(theta[i + 1]);
+        obb_t a = {x[i] + p->wb_rear_axle * c0, y[i] + p->wb_rear_axle * s0, c0, s0, hl, hw};
+        obb_t b = {x[i + 1] + p->wb_rear_axle * c1, y[i + 1] + p->wb_rear_axle * s1, c1, s1, hl, hw};
+        obb_t m = merge_swept(&a, &b);
+        if (boxes) {
+            double *o = boxes + 6 * (size_t)i;
+            o[0] = m.cx; o[1] = m.cy; o[2] = m.ux; o[3] = m.uy; o[4] = m.hl; o[5] = m.hw;
+        }
+        if (first < 0 && pose_collides(tb, &m, p->time_step0 + i)) {
+            first = i;
+            if (!boxes) break;
+        }
+    }
+    return first;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* sampling: FixedIntervalSampling.generate_trajectories_at_level, commonroad_rp/sampling.py:202-242 */
 /* ------------------------------------------------------------------------------------------- */
 void rp_oracle_sample(const rp_params *p, const rp_grids *g, int64_t idx, double lon[6], double lat[6],

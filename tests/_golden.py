@@ -66,7 +66,8 @@ def build_planner_from_plan_golden(name: str, backend_factory, planner_cls=None)
     z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     cfg = ReactivePlannerConfiguration.from_dict(dict(
         planning=dict(dt=float(z["dt"]), time_steps_computation=int(z["N"]), factor=int(z["factor"]),
-                      low_vel_mode_threshold=float(z["low_vel_mode_threshold"])),
+                      low_vel_mode_threshold=float(z["low_vel_mode_threshold"]),
+                      continuous_collision_check=bool(int(z["continuous"]))),
         sampling=dict(longitudinal_mode="stopping" if int(z["lon_mode"]) else "velocity_keeping", t_min=float(z["t_min"]))))
     cls = planner_cls or ReactivePlanner
     rp = cls(cfg, backend_factory=backend_factory)

@@ -63,6 +63,10 @@ class OracleContext:
     def count_collisions_before(self, cost, index):
         return oracle.count_collisions_before(self._run.status, self._run.cost, self._range[0], cost, index)
 
+    def check_swept(self, params, x, y, theta, want_boxes=False):
+        first, boxes = oracle.check_swept(params, self._tables(), x, y, theta, want_boxes)
+        return (first, boxes) if want_boxes else first
+
     def select(self, costs, want_best_states=True):
         run = self._run
         lab = run.status & 3

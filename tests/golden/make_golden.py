@@ -89,7 +89,8 @@ def make_planner(case):
         planning=NS(dt=dt, time_steps_computation=N, factor=case.get("factor", 1),
                     low_vel_mode_threshold=case.get("low_vel_mode_threshold", 4.0),
                     constraints_to_check=list(case.get("constraints", REASONS)),
-                    continuous_collision_check=False, standstill_lookahead=10, replanning_frequency=3),
+                    continuous_collision_check=bool(case.get("continuous", False)), standstill_lookahead=10,
+                    replanning_frequency=3),
         sampling=NS(sampling_method=1, longitudinal_mode=case.get("lon_mode", "velocity_keeping"),
                     num_sampling_levels=case.get("num_levels", 4), t_min=case.get("t_min", 0.4),
                     v_min=0, v_max=0, s_min=-1, s_max=1, d_min=case.get("d_min", -3), d_max=case.get("d_max", 3)),
@@ -413,13 +414,45 @@ def plan_cases():
         dict(base, name="plan_all_collide", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
              x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0,
              obstacles=ObstacleTables(static_circ=[[20.0, 2.0, 30.0]])),
+        # continuous collision check (reactive_planner.py:1049-1058): nothing between the poses of the winner ...
+        dict(base, name="plan_arc_swept_free", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
+             x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3, obstacles=obstacles_arc(),
+             continuous=True),
+        # ... and an obstacle that exists for ONE time index just ahead of the level-1 winner's bumper at that index:
+        # every pose passes, the rectangle around poses i and i + 1 does not -> that level ends without a result
+        # (the `break` of :1058 leaves the loop over the sorted list), the next level is tried
+        swept_trap(dict(base, name="plan_arc_swept_hit", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3],
+                        x0_lat=[0.4, 0.2, -0.1], x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3,
+                        obstacles=obstacles_arc(), continuous=True), step=8),
     ]
+
+
+def swept_trap(case, step):
+    """Add a 0.2 m x 0.2 m obstacle that exists only at time index time_step0 + step, 0.35 m ahead of the front
+    bumper the level-1 winner (per-pose check only) has at that index."""
+    probe = dict(case, continuous=False)
+    rp = make_planner(probe)
+    bundle = rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], samp_level=1)
+    opt = rp._get_optimal_trajectory(bundle)
+    assert opt is not None
+    th = opt.cartesian.theta[step]
+    cx = opt.cartesian.x[step] + VEH["wb_rear_axle"] * np.cos(th)
+    cy = opt.cartesian.y[step] + VEH["wb_rear_axle"] * np.sin(th)
+    ahead = 0.5 * VEH["length"] + 0.35
+    tb = case["obstacles"]
+    row = np.full((1,) + tb.dyn_obb.shape[1:], np.nan)
+    k = case.get("time_step0", 0) + step - tb.dyn_t0
+    row[0, k] = (cx + ahead * np.cos(th), cy + ahead * np.sin(th), th, 0.1, 0.1)
+    case["obstacles"] = ObstacleTables(static_obb=tb.static_obb, static_tri=tb.static_tri, static_circ=tb.static_circ,
+                                       dyn_obb=np.concatenate((tb.dyn_obb, row)), dyn_t0=tb.dyn_t0)
+    return case
 
 
 def run_plan_case(case):
     rp = make_planner(case)
     res = rp.plan()
-    out = dict(case_inputs(rp, case), planned=int(res is not None),
+    out = dict(case_inputs(rp, case), planned=int(res is not None), continuous=int(bool(case.get("continuous", False))),
+               n_swept_checks=rp._cc.n_swept_queries, n_swept_hits=rp._cc.n_swept_hits,
                n_infeasible_kinematics=rp._infeasible_count_kinematics, n_infeasible_collision=rp._infeasible_count_collision,
                reason_counts=np.array([rp._infeasible_reason_dict.get(k, 0) for k in REASONS], dtype=np.int64),
                optimal_cost=float(rp._optimal_cost))
