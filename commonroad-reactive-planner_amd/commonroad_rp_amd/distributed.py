@@ -96,19 +96,32 @@ class MailboxExchange:
         self.dist, self.n = dist, n
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         size = int(self._lib.rp_mailbox_bytes(self.world, n))
-        names = [None]
+        # Set-up is collective and fails on every rank or on none: a rank that fell back to the collectives on its own
+        # would leave its peers waiting here.
+        names, self.shm = [None], None
         if self.rank == 0:
-            self.shm = shared_memory.SharedMemory(create=True, size=size)
-            self.shm.buf[:size] = bytes(size)
-            names = [self.shm.name]
+            try:
+                self.shm = shared_memory.SharedMemory(create=True, size=size)
+                self.shm.buf[:size] = bytes(size)
+                names = [self.shm.name]
+            except OSError:
+                self.shm = None
         dist.broadcast_object_list(names, src=0)
-        if self.rank != 0:
-            self.shm = shared_memory.SharedMemory(name=names[0])
-            try:   # the creator unlinks; do not let this process's resource tracker do it as well
-                from multiprocessing import resource_tracker
-                resource_tracker.unregister(self.shm._name, "shared_memory")
-            except Exception:
-                pass
+        if names[0] is not None and self.rank != 0:
+            try:
+                self.shm = shared_memory.SharedMemory(name=names[0])
+                try:   # the creator unlinks; do not let this process's resource tracker do it as well
+                    from multiprocessing import resource_tracker
+                    resource_tracker.unregister(self.shm._name, "shared_memory")
+                except Exception:
+                    pass
+            except OSError:
+                self.shm = None
+        attached = [None] * self.world
+        dist.all_gather_object(attached, self.shm is not None)
+        if not all(attached):
+            self.close()
+            raise OSError(f"shared-memory mailbox unavailable on rank(s) {[r for r, ok in enumerate(attached) if not ok]}")
         import ctypes as C
         tmp = C.c_char.from_buffer(self.shm.buf)      # (only to learn the mapping's address: a lasting ctypes export
         self._region = C.c_void_p(C.addressof(tmp))   #  would keep SharedMemory.close() from releasing the buffer)
@@ -123,9 +136,11 @@ class MailboxExchange:
     def close(self):
         try:
             self._region = None
-            self.shm.close()
-            if self.rank == 0:
-                self.shm.unlink()
+            if self.shm is not None:
+                self.shm.close()
+                if self.rank == 0:
+                    self.shm.unlink()
+            self.shm = None
         except Exception:
             pass
 

@@ -22,6 +22,14 @@ def main():
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("TEST_BREAK_SHM_ON_RANK") == str(rank):
+        # this rank cannot create / attach shared memory: the mailbox set-up must fail on EVERY rank, so that
+        # transport "auto" falls back to the collectives everywhere
+        from multiprocessing import shared_memory
+
+        def broken(*a, **k):
+            raise OSError("no shared memory on this rank (test)")
+        shared_memory.SharedMemory = broken
     results = {}
     for name in sys.argv[2:]:
         g = Golden(name)
@@ -35,6 +43,8 @@ def main():
                              n_candidates=glob.n_candidates, reasons=glob.reason_counts.tolist(),
                              states_sum=None if glob.best_states is None else float(np.sum(glob.best_states)),
                              lon=glob.best_lon_coeffs.tolist())
+    from commonroad_rp_amd import distributed as D
+    results["_transport"] = sorted(type(e).__name__ for e in D._exchanges.values())
     close_exchanges()
     dist.barrier()
     with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:

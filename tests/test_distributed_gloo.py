@@ -51,6 +51,24 @@ def test_sharded_exchange_matches_unsharded(tmp_path, world, transport):
                 assert res["lon"] == full.best_lon_coeffs.tolist()
 
 
+@pytest.mark.parametrize("broken_rank", [0, 1])
+def test_mailbox_setup_fails_on_every_rank_or_none(tmp_path, broken_rank):
+    """One rank without shared memory: "auto" must end on the collectives on ALL ranks (a rank falling back on its own
+    would leave the others waiting in the mailbox set-up), and the results stay right."""
+    world = 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29690 + broken_rank), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1", RP_AMD_EXCHANGE="auto", TEST_BREAK_SHM_ON_RANK=str(broken_rank))
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(tmp_path), CASES[0]],
+                              env=dict(env, RANK=str(r))) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    g = Golden(CASES[0])
+    for r in range(world):
+        res = json.load(open(tmp_path / f"rank{r}.json"))
+        assert res["_transport"] == ["CollectiveExchange"]
+        assert res[CASES[0]]["best_index"] == int(g["winner"])
+
+
 def test_pack_and_combine_roundtrip():
     g = Golden("arc_hv_l2_obs")
     C = g.inputs.n_candidates
