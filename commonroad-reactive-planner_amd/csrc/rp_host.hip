@@ -525,11 +525,16 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         std::vector<unsigned long long> tl(2 * 4096);
         HIP_TRY(c, hipMemcpy(tl.data(), c->d_debug + 32, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0;
-        for (int b = 0; b < grid && b < 4096; ++b) { t0 = std::min(t0, tl[2 * b]); t1 = std::max(t1, tl[2 * b + 1]); }
-        std::fprintf(stderr, "timeline: %d blocks, span %llu cycles; per block (start,dur):", grid, t1 - t0);
-        for (int b = 0; b < grid && b < 4096; b += std::max(1, grid / 24))
-            std::fprintf(stderr, " b%d(%llu,%llu)", b, tl[2 * b] - t0, tl[2 * b + 1] - tl[2 * b]);
-        std::fprintf(stderr, "\n");
+        const int nb = std::min(grid, 4096);
+        for (int b = 0; b < nb; ++b) { t0 = std::min(t0, tl[2 * b]); t1 = std::max(t1, tl[2 * b + 1]); }
+        std::vector<unsigned long long> st(nb), en(nb), du(nb);
+        for (int b = 0; b < nb; ++b) { st[b] = tl[2 * b] - t0; en[b] = tl[2 * b + 1] - t0; du[b] = tl[2 * b + 1] - tl[2 * b]; }
+        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); std::sort(du.begin(), du.end());
+        auto q = [&](const std::vector<unsigned long long> &v, double f) { return 0.01 * (double)v[(size_t)(f * (nb - 1))]; };
+        std::fprintf(stderr, "timeline (us, 100 MHz clock): %d blocks, first start -> last end %.2f; starts p0/p25/p50/p55/p60/p75/p100 "
+                     "%.2f %.2f %.2f %.2f %.2f %.2f %.2f; ends p0/p50/p100 %.2f %.2f %.2f; durations p0/p50/p100 %.2f %.2f %.2f\n",
+                     grid, 0.01 * (double)(t1 - t0), q(st, 0), q(st, .25), q(st, .5), q(st, .55), q(st, .6), q(st, .75), q(st, 1), q(en, 0), q(en, .5),
+                     q(en, 1), q(du, 0), q(du, .5), q(du, 1));
     }
 #endif
     if (c->timing && !skip_eval) {

@@ -125,13 +125,14 @@ struct DevResult {
 #else
 #define RP_STAMP(k) do { } while (0)
 #endif
-// Per-block timeline (diagnostic build -DRP_TIMELINE): start / end s_memtime of every workgroup.
+// Per-block timeline (diagnostic build -DRP_TIMELINE): start / end of every workgroup on the 100 MHz constant clock
+// (s_memrealtime: the same counter on every XCD, unlike s_memtime).
 #ifdef RP_TIMELINE
 #define RP_TL(slot)                                                                               \
     do {                                                                                          \
         if (a.debug && !a.single_index && threadIdx.x == 0) {                                     \
             unsigned long long t_;                                                                \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
             a.debug[32 + 2 * blockIdx.x + (slot)] = t_;                                           \
         }                                                                                         \
     } while (0)
