@@ -516,7 +516,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         unsigned long long st[32];
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
-        for (int k = 1; k < 15; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        for (int k = 1; k < 17; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
         std::fprintf(stderr, "\n");
     }
 #endif

@@ -850,6 +850,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         int j = tid;
         LonPairIn lin;
         if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
+        RP_STAMP(15);   // single-launch prologue: candidate / grid loads requested
         {
             const double2 *src = reinterpret_cast<const double2 *>(a.tables);
             double2 *dst = reinterpret_cast<double2 *>(lds_tab);
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
 #pragma unroll 4
             for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
         }
+        RP_STAMP(16);   // table copy issued (this wave's share)
         if (tid < P) lds_flags[tid] = 0;
         if (tid < 10) sh_cnt[tid] = 0;
         if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
