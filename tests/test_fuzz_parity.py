@@ -1,0 +1,30 @@
+"""Randomised differential test: the HIP path (through the C ABI) against the CPU oracle on seeded random scenarios
+(tests/_fuzz.py).  A sweep over 1 500 seeds is recorded in profiles/r01_fuzz_parity.txt."""
+import numpy as np
+import pytest
+
+from _fuzz import compare, random_case
+
+
+def test_generator_is_seeded_and_varied():
+    a, _, _, ia = random_case(7)
+    b, _, _, ib = random_case(7)
+    assert ia == ib and np.array_equal(a.T, b.T) and np.array_equal(a.L, b.L) and np.array_equal(a.D, b.D)
+    infos = [random_case(s)[3] for s in range(40)]
+    assert len({i["mode"] for i in infos}) >= 4 and any(i["draw"] for i in infos) and any(i["n_dyn"] > 63 for i in infos)
+    assert any(i["N"] > 64 for i in infos) and any(i["factor"] > 1 for i in infos) and any(i["mask"] != 31 for i in infos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("first", [0, 100, 200, 300])
+def test_random_scenarios_match_oracle(first):
+    from commonroad_rp_amd._capi import RpContext
+    ctx = RpContext(0)
+    winners = candidates = 0
+    for seed in range(first, first + 100):
+        info, C, problems, ro = compare(ctx, seed)
+        assert not problems, (seed, info, problems)
+        winners += ro.best_index >= 0
+        candidates += C
+    assert winners >= 15 and candidates > 10000    # the cases are not degenerate
+    ctx.close()
