@@ -1,0 +1,28 @@
+"""The launch paths of the library that the GPU tests run on (the environment switches are read per plan call):
+  single_launch  small batches: one kernel computes the longitudinal profiles in LDS and evaluates (default)
+  two_kernel     rp_lon_kernel + rp_eval_kernel (what large batches take), 16 lanes per candidate
+  g32 / g64      two-kernel path with 32 / 64 lanes per candidate (g64: LDS-staged linear copy-out of state rows)"""
+import contextlib
+import os
+
+LAUNCH_PATHS = {
+    "single_launch": {},
+    "two_kernel": {"RP_AMD_NO_FUSED_LON": "1"},
+    "g32": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "32"},
+    "g64": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "64"},
+}
+
+
+@contextlib.contextmanager
+def launch_path_env(name):
+    saved = {k: os.environ.get(k) for k in ("RP_AMD_NO_FUSED_LON", "RP_AMD_G")}
+    for k in saved:
+        os.environ.pop(k, None)
+    os.environ.update(LAUNCH_PATHS[name])
+    try:
+        yield
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -1,5 +1,5 @@
 """Randomised differential test: the HIP path (through the C ABI) against the CPU oracle on seeded random scenarios
-(tests/_fuzz.py).  A sweep over 1 500 seeds is recorded in profiles/r01_fuzz_parity.txt."""
+(tests/_fuzz.py).  Sweeps over 10 000 seeds (default launch path) and 3 000 seeds (each other path) are recorded in profiles/r01_fuzz_parity.txt."""
 import numpy as np
 import pytest
 
@@ -16,15 +16,17 @@ def test_generator_is_seeded_and_varied():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("first", [0, 100, 200, 300])
-def test_random_scenarios_match_oracle(first):
+@pytest.mark.parametrize("path,first", [("single_launch", 0), ("single_launch", 100), ("two_kernel", 200), ("g32", 300), ("g64", 400)])
+def test_random_scenarios_match_oracle(path, first):
+    from _paths import launch_path_env
     from commonroad_rp_amd._capi import RpContext
-    ctx = RpContext(0)
-    winners = candidates = 0
-    for seed in range(first, first + 100):
-        info, C, problems, ro = compare(ctx, seed)
-        assert not problems, (seed, info, problems)
-        winners += ro.best_index >= 0
-        candidates += C
-    assert winners >= 15 and candidates > 10000    # the cases are not degenerate
-    ctx.close()
+    with launch_path_env(path):
+        ctx = RpContext(0)
+        winners = candidates = 0
+        for seed in range(first, first + 100):
+            info, C, problems, ro = compare(ctx, seed)
+            assert not problems, (path, seed, info, problems)
+            winners += ro.best_index >= 0
+            candidates += C
+        assert winners >= 15 and candidates > 10000    # the cases are not degenerate
+        ctx.close()

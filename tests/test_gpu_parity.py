@@ -21,33 +21,15 @@ COST_RTOL = 1e-9
 NAMES = case_names()
 
 
-# Every test runs on each launch path of the library (the environment switches are read per plan call):
-#   single_launch  small batches: one kernel computes the longitudinal profiles in LDS and evaluates (default)
-#   two_kernel     rp_lon_kernel + rp_eval_kernel (what large batches take), 16 lanes per candidate
-#   g32 / g64      two-kernel path with 32 / 64 lanes per candidate (g64: LDS-staged linear copy-out of state rows)
-LAUNCH_PATHS = {
-    "single_launch": {},
-    "two_kernel": {"RP_AMD_NO_FUSED_LON": "1"},
-    "g32": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "32"},
-    "g64": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "64"},
-}
+from _paths import LAUNCH_PATHS, launch_path_env
 
 
 @pytest.fixture(scope="module", params=list(LAUNCH_PATHS))
 def ctx(request):
-    import os
-    env = LAUNCH_PATHS[request.param]
-    saved = {k: os.environ.get(k) for k in ("RP_AMD_NO_FUSED_LON", "RP_AMD_G")}
-    for k in saved:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    c = RpContext(0)
-    yield c
-    c.close()
-    for k, v in saved.items():
-        os.environ.pop(k, None)
-        if v is not None:
-            os.environ[k] = v
+    with launch_path_env(request.param):
+        c = RpContext(0)
+        yield c
+        c.close()
 
 
 def _with_flags(inp: PlanInputs, extra: int) -> PlanInputs:
