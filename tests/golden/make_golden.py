@@ -20,6 +20,7 @@ Per case the fixture holds
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import sys
 import types
@@ -366,6 +367,76 @@ def cases():
     cs.append(dict(base, name="arc_all_collide", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
                    x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, max_states=8,
                    obstacles=ObstacleTables(static_circ=[[20.0, 2.0, 30.0]])))
+    return cs + random_cases()
+
+
+def random_cases(n=24):
+    """Seeded random scenarios through the same pipeline (paths, initial states, horizons, levels, modes, obstacles of
+    every kind, constraint subsets, planning.factor): widens what pins the oracle beyond the hand-made cases."""
+    cs = []
+    for k in range(n):
+        rng = np.random.default_rng(1000 + k)
+        kind = k % 3
+        if kind == 0:
+            ref = path_arc(radius=float(rng.uniform(40.0, 300.0)) * (1 if rng.random() < 0.5 else -1), length=float(rng.uniform(120, 220)))
+        elif kind == 1:
+            ref = path_scurve(length=float(rng.uniform(120, 200)), amp=float(rng.uniform(0.2, 0.8)))
+        else:
+            ref = path_straight(float(rng.uniform(100, 200)), heading=float(rng.uniform(-3.1, 3.1)), x0=float(rng.uniform(-200, 200)),
+                                y0=float(rng.uniform(-200, 200)))
+        co = CoordinateSystem(ref)
+        N = int(rng.choice([15, 20, 25, 30, 40]))
+        mode = ["hv", "hv", "lv", "stop", "slow_hv"][int(rng.integers(0, 5))]
+        v0 = {"hv": rng.uniform(5.0, 22.0), "lv": rng.uniform(0.4, 3.5), "stop": rng.uniform(3.0, 10.0), "slow_hv": rng.uniform(0.2, 2.0)}[mode]
+        v0 = float(v0)
+        s0 = float(rng.uniform(6.0, 25.0))
+        low_thr = 0.1 if mode == "slow_hv" else 4.0
+        low_vel = v0 < low_thr
+        d0 = float(rng.normal(0, 0.5))
+        d1 = float(rng.normal(0, 0.02 if low_vel else 0.12))
+        th_ref = float(np.interp(s0, co.ref_pos, np.unwrap(co.ref_theta)))
+        th_cl = math.atan(d1) if low_vel else math.asin(max(-0.5, min(0.5, d1 / max(v0, 0.5))))
+        case = dict(dt=0.1, N=N, t_min=float(0.1 * int(rng.integers(4, max(5, N // 2)))), name=f"rand_{k:02d}_{mode}", ref_path=ref,
+                    level=int(rng.choice([1, 1, 2])), x0_lon=[s0, v0 * math.cos(th_cl), float(rng.normal(0, 0.3))],
+                    x0_lat=[d0, d1, float(rng.normal(0, 0.02))], x0_orientation=th_ref + th_cl, x0_velocity=v0,
+                    low_vel_mode_threshold=low_thr, time_step0=int(rng.integers(0, 12)), factor=int(rng.choice([1, 1, 2])),
+                    draw=bool(rng.random() < 0.25), cost_kind=int(rng.random() < 0.15), max_states=12)
+        if rng.random() < 0.35:
+            # (the pre-filter counts "velocity" / "acceleration" whatever the list says, reactive_planner.py:798-803: a list
+            #  without them raises KeyError in the reference itself)
+            case["constraints"] = [c for c in REASONS if c in ("velocity", "acceleration") or rng.random() < 0.5]
+        if mode == "stop":
+            case.update(lon_mode="stopping", desired_s=float(s0 + rng.uniform(5.0, 1.2 * v0 * N * 0.1)), delta_s_min=float(-rng.uniform(2, 10)),
+                        delta_s_max=float(rng.uniform(1, 6)))
+        else:
+            case["desired_speed"] = float(max(0.0, v0 + rng.normal(0, 2.0)))
+            if mode == "slow_hv":
+                case["v_range"] = (0.0, float(rng.uniform(1.5, 4.0)))
+        # obstacles around the corridor ahead
+        def at(s, d):
+            return co.convert_to_cartesian_coords(float(min(max(s, 1.0), co.ref_pos[-1] - 1.0)), float(d))
+        reach = v0 * N * 0.1 + 15.0
+        n_dyn = int(rng.choice([0, 0, 1, 2, 4]))
+        n_steps = case["time_step0"] + N * case["factor"] + int(rng.integers(-6, 8))
+        dyn = np.full((n_dyn, max(1, n_steps), 5), np.nan)
+        for j in range(n_dyn):
+            sj, dj, vj = s0 + rng.uniform(8.0, reach), rng.choice([-1, 1]) * rng.uniform(1.2, 4.0), rng.uniform(0, 12)
+            a, b = sorted(rng.integers(0, dyn.shape[1] + 1, 2))
+            for q in range(a, b):
+                p_ = at(sj + vj * 0.1 * q / case["factor"], dj + 0.02 * q)
+                dyn[j, q] = (p_[0], p_[1], rng.uniform(-3.2, 3.2), rng.uniform(0.4, 2.6), rng.uniform(0.3, 1.1))
+        sobb, tri, circ = [], [], []
+        for _ in range(int(rng.choice([0, 0, 1, 3, 6]))):
+            p_ = at(s0 + rng.uniform(8.0, reach), rng.choice([-1, 1]) * rng.uniform(0.8, 5.0))
+            q = int(rng.integers(0, 3))
+            if q == 0:
+                sobb.append([p_[0], p_[1], rng.uniform(-3.2, 3.2), rng.uniform(0.3, 5.0), rng.uniform(0.1, 1.0)])
+            elif q == 1:
+                tri.append([p_[0], p_[1], p_[0] + rng.uniform(-2, 2), p_[1] + rng.uniform(-2, 2), p_[0] + rng.uniform(-2, 2), p_[1] + rng.uniform(-2, 2)])
+            else:
+                circ.append([p_[0], p_[1], rng.uniform(0.2, 1.5)])
+        case["obstacles"] = ObstacleTables(static_obb=sobb, static_tri=tri, static_circ=circ, dyn_obb=dyn, dyn_t0=int(rng.integers(0, 3)))
+        cs.append(case)
     return cs
 
 
