@@ -37,9 +37,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_c(tmp_path):
     """sizeof/offsetof from a C translation unit compiled against the header."""
     prog = r'''
+#include "rp_amd.h"   /* first: the header must be self-contained */
 #include <stdio.h>
-#include <stddef.h>
-#include "rp_amd.h"
 int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(rp_params), sizeof(rp_cost), sizeof(rp_grids), sizeof(rp_result));
   printf("%zu %zu %zu %zu\n", offsetof(rp_params, x0_lon), offsetof(rp_params, v_delta_max),
