@@ -13,7 +13,9 @@ from commonroad_rp_amd.distributed import shard_range, pack_result, combine_resu
 from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = ["arc_hv_l2_obs", "straight_hv_l2_ties", "arc_all_collide", "arc_n70_factor2"]
+# (with and without collisions before the winner, no winner at all, ties, every rank / one rank holding the collisions)
+CASES = ["arc_hv_l2_obs", "straight_hv_l2_ties", "arc_all_collide", "arc_n70_factor2", "rand_02_hv", "rand_06_hv", "rand_09_hv",
+         "rand_16_hv"]
 
 
 def test_shard_range_covers_everything():
@@ -81,3 +83,36 @@ def test_pack_and_combine_roundtrip():
     np.testing.assert_array_equal(glob.best_states, full.best_states)
     np.testing.assert_array_equal(glob.reason_counts, full.reason_counts)
     assert (glob.n_feasible, glob.n_collision, glob.n_candidates) == (full.n_feasible, full.n_collision, C)
+
+
+@pytest.mark.parametrize("name", CASES + ["rand_01_hv", "rand_20_hv", "arc_hv_l1_draw"])
+def test_local_share_of_the_collision_count_without_the_second_pass(name):
+    """local_collisions_before takes a rank's share from its own result where that already determines it (owner, no global
+    winner, nothing colliding before the local winner); it must equal the direct count in every case."""
+    from commonroad_rp_amd.distributed import local_collisions_before
+    g = Golden(name)
+    C, n = g.inputs.n_candidates, g.inputs.params.N + 1
+    full = oracle.plan(g.inputs, g.oracle_tables()).out
+
+    class Counting:
+        calls = 0
+
+        def __init__(self, run, base):
+            self.run, self.base = run, base
+
+        def count_collisions_before(self, cost, index):
+            Counting.calls += 1
+            return oracle.count_collisions_before(self.run.status, self.run.cost, self.base, cost, index)
+
+    for world in (2, 3, 5, 8):
+        runs = [oracle.plan(g.inputs, g.oracle_tables(), *shard_range(C, r, world)) for r in range(world)]
+        glob, owner = combine_results(np.stack([pack_result(r.out, n) for r in runs]), n)
+        total = 0
+        for r, run in enumerate(runs):
+            base = shard_range(C, r, world)[0]
+            direct = oracle.count_collisions_before(run.status, run.cost, base, glob.best_cost if glob.best_index >= 0 else 0.0,
+                                                    glob.best_index)
+            got = local_collisions_before(Counting(run, base), run.out, glob, r == owner)
+            assert got == direct, (world, r)
+            total += got
+        assert total == full.n_collision_before_best == int(g["n_infeasible_collision"])
