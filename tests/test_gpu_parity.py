@@ -448,3 +448,42 @@ def test_full_size_workloads(ctx, name):
     if out.best_index >= 0:   # the winner's states, re-evaluated by the oracle
         one = oracle.plan(w.inputs, tb, out.best_index, out.best_index + 1)
         np.testing.assert_allclose(out.best_states, one.states[0], rtol=0, atol=STATE_ATOL)
+
+
+@pytest.mark.parametrize("N", [1000, 4094])
+def test_longest_horizons(ctx, N):
+    """The interface's maximum horizon (N = 4094, rp_plan rejects more) and a long one in between: many step blocks per
+    candidate with carried state, dynamic obstacle rows as long as the horizon."""
+    import math
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import make_params, make_cost, COST_DEFAULT, LON_VELOCITY_KEEPING
+    from commonroad_rp_amd.collision import ObstacleTables
+    from commonroad_rp_amd.coordinate_system import CoordinateSystem
+    from oracle import oracle
+    s = np.arange(0.0, 3000.0, 1.0)
+    co = CoordinateSystem(np.stack((s, 30.0 * np.sin(s / 200.0)), 1))
+    dt = 0.05
+    T = np.array([dt * k for k in (N // 3, N // 2, N)])
+    p = make_params(dt=dt, N=N, factor=1, time_step0=0, low_vel_mode=False, lon_mode=LON_VELOCITY_KEEPING, constraint_mask=31,
+                    flags=FLAG_MATERIALIZE_ALL, x0_lon=[20.0, 12.0, 0.0], x0_lat=[0.3, 0.0, 0.0], x0_orientation=0.15, **W.VEHICLE2)
+    cost = make_cost(COST_DEFAULT, w_a=1.0, desired_speed=12.0, desired_d=0.0, desired_s=None)
+    inp = PlanInputs(p, cost, T, W.traj_len_of(T, dt), np.linspace(8, 14, 5), np.linspace(-2, 2, 5))
+    dyn = np.full((1, N + 1, 5), np.nan)
+    for q in range(N + 1):
+        sq = 60 + 10.0 * q * dt
+        dyn[0, q] = (sq, 3.0 + 30.0 * math.sin(sq / 200.0), 0.1, 2.2, 0.9)
+    obs = ObstacleTables(dyn_obb=dyn, dyn_t0=0)
+    orun = oracle.plan(inp, oracle.OracleTables.from_coordinate_system(co, obs), want_states=True)
+    ctx.set_coordinate_system(co)
+    ctx.set_obstacles(obs)
+    out = ctx.plan(inp)
+    status, cost_g = ctx.fetch_status()
+    _compare_status(status, cost_g, orun)
+    assert out.best_index == orun.out.best_index >= 0
+    have = ((orun.status & 3) == 1) | ((orun.status & 3) == 3)
+    assert have.sum() > 20 and ((orun.status & 3) == 3).any()
+    np.testing.assert_allclose(ctx.fetch_states()[have], orun.states[have], rtol=0, atol=STATE_ATOL)
+    with pytest.raises(Exception):
+        p2 = copy_params(p)
+        p2.N = 4095
+        ctx.plan(PlanInputs(p2, cost, T, W.traj_len_of(T, dt), inp.L, inp.D))
