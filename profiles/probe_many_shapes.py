@@ -1,0 +1,46 @@
+"""Probe: very large obstacle sets (thousands of static shapes, hundreds of dynamic obstacles) against the oracle."""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), os.path.join(REPO, "tests")]
+import _fuzz as F
+from commonroad_rp_amd._capi import RpContext
+from commonroad_rp_amd.collision import ObstacleTables
+
+orig = F.random_case
+
+def big_case(seed):
+    inp, co, obs, info = orig(seed)
+    rng = np.random.default_rng(10_000 + seed)
+    s0 = inp.params.x0_lon[0]
+    n_static = int(rng.choice([500, 2000, 6000]))
+    n_dyn = int(rng.choice([100, 300]))
+    sobb, tri, circ = [], [], []
+    for _ in range(n_static):
+        p = co.convert_to_cartesian_coords(float(np.clip(s0 + rng.uniform(-10, 150), 1.0, co.ref_pos[-1] - 1.0)),
+                                           float(rng.choice([-1, 1]) * rng.uniform(2.0, 12.0)))
+        k = rng.integers(0, 3)
+        if k == 0:
+            sobb.append([p[0], p[1], rng.uniform(-3.2, 3.2), rng.uniform(0.2, 3.0), rng.uniform(0.05, 0.6)])
+        elif k == 1:
+            tri.append([p[0], p[1], p[0] + rng.uniform(-1, 1), p[1] + rng.uniform(-1, 1), p[0] + rng.uniform(-1, 1), p[1] + rng.uniform(-1, 1)])
+        else:
+            circ.append([p[0], p[1], rng.uniform(0.1, 0.8)])
+    n_steps = obs.dyn_obb.shape[1] if obs.dyn_obb.shape[0] else inp.params.N * inp.params.factor + inp.params.time_step0 + 1
+    dyn = np.full((n_dyn, n_steps, 5), np.nan)
+    for j in range(n_dyn):
+        sj, dj, vj = s0 + rng.uniform(-5, 120), rng.choice([-1, 1]) * rng.uniform(1.5, 10.0), rng.uniform(0, 15)
+        for q in range(n_steps):
+            p = co.convert_to_cartesian_coords(float(np.clip(sj + vj * inp.params.dt * q, 1.0, co.ref_pos[-1] - 1.0)), float(dj))
+            dyn[j, q] = (p[0], p[1], rng.uniform(-3.2, 3.2), rng.uniform(0.3, 2.5), rng.uniform(0.3, 1.0))
+    info = dict(info, n_dyn=n_dyn, n_static=n_static)
+    return inp, co, ObstacleTables(static_obb=sobb, static_tri=tri, static_circ=circ, dyn_obb=dyn, dyn_t0=obs.dyn_t0), info
+
+F.random_case = big_case
+ctx = RpContext(0)
+bad = 0
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    info, C, problems, ro = F.compare(ctx, seed)
+    print(seed, info["n_static"], info["n_dyn"], "C", C, "winner", ro.best_index, "n_coll", ro.n_collision, "OK" if not problems else problems, flush=True)
+    bad += bool(problems)
+print("cases with differences:", bad)
