@@ -85,7 +85,10 @@ struct KArgs {
 };
 
 // fields of one step of a longitudinal profile
-enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_NEAR_S, PF_FIELDS };
+enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_NEAR_S, PF_COS_REF, PF_SIN_REF,
+       PF_FIELDS };
+// PF_COS_REF / PF_SIN_REF: cos / sin of theta_ref -- with cos / sin of theta_cl known algebraically (atan branch) the heading's
+// cos / sin (ego rectangle of the collision query, direction of the horizon extension) need no transcendental per candidate
 // PF_NEAR: bit pattern of a 64-bit mask, bit j = dynamic obstacle j can touch SOME candidate of the pair at this step
 // (bit 63: one of the obstacles 63, 64, ... can); PF_NEAR_S: the same for the clusters of static shapes; see near_mask_step
 
@@ -505,6 +508,7 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
     f[PF_KR] = k_r; f[PF_KRD] = k_r_d; f[PF_PX] = px; f[PF_PY] = py;
     f[PF_NX] = -(ay * inv_tn); f[PF_NY] = ax * inv_tn;
     f[PF_INDOM] = (s >= rt.pos_first && s <= rt.pos_last) ? 1.0 : 0.0;
+    rp_sincos(th_ref, &f[PF_SIN_REF], &f[PF_COS_REF]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1125,6 +1129,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     secT = use_atan ? secT : sc;
                     tanT = use_atan ? tanT : sn * sc;
                 }
+                // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref
+                const double sinT = tanT * cosT;
+                double cos_gl = pf.f[PF_COS_REF] * cosT - pf.f[PF_SIN_REF] * sinT;
+                double sin_gl = pf.f[PF_SIN_REF] * cosT + pf.f[PF_COS_REF] * sinT;
                 RP_STAMP(5);   // atan + carry
 
                 // -- curvature, velocity, acceleration (:883-896)
@@ -1197,13 +1205,11 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int ll = L - 1 - base;
                 const bool take = (ll >= 0 && ll < G);     // this chunk holds the last valid state
                 if (__any(take && L < n)) {                // wave-uniform: park the last valid state in LDS
-                    double sn, cs;
-                    rp_sincos(th_gl, &sn, &cs);
                     if (take && gl == ll) {
                         double *o = gs_last;
                         o[0] = x; o[1] = y; o[2] = th_gl; o[3] = v; o[4] = acc; o[5] = kappa; o[6] = kdot;
                         o[7] = s; o[8] = d; o[9] = th_cl; o[10] = sd; o[11] = sdd; o[12] = dd; o[13] = ddd;
-                        o[14] = cs; o[15] = sn;
+                        o[14] = cos_gl; o[15] = sin_gl;
                     }
                 }
                 if (!ONE_CHUNK && c + 1 < nchunks) {
@@ -1226,6 +1232,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         x = o[0] + scx;
                         y = o[1] + scy;
                         th_gl = o[2];                                  // :188
+                        cos_gl = o[14];
+                        sin_gl = o[15];
                         const double sv = o[10] + tk * 0.0;            // :313, s_ddot[-1] is the zero padding
                         const double e_sd = sv * (sv >= 0.0 ? 1.0 : 0.0);   // :315
                         const double e_dd = o[12] + tk * 0.0;          // :319
@@ -1263,13 +1271,16 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (COLL) {
                     const bool want = live && alive && fail_step < 0 && ood_step < 0;
                     bool hit = false;
-                    if (__any(want)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
-                        double sn, cn;
-                        rp_sincos(th_gl, &sn, &cn);
+                    // With the broad-phase masks of the (pair, step) profile a pose whose masks are empty has nothing to be
+                    // tested against: the whole query (sin / cos of the heading, ego rectangle, walks) is skipped unless some
+                    // lane of the wavefront has a bit set.  (Few obstacles: most wavefronts skip it at most steps.)
+                    const bool masked = !COEFFS_IN && a.use_near_mask != 0;
+                    const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]), near_sta = double_as_mask(pf.f[PF_NEAR_S]);
+                    const bool ask = want && (!masked || (near_dyn | near_sta) != 0);
+                    if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
                         const ObsTables &ob = a.obs;
-                        const Obb ego = {x + a.wb_rear_axle * cn, y + a.wb_rear_axle * sn, cn, sn, a.half_length, a.half_width};
-                        hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, want, !COEFFS_IN && a.use_near_mask != 0,
-                                            double_as_mask(pf.f[PF_NEAR]), double_as_mask(pf.f[PF_NEAR_S])) && want;
+                        const Obb ego = {x + a.wb_rear_axle * cos_gl, y + a.wb_rear_axle * sin_gl, cos_gl, sin_gl, a.half_length, a.half_width};
+                        hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, masked, near_dyn, near_sta) && ask;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }

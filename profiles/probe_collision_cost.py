@@ -1,0 +1,18 @@
+"""Probe: evaluation-kernel time with and without the collision test (RP_FLAG_SKIP_COLLISION) on a workload."""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")]
+from commonroad_rp_amd import workloads as W
+from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, FLAG_SKIP_COLLISION
+for name in sys.argv[1:] or ["cfg2", "cfg4"]:
+    w = W.WORKLOADS[name]()
+    ctx = RpContext(0); w.setup(ctx); ctx.set_profiling(True)
+    for label, extra in (("with collision test", 0), ("without", FLAG_SKIP_COLLISION)):
+        for mode, mflags in (("draw", FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL), ("fused", 0)):
+            p = copy_params(w.inputs.params); p.flags |= mflags | extra
+            inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
+            for _ in range(5): ctx.plan(inp)
+            ks = [ctx.plan(inp).kernel_ms for _ in range(30 if w.n_candidates < 100000 else 8)]
+            print(f"{name} {mode:5s} {label:20s} eval kernel {np.median(ks) * 1e3:9.1f} us")
+    ctx.close()
