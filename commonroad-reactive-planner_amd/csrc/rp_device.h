@@ -357,16 +357,17 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 }
 
 // cc.collide(ego pose at scenario time index t)  (reactive_planner.py:1040-1042).
-// `want`: this lane asks; `masked` (wave-uniform): `near` / `near_static` hold this lane's (pair, step) masks of dynamic
+// `want`: this lane asks; MASKED (a property of the kernel variant): `near` / `near_static` hold this lane's (pair, step) masks of dynamic
 // obstacles / static-shape clusters (rp_kernels.h: near_mask_step); otherwise every shape is tested (static shapes
 // after a wave-level bounding-circle rejection).
 // Per lane, a bounding-circle rejection comes before the exact test (conservative: a small relative margin keeps
 // it from ever rejecting a pair the exact test would accept).
-__device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, bool masked,
-                                              uint64_t near, uint64_t near_static) {
+template <bool MASKED>
+__device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
+                                              uint64_t near_static) {
     bool hit = false;
     const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
-    if (masked) {
+    if (MASKED) {
         // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
         // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
         // per-lane gathers, no dependent vector-memory round trips), every lane runs the cheap rejection test
@@ -445,7 +446,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     const bool k_ok = want && k >= 0 && k < ob.n_steps;
     const int kc = k_ok ? k : 0;
     const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
-    if (!masked) {
+    if (!MASKED) {
         if (__any(k_ok)) {
 #pragma unroll 4
             for (int j = 0; j < ob.n_dyn; ++j) {

@@ -28,7 +28,6 @@ constexpr int kBlocksPerCU = 4;           // workgroups per CU of the grid-strid
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
 constexpr int kFoldThreshold = 2048;
 constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass
-constexpr int kNearMaskMinObstacles = 0;  // (pair, step) broad phase of the collision query above this many dynamic obstacles
                                           // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
 
@@ -835,8 +834,9 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     ka.lat_dmin = ka.lat_dmax = g->nD > 0 ? g->D[0] : 0.0;
     for (int i = 1; i < g->nD; ++i) { ka.lat_dmin = std::min(ka.lat_dmin, g->D[i]); ka.lat_dmax = std::max(ka.lat_dmax, g->D[i]); }
     ka.lat_abs_d = std::max(std::fabs(p->x0_lat[0]), std::max(std::fabs(ka.lat_dmin), std::fabs(ka.lat_dmax)));
-    if (!(ka.lat_abs_d < 1e300)) ka.use_near_mask = 0;   // NaN / inf samples: no bound
-    if (c->obs.n_dyn <= kNearMaskMinObstacles && c->obs.n_clus == 0) ka.use_near_mask = 0;
+    // (NaN / inf samples: pair_step_bound reports "no bound" and the masks come out all ones.  The evaluation kernels of grid
+    //  plans always take the masked query: use_near_mask only tells the profile kernels whether there is anything to mask.)
+    if (c->obs.n_dyn <= 0 && c->obs.n_clus == 0) ka.use_near_mask = 0;
     c->have_last = false;
     rc = run_pipeline(c, ka, mat, false, false, result, best_states);
     if (rc != RP_OK) return rc;

@@ -538,6 +538,7 @@ struct BoundIn {
 // circle (cx, cy, R) that contains the ego rectangle of every candidate of the pair at step i; false: no bound
 __device__ __forceinline__ bool pair_step_bound(const KArgs &a, int i, const BoundIn &in, double &cx, double &cy, double &R) {
     const int L = in.L;
+    if (!(a.lat_abs_d < 1e300)) return false;                                   // NaN / inf lateral samples
     if (!(fabs((double)(L - 1) * a.dt - in.T) <= 1e-9 * in.T)) return false;   // T is not the last valid step
     const double wb = fabs(a.wb_rear_axle);
     if (i < L) {
@@ -1274,13 +1275,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     // With the broad-phase masks of the (pair, step) profile a pose whose masks are empty has nothing to be
                     // tested against: the whole query (sin / cos of the heading, ego rectangle, walks) is skipped unless some
                     // lane of the wavefront has a bit set.  (Few obstacles: most wavefronts skip it at most steps.)
-                    const bool masked = !COEFFS_IN && a.use_near_mask != 0;
+                    constexpr bool masked = !COEFFS_IN;   // (the host keeps use_near_mask set for grid plans with obstacles; a pair
+                                                          //  without a bound gets all-ones masks)
                     const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]), near_sta = double_as_mask(pf.f[PF_NEAR_S]);
                     const bool ask = want && (!masked || (near_dyn | near_sta) != 0);
                     if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
                         const ObsTables &ob = a.obs;
                         const Obb ego = {x + a.wb_rear_axle * cos_gl, y + a.wb_rear_axle * sin_gl, cos_gl, sin_gl, a.half_length, a.half_width};
-                        hit = pose_collides(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, masked, near_dyn, near_sta) && ask;
+                        hit = pose_collides<masked>(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }
@@ -1416,7 +1418,7 @@ __global__ __launch_bounds__(64) void rp_swept_kernel(ObsTables ob, const double
     }
     // one radius for the wavefront (the rejection tests of pose_collides take a wave-uniform bound)
     const double r = (double)wave_max_f32(want ? (float)sqrt(m.hl * m.hl + m.hw * m.hw) : 0.f) * 1.000001;
-    const bool hit = pose_collides(ob, m, r, t0 + i, want, false, 0, 0);
+    const bool hit = pose_collides<false>(ob, m, r, t0 + i, want, 0, 0);
     if (want && hit) atomicMin(first_hit, i);
 }
 
