@@ -357,17 +357,18 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 }
 
 // cc.collide(ego pose at scenario time index t)  (reactive_planner.py:1040-1042).
+// STATIC: the obstacle tables hold static shapes (else that half of the query is not compiled in).
 // `want`: this lane asks; MASKED (a property of the kernel variant): `near` / `near_static` hold this lane's (pair, step) masks of dynamic
 // obstacles / static-shape clusters (rp_kernels.h: near_mask_step); otherwise every shape is tested (static shapes
 // after a wave-level bounding-circle rejection).
 // Per lane, a bounding-circle rejection comes before the exact test (conservative: a small relative margin keeps
 // it from ever rejecting a pair the exact test would accept).
-template <bool MASKED>
+template <bool MASKED, bool STATIC>
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
                                               uint64_t near_static) {
     bool hit = false;
     const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
-    if (MASKED) {
+    if (MASKED && STATIC) {
         // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
         // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
         // per-lane gathers, no dependent vector-memory round trips), every lane runs the cheap rejection test
@@ -414,7 +415,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
             }
             kind = nkind; first = nfirst; count = ncount;
         }
-    } else {
+    } else if (STATIC) {
     WaveBound wb = {0.0, 0.0, 0.0};
     if (ob.n_sobb + ob.n_tri + ob.n_circ > 0) wb = ego_wave_bound(want, ego.cx, ego.cy, ego_r);   // wave-uniform
     for (int j = 0; j < ob.n_sobb; ++j) {

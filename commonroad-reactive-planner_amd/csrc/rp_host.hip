@@ -175,7 +175,14 @@ void launch_kargs(rp_ctx *c, const void *kernel, int grid, int block, size_t lds
     }
 }
 
-template <int G, bool MAT, bool CIN, bool COLL, bool STAGE>
+// Kernel variant by obstacle content: 0 no collision test, 1 dynamic obstacles only, 2 static shapes as well (the walks over
+// static shapes are a large part of the query code; workloads without any do not carry them)
+int collision_level(const KArgs &ka) {
+    if (!ka.has_obstacles || (ka.flags & RP_FLAG_SKIP_COLLISION)) return 0;
+    return (ka.obs.n_sobb + ka.obs.n_tri + ka.obs.n_circ) > 0 ? 2 : 1;
+}
+
+template <int G, bool MAT, bool CIN, int COLL, bool STAGE>
 void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
     if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE, false>, grid, RP_BLOCK, lds, ka);
     else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE, false>, grid, RP_BLOCK, lds, ka);
@@ -204,7 +211,7 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     return (bytes + 15) & ~(size_t)15;
 }
 
-template <bool MAT, bool CIN, bool COLL>
+template <bool MAT, bool CIN, int COLL>
 void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
     constexpr int G = kFusedLonG;
     if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
@@ -213,9 +220,10 @@ void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
 
 template <bool MAT, bool CIN>
 void launch_eval_fused_t(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
-    const bool coll = ka.has_obstacles && !(ka.flags & RP_FLAG_SKIP_COLLISION);
-    if (coll) launch_eval_fused_c<MAT, CIN, true>(c, ka, grid, lds);
-    else launch_eval_fused_c<MAT, CIN, false>(c, ka, grid, lds);
+    const int coll = collision_level(ka);
+    if (coll == 2) launch_eval_fused_c<MAT, CIN, 2>(c, ka, grid, lds);
+    else if (coll == 1) launch_eval_fused_c<MAT, CIN, 1>(c, ka, grid, lds);
+    else launch_eval_fused_c<MAT, CIN, 0>(c, ka, grid, lds);
 }
 
 void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, size_t lds) {
@@ -223,7 +231,7 @@ void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin,
     else     { if (cin) launch_eval_fused_t<false, true>(c, ka, grid, lds); else launch_eval_fused_t<false, false>(c, ka, grid, lds); }
 }
 
-template <int G, bool MAT, bool CIN, bool COLL>
+template <int G, bool MAT, bool CIN, int COLL>
 void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
     const bool stage = MAT && !ka.single_index && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
@@ -233,9 +241,10 @@ void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
 
 template <int G, bool MAT, bool CIN>
 void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
-    const bool coll = ka.has_obstacles && !(ka.flags & RP_FLAG_SKIP_COLLISION);
-    if (coll) launch_eval_tc<G, MAT, CIN, true>(c, ka, grid);
-    else launch_eval_tc<G, MAT, CIN, false>(c, ka, grid);
+    const int coll = collision_level(ka);
+    if (coll == 2) launch_eval_tc<G, MAT, CIN, 2>(c, ka, grid);
+    else if (coll == 1) launch_eval_tc<G, MAT, CIN, 1>(c, ka, grid);
+    else launch_eval_tc<G, MAT, CIN, 0>(c, ka, grid);
 }
 
 // Lanes per candidate.  The time axis is cut into step blocks of G lanes; fewer lanes per candidate

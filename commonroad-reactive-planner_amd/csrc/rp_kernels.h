@@ -790,7 +790,7 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
 // gridDim.x * GPB >= count): the workgroup first computes the longitudinal profiles of the (at most
 // a.lds_pairs) pairs its own candidates belong to into LDS -- the work of rp_lon_kernel without the
 // launch, the global round trip of the profile rows and the kernel boundary.
-template <int G, bool MAT, bool COEFFS_IN, bool COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
+template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
 __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
@@ -938,6 +938,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     if (m) atomicOr(mask_word(it, PF_NEAR), m);
                 }
                 uint64_t ms = 0;
+                if (COLL == 2)
                 for (int r = sub; r < slots; r += lanes_per_item) {
                     const int c = (int)((uint32_t)r / (uint32_t)per), mem = r - c * per;
                     if (mem < info[4 * c + 2] && static_shape_near(ob, info[4 * c], info[4 * c + 1] + mem, bx, by, bR)) ms |= 1ull << c;
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
                         const ObsTables &ob = a.obs;
                         const Obb ego = {x + a.wb_rear_axle * cos_gl, y + a.wb_rear_axle * sin_gl, cos_gl, sin_gl, a.half_length, a.half_width};
-                        hit = pose_collides<masked>(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
+                        hit = pose_collides<masked, COLL == 2>(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }
@@ -1418,7 +1419,7 @@ __global__ __launch_bounds__(64) void rp_swept_kernel(ObsTables ob, const double
     }
     // one radius for the wavefront (the rejection tests of pose_collides take a wave-uniform bound)
     const double r = (double)wave_max_f32(want ? (float)sqrt(m.hl * m.hl + m.hw * m.hw) : 0.f) * 1.000001;
-    const bool hit = pose_collides<false>(ob, m, r, t0 + i, want, 0, 0);
+    const bool hit = pose_collides<false, true>(ob, m, r, t0 + i, want, 0, 0);
     if (want && hit) atomicMin(first_hit, i);
 }
 
