@@ -720,10 +720,13 @@ __device__ __forceinline__ void st_row(double *p, double v) {
 struct ProfStep { double f[PF_FIELDS]; };
 
 // rows of one profile step: wave-uniform base + 32-bit byte offset per lane (one scalar-operand add per row)
+template <int FIELDS = PF_FIELDS>   // the first FIELDS rows (kernels without a collision query do not read cos / sin of theta_ref)
 __device__ __forceinline__ ProfStep load_profile(const char *base, uint32_t off8, uint32_t n8) {
     ProfStep p;
 #pragma unroll
-    for (int k = 0; k < PF_FIELDS; ++k) p.f[k] = *reinterpret_cast<const double *>(base + (size_t)(off8 + (uint32_t)k * n8));
+    for (int k = 0; k < FIELDS; ++k) p.f[k] = *reinterpret_cast<const double *>(base + (size_t)(off8 + (uint32_t)k * n8));
+#pragma unroll
+    for (int k = FIELDS; k < PF_FIELDS; ++k) p.f[k] = 0.0;
     return p;
 }
 
@@ -804,6 +807,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int gbase = lane & ~(G - 1);    // first lane of the group inside the wave
     constexpr int GPB = RP_BLOCK / G;     // groups per block
     constexpr int GPW = 64 / G;           // groups per wave
+    constexpr int PFN = COLL ? PF_FIELDS : PF_COS_REF;   // profile rows this variant reads
     const int wave_in_block = tid >> 6;
     const int group_in_wave = gbase / G;
     const int grp = tid / G;              // group inside the block
@@ -960,7 +964,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             cin.L = h.L;
             cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
                              : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
-            pf0 = load_profile(reinterpret_cast<const char *>(lds_prof), (uint32_t)cin.pair_slot * PF_FIELDS * (uint32_t)n0 * 8u + (uint32_t)(gl <= a.N ? gl : a.N) * 8u,
+            pf0 = load_profile<PFN>(reinterpret_cast<const char *>(lds_prof), (uint32_t)cin.pair_slot * PF_FIELDS * (uint32_t)n0 * 8u + (uint32_t)(gl <= a.N ? gl : a.N) * 8u,
                                (uint32_t)n0 * 8u);
         }
     } else {
@@ -971,7 +975,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int32_t ps0 = (int32_t)((COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0);
         const int32_t pw0 = __builtin_amdgcn_readfirstlane(ps0);   // pair of the wavefront's first candidate (wave-uniform)
         const uint32_t n80 = (uint32_t)(a.N + 1) * 8u;
-        pf0 = load_profile(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
+        pf0 = load_profile<PFN>(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
                            (uint32_t)(ps0 - pw0) * PF_FIELDS * n80 + (uint32_t)(gl <= a.N ? gl : a.N) * 8u, n80);
     }
 
@@ -1071,7 +1075,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const bool act = i < L;
 
                 // -- this step of the pair's longitudinal profile (coalesced: lanes = consecutive steps)
-                if (!ONE_CHUNK && c > 0) pf = load_profile(pbase, poff8 + (uint32_t)(live ? i : N) * 8u, n8p);   // dead lanes clamp into the rows
+                if (!ONE_CHUNK && c > 0) pf = load_profile<PFN>(pbase, poff8 + (uint32_t)(live ? i : N) * 8u, n8p);   // dead lanes clamp into the rows
                 double s = pf.f[PF_S], sd = pf.f[PF_SD], sdd = pf.f[PF_SDD];
                 const double inv_sd = pf.f[PF_INV_SD], th_ref = pf.f[PF_TH_REF];
                 const double k_r = pf.f[PF_KR], k_r_d = pf.f[PF_KRD];
@@ -1131,7 +1135,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     secT = use_atan ? secT : sc;
                     tanT = use_atan ? tanT : sn * sc;
                 }
-                // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref
+                // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref (variants with a
+                // collision query; the others need them for one lane per candidate only, where the extension starts)
                 const double sinT = tanT * cosT;
                 double cos_gl = pf.f[PF_COS_REF] * cosT - pf.f[PF_SIN_REF] * sinT;
                 double sin_gl = pf.f[PF_SIN_REF] * cosT + pf.f[PF_COS_REF] * sinT;
@@ -1207,6 +1212,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int ll = L - 1 - base;
                 const bool take = (ll >= 0 && ll < G);     // this chunk holds the last valid state
                 if (__any(take && L < n)) {                // wave-uniform: park the last valid state in LDS
+                    if (!COLL) rp_sincos(th_gl, &sin_gl, &cos_gl);
                     if (take && gl == ll) {
                         double *o = gs_last;
                         o[0] = x; o[1] = y; o[2] = th_gl; o[3] = v; o[4] = acc; o[5] = kappa; o[6] = kdot;
