@@ -26,6 +26,9 @@
 #ifndef RP_WRITE_THROUGH
 #define RP_WRITE_THROUGH 1   // single-launch variant: agent-scope write-through stores of the state rows (see st_row)
 #endif
+#ifndef RP_LATE_KERNARGS
+#define RP_LATE_KERNARGS 1   // single-launch variant: kernel arguments of the step loop are loaded after the prologue
+#endif
 #ifndef RP_WAVES_PER_SIMD
 #define RP_WAVES_PER_SIMD 3  // register budget of the evaluation kernel: 512 / 3 -> 168 VGPRs.  One wavefront issues
                              // an instruction only every ~10-13 cycles (profiles/r01_instruction_costs.txt), so the
@@ -986,12 +989,22 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     }
     RP_STAMP(1);
 
-    const int N = a.N, n = N + 1;
+    // The kernel arguments of everything below are read through a pointer the compiler cannot see through: the loads
+    // then happen HERE, after the prologue, instead of at kernel entry -- where the values would be live across the
+    // prologue of the single-launch variant, lose their scalar registers to it and be reloaded (v_readlane) at every use
+    // in the step loop.
+    typedef const KArgs __attribute__((address_space(4))) *kargs_cptr;
+    // (the kernarg segment itself -- KArgs is the kernel's only explicit argument, at offset 0; `&a` would make the compiler
+    //  materialise a private copy of the by-value struct)
+    kargs_cptr ap_late = (kargs_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    if (RP_LATE_KERNARGS && LON_FUSED) asm volatile("" : "+s"(ap_late));
+    const KArgs __attribute__((address_space(4))) &al = *ap_late;
+    const int N = al.N, n = N + 1;
     const int nchunks = ONE_CHUNK ? 1 : (n + G - 1) / G;
-    const double dt = a.dt;
-    const bool draw = (a.flags & RP_FLAG_DRAW_ALL) != 0;
-    const bool low = a.low_vel_mode != 0;
-    const uint32_t cm = a.constraint_mask;
+    const double dt = al.dt;
+    const bool draw = (al.flags & RP_FLAG_DRAW_ALL) != 0;
+    const bool low = al.low_vel_mode != 0;
+    const uint32_t cm = al.constraint_mask;
     const int mid = n / 2;  // int(len(v) / 2), cost_function.py:59
     double *const gs_poly = sh_grp[grp].poly;
     double *const gs_last = sh_grp[grp].last;
@@ -1000,18 +1013,18 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     // every lane adds its own step, the lanes holding steps N and N/2 also add the terminal terms
     auto cost_terms = [&](int i, double acc, double v, double s, double d, double th_cl) -> double {
         double e, cst;
-        e = a.w_a * acc; cst = e * e;
-        e = 0.25 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+        e = al.w_a * acc; cst = e * e;
+        e = 0.25 * (al.desired_d - d); cst = __builtin_fma(e, e, cst);
         e = 0.25 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
-        if (a.has_speed) { e = 5.0 * (v - a.desired_speed); cst = __builtin_fma(e, e, cst); }
-        if (a.has_s) { e = 0.25 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        if (al.has_speed) { e = 5.0 * (v - al.desired_speed); cst = __builtin_fma(e, e, cst); }
+        if (al.has_s) { e = 0.25 * (al.desired_s - s); cst = __builtin_fma(e, e, cst); }
         if (i == N) {
-            e = 20.0 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+            e = 20.0 * (al.desired_d - d); cst = __builtin_fma(e, e, cst);
             e = 5.0 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
-            if (a.has_speed) { e = v - a.desired_speed; cst += 50.0 * (e * e); }
-            if (a.has_s) { e = 20.0 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+            if (al.has_speed) { e = v - al.desired_speed; cst += 50.0 * (e * e); }
+            if (al.has_s) { e = 20.0 * (al.desired_s - s); cst = __builtin_fma(e, e, cst); }
         }
-        if (i == mid && a.has_speed) { e = v - a.desired_speed; cst += 100.0 * (e * e); }
+        if (i == mid && al.has_speed) { e = v - al.desired_speed; cst += 100.0 * (e * e); }
         return cst;
     };
 
@@ -1022,14 +1035,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
         const bool valid = slot < count;
         // (lanes without a candidate shadow the first candidate of their wavefront, whose profile rows exist)
-        const int64_t gidx = a.single_index ? *a.single_index : a.cand_begin + (valid ? slot : w0);
+        const int64_t gidx = al.single_index ? *al.single_index : al.cand_begin + (valid ? slot : w0);
 
         // ---- lateral polynomial: sampling.py:226-238, 268-270
         const int L = cin.L;
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
-        const int32_t pair_slot_ = (int32_t)((COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)a.nD)) - pair0);
+        const int32_t pair_slot_ = (int32_t)((COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)al.nD)) - pair0);
         const int32_t pair_w = __builtin_amdgcn_readfirstlane(pair_slot_);   // wavefront's first candidate: wave-uniform base
         const uint32_t n8p = (uint32_t)n * 8u;
         const char *const pbase = reinterpret_cast<const char *>(prof_base + ((size_t)pair_w * PF_FIELDS) * (size_t)n);
@@ -1038,7 +1051,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         {
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
-            else lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
+            else lat = quintic_coeffs(al.x0_lat[0], al.x0_lat[1], al.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
             if (gl == 0) park_poly(gs_poly, lat);   // same-wave LDS ordering makes it visible to the group
         }
         RP_STAMP(2);   // polynomial ready
@@ -1051,7 +1064,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
 
         bool alive = valid && pre_reason == RP_REASON_NONE;
         if (__ballot(alive) != 0) {   // wave-uniform
-            double theta_carry = a.x0_orientation;  // theta_gl[base-1]; at base 0 the i == 0 rule of :866
+            double theta_carry = al.x0_orientation;  // theta_gl[base-1]; at base 0 the i == 0 rule of :866
             double kappa_carry = 0.0;
             double cumx = 0.0, cumy = 0.0;
             const bool store_ok = MAT && valid && pre_reason == RP_REASON_NONE;
@@ -1060,7 +1073,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             // address per (lane, row) formed from 14 hoisted -- and spilled -- row pointers.
             char *const obase = !MAT ? nullptr
                                 : (STAGE_OUT ? reinterpret_cast<char *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n)
-                                             : reinterpret_cast<char *>(a.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n));
+                                             : reinterpret_cast<char *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n));
             const uint32_t n8 = (uint32_t)n * 8u;
             const uint32_t lane_off8 = (uint32_t)group_in_wave * RP_N_ARRAYS * n8;   // this group's candidate inside the wavefront
             auto row_at = [&](uint32_t off8, int row) -> double * {
@@ -1161,15 +1174,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
                 uint32_t reason = RP_REASON_NONE;
                 if (act) {
-                    const double wk = a.wheelbase * kappa;
+                    const double wk = al.wheelbase * kappa;
                     // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
-                    const bool bad_yaw = fabs(rint(dth * a.c_yaw)) > a.kappa_max * v * 1e5;
+                    const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > al.kappa_max * v * 1e5;
                     // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
-                    const bool bad_kd = fabs(kdot) > a.c_kdot * __builtin_fma(wk, wk, 1.0);
+                    const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
                     // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
-                    const bool ok_acc = (-a.a_max <= acc) && (v > a.v_switch ? acc * v <= a.a_max * a.v_switch : acc <= a.a_max);
+                    const bool ok_acc = (-al.a_max <= acc) && (v > al.v_switch ? acc * v <= al.a_max * al.v_switch : acc <= al.a_max);
                     if ((cm & RP_CHECK_VELOCITY) && v < -RP_EPS) reason = RP_REASON_VELOCITY;
-                    else if ((cm & RP_CHECK_KAPPA) && fabs(kappa) > a.kappa_max) reason = RP_REASON_KAPPA;
+                    else if ((cm & RP_CHECK_KAPPA) && fabs(kappa) > al.kappa_max) reason = RP_REASON_KAPPA;
                     else if ((cm & RP_CHECK_YAW_RATE) && bad_yaw) reason = RP_REASON_YAW_RATE;
                     else if ((cm & RP_CHECK_KAPPA_DOT) && bad_kd) reason = RP_REASON_KAPPA_DOT;
                     else if ((cm & RP_CHECK_ACCELERATION) && !ok_acc) reason = RP_REASON_ACCELERATION;
@@ -1185,7 +1198,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 RP_STAMP(7);   // constraints + first-failure vote
 
                 // -- (s, d) -> (x, y) = foot point + d * unit normal, reactive_planner.py:908-917
-                const bool in_dom = s_in_dom && fabs(d) <= a.proj_d_limit;
+                const bool in_dom = s_in_dom && fabs(d) <= al.proj_d_limit;
                 double x = px + d * nx, y = py + d * ny;
                 if (__any(act && !in_dom) || ood_step >= 0) {   // wave-uniform ("ood_step" alone is group-uniform: harmless)
                     const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
@@ -1287,9 +1300,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]), near_sta = double_as_mask(pf.f[PF_NEAR_S]);
                     const bool ask = want && (!masked || (near_dyn | near_sta) != 0);
                     if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
-                        const ObsTables &ob = a.obs;
-                        const Obb ego = {x + a.wb_rear_axle * cos_gl, y + a.wb_rear_axle * sin_gl, cos_gl, sin_gl, a.half_length, a.half_width};
-                        hit = pose_collides<masked, COLL == 2>(ob, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
+                        ObsTables ob;   // (copied out of the constant address space, member by member)
+                        ob.sobb = al.obs.sobb; ob.tri = al.obs.tri; ob.circ = al.obs.circ; ob.dyn = al.obs.dyn;
+                        ob.clus = al.obs.clus; ob.clus_info = al.obs.clus_info;
+                        ob.n_sobb = al.obs.n_sobb; ob.n_tri = al.obs.n_tri; ob.n_circ = al.obs.n_circ; ob.n_dyn = al.obs.n_dyn;
+                        ob.n_steps = al.obs.n_steps; ob.dyn_t0 = al.obs.dyn_t0; ob.n_clus = al.obs.n_clus; ob.clus_per = al.obs.clus_per;
+                        const Obb ego = {x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl, cos_gl, sin_gl, al.half_length, al.half_width};
+                        hit = pose_collides<masked, COLL == 2>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask, near_dyn, near_sta) && ask;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }
@@ -1304,7 +1321,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             if (okmask) {
                 const int blk2 = (RP_N_ARRAYS * n) >> 1;             // double2 pieces per candidate (14 n is even)
                 const double2 *src = reinterpret_cast<const double2 *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n);
-                double2 *dst = reinterpret_cast<double2 *>(a.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n);
+                double2 *dst = reinterpret_cast<double2 *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n);
                 for (int k = lane; k < GPW * blk2; k += 64) {
                     const int cand = k / blk2;
                     if ((okmask >> (cand * G)) & 1ull) RP_COPY_OUT_STORE(dst + k, src[k]);
@@ -1328,8 +1345,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         double cost = group_sum_last<G>(cost_acc);
         if (decided_bad) cost = __builtin_nan("");
         if (valid && gl == G - 1) {
-            a.status[slot] = status;
-            a.cost[slot] = cost;
+            al.status[slot] = status;
+            al.cost[slot] = cost;
             const uint32_t lab = RP_STATUS_LABEL(status), rs = RP_STATUS_REASON(status);
             if (rs) atomicAdd(&sh_cnt[2 + rs], 1);
             if (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION) atomicAdd(&sh_cnt[0], 1);
@@ -1344,7 +1361,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     RP_STAMP(13);  // cost reduction + status written
 
     // ---- block partial: lexicographic (cost, index) min + counters ----
-    if (a.partials) {
+    if (al.partials) {
         __syncthreads();
         if (tid == 0) {
             BlockPartial bp;
@@ -1359,15 +1376,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             bp.n_feasible = sh_cnt[0];
             bp.n_collision = sh_cnt[1];
             for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
-            a.partials[blockIdx.x] = bp;
+            al.partials[blockIdx.x] = bp;
         }
     }
     RP_STAMP(14);
     RP_TL(1);
-    if (a.single_index && a.host_seq) {   // winner re-evaluation (one workgroup): ticket after the state rows
+    if (al.single_index && al.host_seq) {   // winner re-evaluation (one workgroup): ticket after the state rows
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(al.host_seq, al.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
