@@ -996,7 +996,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     typedef const KArgs __attribute__((address_space(4))) *kargs_cptr;
     // (the kernarg segment itself -- KArgs is the kernel's only explicit argument, at offset 0; `&a` would make the compiler
     //  materialise a private copy of the by-value struct)
-    kargs_cptr ap_late = (kargs_cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    // Variants that write no state rows and have no long prologue keep the plain argument accesses (entry-block loads):
+    // they spilled little to begin with and lose 2 % to the later loads (cfg5 production mode 1.126 -> 1.155 ms).
+    kargs_cptr ap_late = (LON_FUSED || MAT) ? (kargs_cptr)__builtin_amdgcn_kernarg_segment_ptr() : (kargs_cptr)&a;
     if (RP_LATE_KERNARGS && LON_FUSED) asm volatile("" : "+s"(ap_late));
     const KArgs __attribute__((address_space(4))) &al = *ap_late;
     const int N = al.N, n = N + 1;
