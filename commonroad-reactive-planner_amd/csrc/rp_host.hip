@@ -86,6 +86,7 @@ struct rp_ctx {
     unsigned long long t_calls = 0;
     bool t_warm = false;
     std::chrono::steady_clock::time_point t_entry;
+    int last_G = 0;              // lanes per candidate of the last plan
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
     std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
@@ -255,11 +256,15 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
         int g = std::atoi(e);
         if (g == 16 || g == 32 || g == 64) return g;
     }
-    (void)c; (void)count;
     // measured on MI355X (profiles/r01_lanes_per_candidate.txt): without state rows 16 lanes per candidate
     // win at every horizon; with state rows long horizons want whole-wavefront rows (512-byte runs)
     if (!mat) return 16;
-    return (N + 1 <= 32) ? 16 : 64;
+    if (N + 1 <= 32) return 16;
+    // up to 64 steps (the reference's default horizon, N = 60): one wavefront per candidate as long as that is at most
+    // ~4 wavefronts per SIMD; beyond, and while the single-launch variant still applies, 16 lanes (4 candidates per
+    // wavefront, 4 step blocks) are 10 % faster (6 000 candidates: 68 vs 75 us per step; 2 600: equal; 400: 43 vs 60)
+    if (N + 1 <= 64 && count > (int64_t)c->num_cus * 16 && count <= (int64_t)fused_lon_max_blocks(c) * (RP_BLOCK / kFusedLonG)) return 16;
+    return 64;
 }
 
 template <int G>
@@ -403,12 +408,14 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
     ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
     const int64_t count = ka.count;
-    const int G = lanes_per_candidate(c, ka.N, count, mat);
+    int G = lanes_per_candidate(c, ka.N, count, mat);
     // small batches: one launch computes the longitudinal profiles and evaluates (rp_eval_kernel<.., LON_FUSED>)
     int fused_pairs = 0;
     const size_t fused_lds = (skip_eval || std::getenv("RP_AMD_NO_FUSED_LON")) ? 0 : fused_lon_lds(c, ka, count, G, cin, &fused_pairs);
+    // (16 lanes per candidate for mid-size batches of up to 64 steps only pay in the single-launch variant)
+    if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
     ka.lds_pairs = fused_pairs;
-    if (!skip_eval) c->last_fused_lds = fused_lds;
+    if (!skip_eval) { c->last_fused_lds = fused_lds; c->last_G = G; }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
     if (grid > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
@@ -940,7 +947,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.pair_count = 1;
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
-    const int G1 = lanes_per_candidate(c, kw.N, 1, true);
+    const int G1 = c->last_G ? c->last_G : lanes_per_candidate(c, kw.N, 1, true);   // the batch's choice: same code path, same bits
     if (c->last_fused_lds && G1 == kFusedLonG) {   // same code path as the batch: results agree bit for bit
         launch_eval_fused(c, kw, 1, true, c->last_coeffs, c->last_fused_lds);
     } else {
