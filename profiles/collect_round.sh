@@ -7,6 +7,7 @@ ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 python3 bench.py > $OUT/${TAG}_bench_cfg2.json 2> $OUT/bench_cfg2.err
+python3 bench.py --workload cfg1 --cpu-seconds 6 > $OUT/${TAG}_bench_cfg1.json 2> $OUT/bench_cfg1.err
 for wl in cfg3 cfg4 cfg5; do
   python3 bench.py --workload $wl --steps 20 --warmup 3 --cpu-seconds 6 > $OUT/${TAG}_bench_$wl.json 2> $OUT/bench_$wl.err
 done
