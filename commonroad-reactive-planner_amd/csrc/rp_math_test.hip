@@ -136,3 +136,41 @@ extern "C" double rpt_ubench(int which, int waves, int iters) {
     for (int w = 0; w < waves; ++w) sum += (double)h[w];
     return sum / waves / (64.0 * iters);
 }
+
+// What a hipEvent bracket adds to a short kernel (diagnostic for bench.py's roofline.kernel_ms): median elapsed time, in
+// microseconds, between two events recorded on one stream with (a) nothing, (b) one kernel that spins for `spin_us` on the
+// 100 MHz constant clock between them.  out[0] = (a), out[1] = (b).
+__global__ void k_spin(unsigned long long ticks, unsigned long long *sink) {
+    unsigned long long t0, t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    do {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    } while (t1 - t0 < ticks);
+    if (threadIdx.x == 0 && blockIdx.x == 0) *sink = t1 - t0;
+}
+extern "C" int rpt_event_bracket(double spin_us, int reps, double *out) {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    unsigned long long *d_sink = nullptr;
+    if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    if (hipMalloc(&d_sink, 8) != hipSuccess) return -1;
+    const unsigned long long ticks = (unsigned long long)(spin_us * 100.0);
+    for (int mode = 0; mode < 2; ++mode) {
+        double acc[64];
+        const int n = reps < 64 ? reps : 64;
+        for (int r = 0; r < n + 3; ++r) {
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, 100ull, d_sink);   // some earlier work on the stream, as in a step
+            hipEventRecord(e0, st);
+            if (mode == 1) hipLaunchKernelGGL(k_spin, dim3(465), dim3(256), 0, st, ticks, d_sink);
+            hipEventRecord(e1, st);
+            hipStreamSynchronize(st);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (r >= 3) acc[r - 3] = ms * 1e3;
+        }
+        for (int i = 1; i < n; ++i) { double v = acc[i]; int j = i - 1; while (j >= 0 && acc[j] > v) { acc[j + 1] = acc[j]; --j; } acc[j + 1] = v; }
+        out[mode] = acc[n / 2];
+    }
+    hipFree(d_sink); hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(st);
+    return 0;
+}
