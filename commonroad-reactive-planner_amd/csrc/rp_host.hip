@@ -1010,22 +1010,33 @@ int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double 
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = (size_t)n_poses;
     int rc;
-    if ((rc = grow(c, c->d_user, c->cap_user, 9 * n + 2)) != RP_OK) return rc;
-    double *d_poses = c->d_user, *d_boxes = c->d_user + 3 * n;
-    int *d_hit = reinterpret_cast<int *>(c->d_user + 9 * n);
-    HIP_TRY(c, hipMemcpyAsync(d_poses, x, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_poses + n, y, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_poses + 2 * n, theta, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(d_hit, 0x7f, sizeof(int), c->stream));   // 0x7f7f7f7f: larger than any segment index
-    const int grid = (n_poses - 1 + 63) / 64;
-    hipLaunchKernelGGL(rp_swept_kernel, dim3(grid), dim3(64), 0, c->stream, c->obs, (const double *)d_poses, (int)n_poses, p->wb_rear_axle,
-                       0.5 * p->length, 0.5 * p->width, (int)p->time_step0, d_hit, boxes ? d_boxes : (double *)nullptr);
+    // poses and results go through the pinned, device-visible mirror of the result block (free between plans: rp_plan has
+    // copied its result out before it returned): 9 n doubles behind the header fit where 14 n are reserved
+    if ((rc = ensure_result(c, n_poses)) != RP_OK) return rc;
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    double *h_poses = reinterpret_cast<double *>(hrb_host + 1);
+    std::memcpy(h_poses, x, sizeof(double) * n);
+    std::memcpy(h_poses + n, y, sizeof(double) * n);
+    std::memcpy(h_poses + 2 * n, theta, sizeof(double) * n);
+    const unsigned long long seq = ++c->seq;
+    hrb_host->seq = 0;
+    hipLaunchKernelGGL(rp_swept_kernel, dim3(1), dim3(RP_SWEPT_THREADS), 0, c->stream, c->obs, (int)n_poses, p->wb_rear_axle, 0.5 * p->length,
+                       0.5 * p->width, (int)p->time_step0, reinterpret_cast<ResultBlock *>(c->h_result_dev), boxes ? 1 : 0, seq);
     HIP_TRY(c, hipGetLastError());
-    int hit = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hit, d_hit, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (boxes) HIP_TRY(c, hipMemcpyAsync(boxes, d_boxes, sizeof(double) * 6 * (n - 1), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *first_hit = hit < n_poses - 1 ? hit : -1;
+    bool done = false;
+    if (c->spin_wait) {
+        const volatile unsigned long long *flag = &hrb_host->seq;
+        const auto t_start = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
+            if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned int hit = (unsigned int)hrb_host->n_before;
+    *first_hit = hit < (unsigned int)(n_poses - 1) ? (int32_t)hit : -1;
+    if (boxes) std::memcpy(boxes, h_poses + 3 * n, sizeof(double) * 6 * (n - 1));
     return RP_OK;
 }
 

@@ -1442,25 +1442,44 @@ __global__ __launch_bounds__(64) void rp_fold_partials_kernel(const BlockPartial
 // t0 + i -- the reference's ego object starts at x_0.time_step and advances one index per pose, planning.factor does
 // not enter (:1050).  One lane per segment; first_hit receives the smallest colliding segment (atomicMin).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rp_swept_kernel(ObsTables ob, const double *poses /* [3][n]: x, y, theta */, int n, double wb_rear_axle,
-                                                      double hl, double hw, int t0, int *first_hit, double *boxes /* [n-1][6] or null */) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    const bool want = i < n - 1;
-    const int ic = want ? i : 0;
-    double s0, c0, s1, c1;
-    sincos(poses[2 * n + ic], &s0, &c0);
-    sincos(poses[2 * n + ic + 1], &s1, &c1);
-    const Obb a = {poses[ic] + wb_rear_axle * c0, poses[n + ic] + wb_rear_axle * s0, c0, s0, hl, hw};
-    const Obb b = {poses[ic + 1] + wb_rear_axle * c1, poses[n + ic + 1] + wb_rear_axle * s1, c1, s1, hl, hw};
-    const Obb m = merge_swept(a, b);
-    if (want && boxes) {
-        double *o = boxes + (size_t)i * 6;
-        o[0] = m.cx; o[1] = m.cy; o[2] = m.ux; o[3] = m.uy; o[4] = m.hl; o[5] = m.hw;
+#define RP_SWEPT_THREADS 256
+// One workgroup; poses and results live in the pinned host mirror of the result block (device-visible): no copies, no memset --
+// the kernel reads 3 n doubles over the bus, writes the first colliding segment (and the rectangles, if asked) back and hands
+// the completion ticket to the spinning host thread.  Layout behind the FinalizeOut header: poses [3][n] | boxes [n-1][6].
+__global__ __launch_bounds__(RP_SWEPT_THREADS) void rp_swept_kernel(ObsTables ob, int n, double wb_rear_axle, double hl, double hw, int t0,
+                                                                    FinalizeOut *host_out, int want_boxes, unsigned long long seq) {
+    __shared__ int sh_first;
+    const int tid = threadIdx.x;
+    const double *poses = reinterpret_cast<const double *>(host_out + 1);
+    double *boxes = const_cast<double *>(poses) + 3 * (size_t)n;
+    if (tid == 0) sh_first = 0x7fffffff;
+    __syncthreads();
+    for (int base = 0; base < n - 1; base += RP_SWEPT_THREADS) {   // (uniform trip count: pose_collides works wavefront-wide)
+        const int i = base + tid;
+        const bool want = i < n - 1;
+        const int ic = want ? i : 0;
+        double s0, c0, s1, c1;
+        sincos(poses[2 * n + ic], &s0, &c0);
+        sincos(poses[2 * n + ic + 1], &s1, &c1);
+        const Obb a = {poses[ic] + wb_rear_axle * c0, poses[n + ic] + wb_rear_axle * s0, c0, s0, hl, hw};
+        const Obb b = {poses[ic + 1] + wb_rear_axle * c1, poses[n + ic + 1] + wb_rear_axle * s1, c1, s1, hl, hw};
+        const Obb m = merge_swept(a, b);
+        if (want && want_boxes) {
+            double *o = boxes + (size_t)i * 6;
+            o[0] = m.cx; o[1] = m.cy; o[2] = m.ux; o[3] = m.uy; o[4] = m.hl; o[5] = m.hw;
+        }
+        // one radius for the wavefront (the rejection tests of pose_collides take a wave-uniform bound)
+        const double r = (double)wave_max_f32(want ? (float)sqrt(m.hl * m.hl + m.hw * m.hw) : 0.f) * 1.000001;
+        const bool hit = pose_collides<false, true>(ob, m, r, t0 + i, want, 0, 0);
+        if (want && hit) atomicMin(&sh_first, i);
     }
-    // one radius for the wavefront (the rejection tests of pose_collides take a wave-uniform bound)
-    const double r = (double)wave_max_f32(want ? (float)sqrt(m.hl * m.hl + m.hw * m.hw) : 0.f) * 1.000001;
-    const bool hit = pose_collides<false, true>(ob, m, r, t0 + i, want, 0, 0);
-    if (want && hit) atomicMin(first_hit, i);
+    __threadfence_system();   // the rectangles, before the ticket
+    __syncthreads();
+    if (tid == 0) {
+        host_out->n_before = (unsigned long long)(unsigned int)sh_first;
+        __threadfence_system();
+        __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
