@@ -154,7 +154,7 @@ def test_gpu_matches_oracle():
     ctx.set_reference(tb0.ref_pos, tb0.ref_theta, tb0.ref_curv, tb0.ref_curv_d, np.stack((tb0.ref_x, tb0.ref_y), 1), 20.0)
     hits = 0
     for trial in range(120):
-        n = int(rng.choice([2, 3, 21, 31, 64, 65, 66, 101, 130]))
+        n = int(rng.choice([2, 3, 21, 31, 64, 65, 66, 101, 130, 256, 257, 258, 1000, 4095]))   # (256 segments per pass of the kernel)
         x, y, th, t0, obs = _random_case(rng, n, n_dyn=int(rng.integers(0, 70)) if trial % 4 == 0 else int(rng.integers(0, 6)),
                                          n_static=int(rng.integers(0, 12)) if trial % 3 else 0)
         p = _params(time_step0=t0, n=n)
