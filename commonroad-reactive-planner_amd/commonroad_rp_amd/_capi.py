@@ -201,6 +201,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
         "rp_count_collisions_before": (C.c_int, [ctx, C.c_double, C.c_int64, C.POINTER(C.c_int64)]),
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
+        "rp_cost_range": (C.c_int, [ctx, dp, dp, C.POINTER(C.c_int64)]),
         "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
         "rp_mailbox_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
         "rp_mailbox_exchange": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(RpResult), dp,
@@ -221,7 +222,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
+                    "rp_cost_range", "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
 
 
 class RpContext:
@@ -338,6 +339,12 @@ class RpContext:
         self._check(self._lib.rp_count_collisions_before(self._h, float(cost), int(index), C.byref(n)),
                     "rp_count_collisions_before")
         return int(n.value)
+
+    def cost_range(self):
+        """(min, max, n) of the costs of the kinematically feasible candidates of the last plan (NaN, NaN, 0 if none)."""
+        lo, hi, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self._lib.rp_cost_range(self._h, C.byref(lo), C.byref(hi), C.byref(n)), "rp_cost_range")
+        return float(lo.value), float(hi.value), int(n.value)
 
     def check_swept(self, params: RpParams, x, y, theta, want_boxes: bool = False):
         """Continuous collision check of one trajectory (reactive_planner.py:1049-1058): first colliding segment

@@ -63,7 +63,9 @@ class GpuTrajectoryBundle:
         self.grids = grids            # (T, traj_len, L, D) or None
         self._samples = samples       # foreign sampling space: list of TrajectorySample
         self._is_sorted = False
-        self.costs: Optional[np.ndarray] = None   # per-candidate costs after _get_optimal_trajectory
+        self.costs: Optional[np.ndarray] = None   # per-candidate costs after _get_optimal_trajectory (when they were fetched)
+        self._range_fn = None         # () -> (min, max, n) of the costs on the device: min_costs() / max_costs() without a fetch
+        self._range = None
 
     @property
     def n_candidates(self) -> int:
@@ -86,13 +88,27 @@ class GpuTrajectoryBundle:
     def empty(self) -> bool:
         return self.n_candidates == 0
 
+    def _cost_range(self):
+        """(min, max) over the candidates that have a cost, or None: from the fetched costs if there are any, else from the
+        device (``rp_cost_range``, asked once, while the context still holds this bundle's plan)."""
+        if self._range is None:
+            c = self.costs
+            if c is not None:
+                self._range = (float(np.nanmin(c)), float(np.nanmax(c))) if np.any(~np.isnan(c)) else ()
+            elif self._range_fn is not None:
+                lo, hi, n = self._range_fn()
+                self._range = (lo, hi) if n > 0 else ()
+            else:
+                self._range = ()
+        return self._range or None
+
     def min_costs(self):
-        c = self.costs
-        return _CostView(np.float64(np.nanmin(c))) if c is not None and np.any(~np.isnan(c)) else None
+        r = self._cost_range()
+        return _CostView(np.float64(r[0])) if r else None
 
     def max_costs(self):
-        c = self.costs
-        return _CostView(np.float64(np.nanmax(c))) if c is not None and np.any(~np.isnan(c)) else None
+        r = self._cost_range()
+        return _CostView(np.float64(r[1])) if r else None
 
 
 def _tables_from_scenario(scenario, road_boundary_obstacle=None) -> ObstacleTables:
@@ -236,8 +252,11 @@ class GpuBackendMixin:
         for i, name in enumerate(_capi.REASON_NAMES[1:6], start=1):
             if name in self._infeasible_reason_dict:
                 self._infeasible_reason_dict[name] = int(out.reason_counts[i])
-        status, costs = ctx.fetch_status() if (self._draw_traj_set or bundle.grids is None or self._wants_costs()) else (None, None)
+        status, costs = ctx.fetch_status() if (self._draw_traj_set or bundle.grids is None) else (None, None)
         bundle.costs = costs
+        # plan()'s standstill branch reads bundle.min_costs() / max_costs() (reactive_planner.py:650-651): two numbers, worked out
+        # on the device when somebody asks (the reference's bundle then holds the kinematically feasible samples, :1128)
+        bundle._range_fn, bundle._range = getattr(ctx, "cost_range", None), None
         if self._draw_traj_set:
             self.stored_trajectories = self._gpu_stored_trajectories(ctx, bundle, status, costs)
         if out.best_index < 0:
@@ -251,10 +270,6 @@ class GpuBackendMixin:
                 self._infeasible_count_collision += 1
                 return None
         return self._gpu_winner_sample(bundle, out)
-
-    def _wants_costs(self) -> bool:
-        # plan()'s standstill branch reads bundle.min_costs()/max_costs() (reactive_planner.py:650-651)
-        return getattr(self.x_0, "velocity", 1.0) <= 0.05
 
     # ---- helpers ----------------------------------------------------------------------------------
     def _gpu_candidate_sample(self, bundle: GpuTrajectoryBundle, index: int, lon_coeffs=None, lat_coeffs=None,

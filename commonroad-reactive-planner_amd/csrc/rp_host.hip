@@ -1001,6 +1001,39 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
     return run_pipeline(c, ka, c->last_mat, c->last_coeffs, true, result, best_states);
 }
 
+int rp_cost_range(rp_ctx *c, double *min_cost, double *max_cost, int64_t *n_out) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last || !min_cost || !max_cost || !n_out) return fail(c, RP_ESTATE, "rp_cost_range: no plan / null output");
+    *min_cost = *max_cost = std::nan("");
+    *n_out = 0;
+    const KArgs &l = c->last;
+    if (l.count == 0) return RP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = grow(c, c->d_user, c->cap_user, (size_t)4)) != RP_OK) return rc;
+    unsigned long long *d_out = reinterpret_cast<unsigned long long *>(c->d_user);
+    static const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+    HIP_TRY(c, hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((l.count + RP_BLOCK * 8 - 1) / (RP_BLOCK * 8), (int64_t)c->num_cus * 4));
+    hipLaunchKernelGGL(rp_cost_range_kernel, dim3(grid), dim3(RP_BLOCK), 0, c->stream, (const uint32_t *)c->d_status, (const double *)c->d_cost,
+                       l.count, d_out);
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long h[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h[2] == 0) return RP_OK;
+    auto unkey = [](unsigned long long k) {
+        const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double d;
+        std::memcpy(&d, &b, sizeof(d));
+        return d;
+    };
+    *min_cost = unkey(h[0]);
+    *max_cost = unkey(h[1]);
+    *n_out = (int64_t)h[2];
+    return RP_OK;
+}
+
 int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double *x, const double *y, const double *theta,
                    int32_t *first_hit, double *boxes) {
     if (!c) return RP_EINVAL;

@@ -1483,6 +1483,35 @@ __global__ __launch_bounds__(RP_SWEPT_THREADS) void rp_swept_kernel(ObsTables ob
 }
 
 // ------------------------------------------------------------------------------------------------
+// Range of the costs of the kinematically feasible candidates (TrajectoryBundle.min_costs / max_costs after
+// _get_optimal_trajectory, reactive_planner.py:650-651).  out[0] = min key, out[1] = max key, out[2] = count; keys are the
+// order-preserving integer images of the doubles (sign flip), so that integer atomics order them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long cost_key(double c) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__global__ __launch_bounds__(RP_BLOCK) void rp_cost_range_kernel(const uint32_t *status, const double *cost, int64_t count, unsigned long long *out) {
+    __shared__ unsigned long long sh[3];
+    if (threadIdx.x == 0) { sh[0] = ~0ull; sh[1] = 0ull; sh[2] = 0ull; }
+    __syncthreads();
+    unsigned long long lo = ~0ull, hi = 0ull, n = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * RP_BLOCK + threadIdx.x; i < count; i += (int64_t)gridDim.x * RP_BLOCK) {
+        const uint32_t lab = RP_STATUS_LABEL(status[i]);
+        const double c = cost[i];
+        if ((lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION) && c == c) {
+            const unsigned long long k = cost_key(c);
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+            ++n;
+        }
+    }
+    if (n) { atomicMin(&sh[0], lo); atomicMax(&sh[1], hi); atomicAdd(&sh[2], n); }
+    __syncthreads();
+    if (threadIdx.x == 0 && sh[2]) { atomicMin(&out[0], sh[0]); atomicMax(&out[1], sh[1]); atomicAdd(&out[2], sh[2]); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block partials from the status / cost arrays (plug-in cost path, rp_select).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *status, const double *cost, int64_t count,

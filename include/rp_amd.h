@@ -200,6 +200,12 @@ int rp_count_collisions_before(rp_ctx *ctx, double cost, int64_t index, int64_t 
  * redo the selection (argmin + collision counters) on the device. */
 int rp_select(rp_ctx *ctx, const double *costs, int64_t count, rp_result *result, double *best_states);
 
+/* Smallest and largest cost among the local candidates of the last plan that have one (the kinematically feasible ones,
+ * labels FEASIBLE and INFEASIBLE_COLLISION) and their number: what TrajectoryBundle.min_costs() / max_costs() return once
+ * _get_optimal_trajectory has left the feasible samples in the bundle (commonroad_rp/reactive_planner.py:1128; read by the
+ * standstill branch of plan(), :650-651).  n == 0: *min_cost and *max_cost are NaN. */
+int rp_cost_range(rp_ctx *ctx, double *min_cost, double *max_cost, int64_t *n);
+
 /* Continuous collision check of ONE trajectory -- the second test of ReactivePlanner._check_collisions
  * (commonroad_rp/reactive_planner.py:1049-1058, planning.continuous_collision_check), which the reference applies
  * to the first candidate of the sorted list that passed the per-pose test: the ego rectangles (half extents

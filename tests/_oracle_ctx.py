@@ -63,6 +63,11 @@ class OracleContext:
     def count_collisions_before(self, cost, index):
         return oracle.count_collisions_before(self._run.status, self._run.cost, self._range[0], cost, index)
 
+    def cost_range(self):
+        lab = self._run.status & 3
+        c = self._run.cost[((lab == 1) | (lab == 3)) & ~np.isnan(self._run.cost)]
+        return (float(c.min()), float(c.max()), len(c)) if len(c) else (float("nan"), float("nan"), 0)
+
     def check_swept(self, params, x, y, theta, want_boxes=False):
         first, boxes = oracle.check_swept(params, self._tables(), x, y, theta, want_boxes)
         return (first, boxes) if want_boxes else first

@@ -487,3 +487,31 @@ def test_longest_horizons(ctx, N):
         p2 = copy_params(p)
         p2.N = 4095
         ctx.plan(PlanInputs(p2, cost, T, W.traj_len_of(T, dt), inp.L, inp.D))
+
+
+@pytest.mark.parametrize("name", ["arc_hv_l2_obs", "arc_all_collide", "rand_07_stop", "rand_10_slow_hv", "scurve_hv_l3"])
+def test_cost_range_entry(ctx, name):
+    """rp_cost_range (TrajectoryBundle.min_costs / max_costs of the standstill branch, reactive_planner.py:650-651): range over
+    the candidates that have a cost -- feasible and colliding ones -- without fetching the arrays; also for a shard and after
+    plug-in costs were applied."""
+    g = Golden(name)
+    g.setup_context(ctx)
+    C = g.inputs.n_candidates
+    for lo, hi in ((0, C), (C // 3, (2 * C) // 3)):
+        ctx.plan(g.inputs, lo, hi)
+        status, cost = ctx.fetch_status()
+        have = (((status & 3) == 1) | ((status & 3) == 3)) & ~np.isnan(cost)
+        cmin, cmax, n = ctx.cost_range()
+        assert n == int(have.sum())
+        if n:
+            assert cmin == cost[have].min() and cmax == cost[have].max()
+        else:
+            assert np.isnan(cmin) and np.isnan(cmax)
+    ctx.plan(_with_flags(g.inputs, FLAG_MATERIALIZE_ALL))
+    status, cost = ctx.fetch_status()
+    have = ((status & 3) == 1) | ((status & 3) == 3)
+    user = np.where(have, -3.0 + np.arange(C) * 0.5, np.nan)    # negative values too: the keys order them
+    ctx.select(user)
+    cmin, cmax, n = ctx.cost_range()
+    if have.any():
+        assert (cmin, cmax, n) == (user[have].min(), user[have].max(), int(have.sum()))
