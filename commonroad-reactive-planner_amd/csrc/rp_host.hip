@@ -198,9 +198,11 @@ int fused_lon_max_blocks(const rp_ctx *c) {    // batches up to this many workgr
 }
 
 // LDS bytes of the single-launch variant for this batch (0: not eligible); *pairs = profile capacity per workgroup
-size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool cin, int *pairs) {
-    if (G != kFusedLonG || count <= 0) return 0;
-    const int gpb = RP_BLOCK / kFusedLonG;
+size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool cin, bool mat, int *pairs) {
+    // 16 lanes per candidate, or one wavefront per candidate for horizons of up to 64 steps (small batches at the reference's
+    // default N = 60: one launch instead of rp_lon_kernel + rp_eval_kernel)
+    if (count <= 0 || !(G == kFusedLonG || (G == 64 && mat && ka.N + 1 <= 64))) return 0;
+    const int gpb = RP_BLOCK / G;
     if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
@@ -213,23 +215,27 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
 }
 
 template <bool MAT, bool CIN, int COLL>
-void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int lanes) {
+    if (lanes == 64) {   // (only chosen with state rows and N + 1 <= 64: one step block)
+        launch_kargs(c, (const void *)rp_eval_kernel<64, true, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
+        return;
+    }
     constexpr int G = kFusedLonG;
     if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
     else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, false, true>, grid, RP_BLOCK, lds, ka);
 }
 
 template <bool MAT, bool CIN>
-void launch_eval_fused_t(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+void launch_eval_fused_t(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int lanes) {
     const int coll = collision_level(ka);
-    if (coll == 2) launch_eval_fused_c<MAT, CIN, 2>(c, ka, grid, lds);
-    else if (coll == 1) launch_eval_fused_c<MAT, CIN, 1>(c, ka, grid, lds);
-    else launch_eval_fused_c<MAT, CIN, 0>(c, ka, grid, lds);
+    if (coll == 2) launch_eval_fused_c<MAT, CIN, 2>(c, ka, grid, lds, lanes);
+    else if (coll == 1) launch_eval_fused_c<MAT, CIN, 1>(c, ka, grid, lds, lanes);
+    else launch_eval_fused_c<MAT, CIN, 0>(c, ka, grid, lds, lanes);
 }
 
-void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, size_t lds) {
-    if (mat) { if (cin) launch_eval_fused_t<true, true>(c, ka, grid, lds); else launch_eval_fused_t<true, false>(c, ka, grid, lds); }
-    else     { if (cin) launch_eval_fused_t<false, true>(c, ka, grid, lds); else launch_eval_fused_t<false, false>(c, ka, grid, lds); }
+void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, size_t lds, int lanes) {
+    if (mat) { if (cin) launch_eval_fused_t<true, true>(c, ka, grid, lds, lanes); else launch_eval_fused_t<true, false>(c, ka, grid, lds, lanes); }
+    else     { if (cin) launch_eval_fused_t<false, true>(c, ka, grid, lds, kFusedLonG); else launch_eval_fused_t<false, false>(c, ka, grid, lds, kFusedLonG); }
 }
 
 template <int G, bool MAT, bool CIN, int COLL>
@@ -411,7 +417,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     int G = lanes_per_candidate(c, ka.N, count, mat);
     // small batches: one launch computes the longitudinal profiles and evaluates (rp_eval_kernel<.., LON_FUSED>)
     int fused_pairs = 0;
-    const size_t fused_lds = (skip_eval || std::getenv("RP_AMD_NO_FUSED_LON")) ? 0 : fused_lon_lds(c, ka, count, G, cin, &fused_pairs);
+    const size_t fused_lds = (skip_eval || std::getenv("RP_AMD_NO_FUSED_LON")) ? 0 : fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
     // (16 lanes per candidate for mid-size batches of up to 64 steps only pay in the single-launch variant)
     if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
     ka.lds_pairs = fused_pairs;
@@ -457,7 +463,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) {
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds);
+            if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds, G);
             else launch_eval(c, ka, grid, mat, cin, G);
             if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
         }
@@ -502,7 +508,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.partials = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
-        if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds);
+        if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds, G);
         else launch_eval(c, kw, 1, true, cin, G);
     }
     HIP_TRY(c, hipGetLastError());
@@ -948,8 +954,8 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
     const int G1 = c->last_G ? c->last_G : lanes_per_candidate(c, kw.N, 1, true);   // the batch's choice: same code path, same bits
-    if (c->last_fused_lds && G1 == kFusedLonG) {   // same code path as the batch: results agree bit for bit
-        launch_eval_fused(c, kw, 1, true, c->last_coeffs, c->last_fused_lds);
+    if (c->last_fused_lds) {   // same code path as the batch: results agree bit for bit
+        launch_eval_fused(c, kw, 1, true, c->last_coeffs, c->last_fused_lds, G1);
     } else {
         launch_lon(c, kw, c->last_coeffs);
         launch_eval(c, kw, 1, true, c->last_coeffs, G1);
