@@ -201,7 +201,7 @@ int fused_lon_max_blocks(const rp_ctx *c) {    // batches up to this many workgr
 size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool cin, bool mat, int *pairs) {
     // 16 lanes per candidate, or one wavefront per candidate for horizons of up to 64 steps (small batches at the reference's
     // default N = 60: one launch instead of rp_lon_kernel + rp_eval_kernel)
-    if (count <= 0 || !(G == kFusedLonG || (G == 64 && mat && ka.N + 1 <= 64))) return 0;
+    if (count <= 0 || !(G == kFusedLonG || (G == 64 && mat && ka.N + 1 <= 64) || (G == 32 && mat && ka.N + 1 <= 32))) return 0;
     const int gpb = RP_BLOCK / G;
     if ((count + gpb - 1) / gpb > (int64_t)fused_lon_max_blocks(c)) return 0;
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
@@ -218,6 +218,10 @@ template <bool MAT, bool CIN, int COLL>
 void launch_eval_fused_c(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int lanes) {
     if (lanes == 64) {   // (only chosen with state rows and N + 1 <= 64: one step block)
         launch_kargs(c, (const void *)rp_eval_kernel<64, true, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
+        return;
+    }
+    if (lanes == 32) {   // (state rows, N + 1 <= 32: one step block)
+        launch_kargs(c, (const void *)rp_eval_kernel<32, true, CIN, COLL, true, false, true>, grid, RP_BLOCK, lds, ka);
         return;
     }
     constexpr int G = kFusedLonG;
@@ -265,7 +269,10 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
     // measured on MI355X (profiles/r01_lanes_per_candidate.txt): without state rows 16 lanes per candidate
     // win at every horizon; with state rows long horizons want whole-wavefront rows (512-byte runs)
     if (!mat) return 16;
-    if (N + 1 <= 32) return 16;
+    // up to 32 steps (the shipped configurations: N = 20): 16 lanes, two step blocks -- except for the smallest batches, where
+    // every wavefront has a SIMD to itself either way and one step block of 32 lanes is the shorter chain
+    // (profiles/probe_small_n20.py: 120 candidates 28.8 vs 31.5 us per step, 630: 29.6 vs 32.2, 3 060: equal, 7 440: 41 vs 32)
+    if (N + 1 <= 32) return (N + 1 > 16 && count <= (int64_t)c->num_cus * 4) ? 32 : 16;
     // up to 64 steps (the reference's default horizon, N = 60): one wavefront per candidate as long as that is at most
     // ~4 wavefronts per SIMD; beyond, and while the single-launch variant still applies, 16 lanes (4 candidates per
     // wavefront, 4 step blocks) are 10 % faster (6 000 candidates: 68 vs 75 us per step; 2 600: equal; 400: 43 vs 60)
