@@ -4,26 +4,36 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2] [--mode draw|materialize|fused]
 
-One *step* = one ``rp_plan`` call over the whole candidate batch of one replanning cycle (grids and
-parameters staged host->device inside the call: a few hundred bytes; tables resident), including
-the winner's state block coming back to the host.  N > 1: one process per GPU, every rank evaluates
-its contiguous shard of an N-times denser longitudinal grid (weak scaling) and the ranks exchange
-one {cost, index, counters, winner block} message per step (commonroad_rp_amd/distributed.py: shared-memory
-mailbox between the ranks of one node -- the result blocks are already in pinned host memory --, RCCL
-collectives otherwise or with RP_AMD_EXCHANGE=collective); the group, barriers and the max-over-ranks
-timing run over torch.distributed (nccl).
+One *step* = one ``rp_plan`` call over the whole candidate batch of one replanning cycle (grids and parameters staged
+host->device inside the call: a few hundred bytes; tables resident), including the winner's state block coming back to
+the host.  Consecutive steps are consecutive cycles of a REPLANNING SEQUENCE (``workloads.replan_sequence``: the scenario
+driven in closed loop, every step a new initial state, velocity grid and time index; cfg5: a seeded list of initial
+states), not one repeated input.  A timed region is exactly K steps; regions are repeated until at least
+``--min-seconds`` of timed work has accumulated, ``ms_per_step`` is the median region, the spread is reported.
+
+N = 1 (default): headline = cfg2 (BASELINE.json configs[1]) in draw mode, plus -- in the same JSON line --
+  ``configs``          draw- and production-mode records of cfg3, cfg4, cfg5, each with its own roofline
+  ``fused_mode``       the headline workload in production mode (12 B per candidate leave the kernel)
+  ``plan_latency_ms``  p50 / p90 of ReactivePlanner.plan() over closed-loop replans (Python boundary included)
+  ``cpu_baseline``     the C port of the reference algorithm (oracle/) on the host cores, bounded sample
+N > 1: one process per GPU (the driver's ``python -m torch.distributed.run ... bench.py --gpus N``; started without a
+  launcher, this script starts the N ranks itself as child processes BEFORE anything touches the GPU and relays rank
+  0's line).  Headline = BASELINE.json configs[3], cfg4, STRONG scaling: every rank evaluates its contiguous range of
+  the same 512 064-candidate grid and the ranks exchange one {cost, index, counters, winner block} message per step
+  (commonroad_rp_amd/distributed.py).  Beside it: the same region with the other exchange transport, the exchange time
+  per step of both, rank 0 alone on the whole grid, and a weak-scaling record (cfg2-sized shard per rank).
 
 Prints ONE JSON line (rank 0).  Modes:
-  draw        every candidate fully evaluated (no pre-filter / early exit, the reference's
-              draw_traj_set semantics) and all 14 state rows of every candidate written to HBM.
-              Default: work per candidate is data independent and the byte count is SURVEY 8(d)'s
-              bytes = C*12 + C*112*(N+1) + 112*(N+1).
+  draw        every candidate fully evaluated (no pre-filter / early exit, the reference's draw_traj_set semantics)
+              and all 14 state rows of every candidate written to HBM.  Default: work per candidate is data independent
+              and the byte count is SURVEY 8(d)'s bytes = C*12 + C*112*(N+1) + 112*(N+1).
   materialize production early-exit semantics, state rows of feasible candidates written
   fused       production semantics, 12 B per candidate leave the kernel
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,17 +44,43 @@ for _p in (REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # half the FP32 vector peak of the same table (157.3 TFLOPS): 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2.4 GHz
+PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+FLOP_FILE = os.path.join(REPO, "profiles", "r02_fp64_flops.json")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None, help="default: cfg2 at N = 1, cfg4 (strong scaling) at N > 1")
+    ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: which record is the headline")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measured record (regions of K steps are repeated)")
+    ap.add_argument("--sequence", type=int, default=32, help="replanning cycles in the input sequence")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the cfg3 / cfg4 / cfg5 records")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed region of the headline (no other leg): counter passes")
+    ap.add_argument("--road-boundary", action="store_true",
+                    help="scenario workloads: add the road boundary (thin rectangles, collision.road_boundary_obb) to the obstacle tables")
+    return ap.parse_args()
 
 
 def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     # Only the JSON line may reach stdout: native libraries (RCCL prints a version banner) write to fd 1
     # directly, so fd 1 is pointed at stderr for the duration of the run and restored for the final print.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        line = run()
+        line = run(args)
     finally:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
@@ -53,37 +89,153 @@ def main():
         print(line, flush=True)
 
 
-def run():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg2")
-    ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--main-only", action="store_true",
-                    help="only the timed region (no production-mode leg, no plan() latency leg, no cpu_baseline): counter passes")
-    ap.add_argument("--road-boundary", action="store_true",
-                    help="scenario workloads: add the road boundary (thin rectangles, collision.road_boundary_obb) to the obstacle tables")
-    args = ap.parse_args()
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as fresh child processes (torch.distributed.run),
+    before this process has imported torch or touched the GPU (never exec from a process that has), relay rank 0's JSON
+    line and return the children's status."""
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and out.endswith("}"):
+            line = out
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc != 0 else (0 if line is not None else 1)
 
+
+# --------------------------------------------------------------------------------------------------------------------
+def with_mode(seq, mode):
+    """The sequence's inputs with the flags of a mode."""
+    from commonroad_rp_amd._capi import PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL
+    flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[mode]
+    out = []
+    for q in seq:
+        p = copy_params(q.params)
+        p.flags = (p.flags & ~(FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL)) | flags
+        out.append(PlanInputs(p, q.cost, q.T, q.traj_len, q.L, q.D))
+    return out
+
+
+def measure(step, n_inputs, steps, warmup, min_seconds, sync, barrier=None, max_regions=4000):
+    """Timed regions of exactly ``steps`` steps (barrier + device sync on both sides), repeated until ``min_seconds`` of
+    timed work; step(k) runs cycle k of the input sequence.  Returns the per-region step times (ms)."""
+    k = 0
+    for _ in range(warmup):
+        step(k % n_inputs)
+        k += 1
+    regions, total = [], 0.0
+    while (total < min_seconds and len(regions) < max_regions) or not regions:
+        if barrier:
+            barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(k % n_inputs)
+            k += 1
+        sync()
+        if barrier:
+            barrier()
+        el = time.perf_counter() - t0
+        if barrier:
+            el = barrier.max_over_ranks(el)   # every rank sees the same number -> the same number of regions
+        regions.append(el / steps * 1e3)
+        total += el
+    return regions
+
+
+def spread(regions):
+    r = np.asarray(regions)
+    return {"regions": int(len(r)), "timed_s": float(r.sum() * 1e-3) if len(r) else 0.0, "median": float(np.median(r)),
+            "min": float(r.min()), "p10": float(np.percentile(r, 10)), "p90": float(np.percentile(r, 90)), "max": float(r.max())}
+
+
+def load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
+
+
+def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_ms, single_gpu=True):
+    """Roofline of rp_eval_kernel for one record.  draw / materialize: HBM write stream, algorithmic bytes per launch
+     / average kernel duration (HIP events inside rp_plan, on the context's stream).  fused: 12 B per candidate
+    leave the kernel, the kernel is FP64-VALU bound: counted FP64 flops of the executed instruction stream per (candidate,
+    step) (profiles/count_fp64.py over the disassembly of the variant this workload takes; profiles/r02_fp64_flops.json)
+    x candidates x steps / kernel duration against the FP64 vector peak."""
+    blk = 112 * n_steps_plus1
+    pmc = load_json(PMC_FILE).get(f"{name}:{mode}") if single_gpu else None
+    traffic = pmc.get("traffic_bytes") if pmc else None
+    if mode == "fused":
+        fl = load_json(FLOP_FILE).get(name)
+        if fl and kernel_ms > 0:
+            flops = float(fl["flops_per_candidate_step"]) * cand_mean * n_steps_plus1
+            ach = flops / (kernel_ms * 1e-3) / 1e12
+            return {"bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
+                    "traffic": traffic, "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "flops_per_launch": flops,
+                    "flops_per_candidate_step": fl["flops_per_candidate_step"], "flop_model": fl.get("model")}
+        bytes_per_launch = cand_mean * 12
+    elif mode == "draw":
+        bytes_per_launch = cand_mean * 12 + cand_mean * blk
+    else:
+        bytes_per_launch = cand_mean * 12 + feasible_mean * blk
+    ach = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else float("nan")
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch}
+
+
+def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=4):
+    """One measured record on one GPU: the sequence in one mode."""
+    inputs = with_mode(seq, mode)
+    kms, feas = [], []
+    ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 4th step (a bracket costs ~8 us of stream time)
+
+    def step(k):
+        out = ctx.plan(inputs[k])
+        if out.kernel_ms > 0:
+            kms.append(out.kernel_ms)
+        feas.append(out.n_feasible)
+    regions = measure(step, len(inputs), steps, warmup, min_seconds, sync)
+    ctx.set_profiling(0)
+    sp = spread(regions)
+    cand = float(np.mean([q.n_candidates for q in inputs]))
+    kernel_ms = float(np.mean(kms)) if kms else float("nan")
+    n1 = inputs[0].params.N + 1
+    rec = {"mode": mode, "candidates_per_step": cand, "ms_per_step": sp["median"], "value": cand / (sp["median"] * 1e-3),
+           "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms, "sequence": len(inputs),
+           "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms)}
+    return rec
+
+
+def steps_for(ms_guess, steps):
+    """K for the side records: about 50 ms per region, at most the headline's K."""
+    return int(max(3, min(steps, 50.0 / max(ms_guess, 1e-3))))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        args.gpus = world
+    args.gpus = world
 
     import torch
-    dist = None
-    force_dist = os.environ.get("RP_BENCH_FORCE_DIST") == "1"   # rehearse the N > 1 code path on one GPU
     # RP_BENCH_REHEARSE=1: several ranks on ONE GPU (gloo group, every rank on cuda:0) -- a functional rehearsal of
-    # the N > 1 path on a one-GPU box; its timings mean nothing
+    # the N > 1 path on a one-GPU box; its timings mean nothing.  RP_BENCH_FORCE_DIST=1: the N > 1 code path with one rank.
     rehearse = os.environ.get("RP_BENCH_REHEARSE") == "1"
+    force_dist = os.environ.get("RP_BENCH_FORCE_DIST") == "1"
     if rehearse:
         local_rank = 0
+    dist = None
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -92,142 +244,234 @@ def run():
         if rehearse:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-
-    from commonroad_rp_amd import workloads as W
-    from commonroad_rp_amd._capi import (RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL)
-    from commonroad_rp_amd.distributed import shard_range, make_exchange, close_exchanges
-
-    flags = {"draw": FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL, "materialize": FLAG_MATERIALIZE_ALL, "fused": 0}[args.mode]
-    base = W.WORKLOADS[args.workload](road_boundary=True) if args.road_boundary else W.WORKLOADS[args.workload]()
-    w = W.replicate_for_ranks(base, world)
-    p = copy_params(w.inputs.params)
-    p.flags |= flags
-    inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
-    C_total = inp.n_candidates
-    lo, hi = shard_range(C_total, rank, world)
-    N = p.N
-
-    ctx = RpContext(local_rank)
-    w.setup(ctx)
-    # HIP events bracket the evaluation kernel of every 4th step of the timed region (each bracket costs ~8 us of
-    # stream time on this 20-us kernel; profiles/host_overhead.py), the average is over the sampled launches
-    ctx.set_profiling(4)
-
-    exchange = make_exchange(dist, torch.device("cuda", local_rank), N + 1) if dist is not None else None
-
-    def step():
-        out = ctx.plan(inp, lo, hi)
-        if exchange is not None:
-            return exchange(ctx, out), out
-        return out, out
-
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    kernel_ms = []
-    n_feasible = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        g, loc = step()
-        if loc.kernel_ms > 0:
-            kernel_ms.append(loc.kernel_ms)
-        n_feasible = loc.n_feasible
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if rehearse else torch.device("cuda", local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- roofline of the dominant kernel (rp_eval_kernel): algorithmic bytes per launch / avg duration
-    C_loc = hi - lo
-    blk = 112 * (N + 1)
-    if args.mode == "draw":
-        bytes_per_launch = C_loc * 12 + C_loc * blk
-    elif args.mode == "materialize":
-        bytes_per_launch = C_loc * 12 + n_feasible * blk
-    else:
-        bytes_per_launch = C_loc * 12
-    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-    achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9 if k_ms > 0 else float("nan")
-
-    # HBM bytes per launch from the PMC counters: cannot be collected inside this process (rocprofv3 --pmc wraps the
-    # command), so the figure measured for this workload + mode by profiles/collect_pmc.sh is read back
-    # (WRITE_SIZE + 2 x FETCH_SIZE, the gfx950 correction of MI355X_MICROARCH.md); null if never measured
-    traffic = None
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json"))).get(base.name)
-        if pmc and pmc.get("mode") == args.mode and world == 1:
-            traffic = pmc["traffic_bytes"]
-    except Exception:
-        traffic = None
+        if dist is None:
+            result = run_single(args, torch, local_rank)
+        else:
+            result = run_multi(args, torch, dist, rank, local_rank, world, rehearse)
+    finally:
+        if dist is not None:
+            from commonroad_rp_amd.distributed import close_exchanges
+            close_exchanges()
+            dist.destroy_process_group()
+    return json.dumps(result) if rank == 0 and result is not None else None
 
+
+def run_single(args, torch, device):
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    name = args.workload or "cfg2"
+    base = W.WORKLOADS[name](road_boundary=True) if args.road_boundary else W.WORKLOADS[name]()
+    ctx = RpContext(device)
+    base.setup(ctx)
+    sync = torch.cuda.synchronize
+    seq = W.replan_sequence(base, args.sequence, device=device)
+    base.setup(ctx)
+    head = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, args.min_seconds, sync)
+    N = base.inputs.params.N
     result = {
         "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
-        "value": C_total * args.steps / elapsed,
-        "unit": "candidates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{base.name}: {w.description}", "mode": args.mode, "candidates_per_step": C_total,
-                   "candidates_per_gpu": C_loc, "horizon_steps": N,
-                   "n_obstacles": int(w.obstacles.dyn_obb.shape[0] + len(w.obstacles.static_obb)),
-                   "parallelism": f"candidate-range sharding x{world}",
-                   "exchange": ({"MailboxExchange": "shared-memory mailbox (ranks of one node; RP_AMD_EXCHANGE=collective for RCCL)",
-                                 "CollectiveExchange": "torch.distributed collectives (RCCL)"}.get(type(exchange).__name__, "?")
-                                if exchange is not None else "none")},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rp_eval_kernel",
-                     "kernel_ms": k_ms, "bytes_per_launch": bytes_per_launch},
+        "value": head["value"], "unit": "candidates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{base.name}: {base.description}", "mode": args.mode,
+                   "candidates_per_step": head["candidates_per_step"], "candidates_per_gpu": head["candidates_per_step"],
+                   "horizon_steps": N, "n_obstacles": int(base.obstacles.dyn_obb.shape[0] + len(base.obstacles.static_obb)),
+                   "inputs": f"replanning sequence of {len(seq)} consecutive cycles (closed loop over the scenario; cfg5: seeded initial states)",
+                   "parallelism": "one GPU", "exchange": "none"},
+        "timing": dict(head["spread_ms"], what="K-step regions bracketed by device syncs, repeated until min-seconds; ms_per_step = median region"),
+        "roofline": head["roofline"],
+    }
+    if not args.main_only:
+        if args.mode != "fused":
+            result["fused_mode"] = run_record(ctx, base, seq, "fused", args.steps, args.warmup, args.min_seconds, sync)
+        ctx.close()
+        ctx = None
+        if not args.no_configs:
+            result["configs"] = side_configs(args, torch, device, skip=base.name)
+        result["plan_latency_ms"] = plan_latency(base, device)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(base, with_mode(seq, args.mode)[0], args.cpu_seconds)
+    if ctx is not None:
+        ctx.close()
+    return result
+
+
+def side_configs(args, torch, device, skip):
+    """Draw- and production-mode records of the larger single-GPU configurations of BASELINE.json (cfg3, cfg4) and of the
+    stress grid cfg5, so that the driver-run line carries them (the headline is the smallest GPU configuration)."""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    out = {}
+    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg3": 0.3, "cfg4": 1.8, "cfg5": 2.9}
+    for name in ("cfg3", "cfg4", "cfg5"):
+        if name == skip:
+            continue
+        w = W.WORKLOADS[name]()
+        ctx = RpContext(device)
+        w.setup(ctx)
+        seq = W.replan_sequence(w, 16 if name != "cfg5" else 8, device=device)
+        w.setup(ctx)
+        rec = {"workload": f"{w.name}: {w.description}", "horizon_steps": int(w.inputs.params.N)}
+        for mode in ("draw", "fused"):
+            k = steps_for(guess[name] * (1.0 if mode == "draw" else 0.5), args.steps)
+            rec[mode] = run_record(ctx, w, seq, mode, k, 3, args.min_seconds, torch.cuda.synchronize)
+        ctx.close()
+        out[name] = rec
+    return out
+
+
+def plan_latency(base, device, n_replans=220, warm=20):
+    """Second half of BASELINE.json's metric: latency of a whole ReactivePlanner.plan() call -- Python boundary, output packing,
+    production mode, one sampling level of the workload's grid -- over closed-loop replans of the scenario
+    (harness.run_closed_loop, replanning every time step; the loop is restarted from the initial state when the route ends)."""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    from commonroad_rp_amd.harness import run_closed_loop
+    import math
+    if base.n_candidates > 100000 or base.name == "cfg5":
+        return None
+    ctx = RpContext(device)
+
+    class Shared:   # the loops share one context (tables stay resident; closing is done here)
+        def __new__(cls, dev):
+            return ctx
+    lat, loops, failed = [], 0, 0
+    c = base.inputs.cost
+    dv = None if math.isnan(c.desired_speed) else float(c.desired_speed)
+    while len(lat) < n_replans + warm and loops < 40:
+        rp = W.make_planner(base, backend_factory=Shared, device=device)
+        res = run_closed_loop(rp, max_steps=80, replanning_frequency=1, desired_velocity=dv)
+        lat += res.plan_times if res.completed else res.plan_times[:-1]   # (a failed plan() runs every sampling level: not a replan)
+        failed += 0 if res.completed else 1
+        loops += 1
+    ctx.close()
+    lat = np.asarray(lat[warm:]) * 1e3
+    if len(lat) == 0:
+        return None
+    return {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "p99": float(np.percentile(lat, 99)),
+            "n": int(len(lat)), "loops": loops, "what": "ReactivePlanner.plan() wall time per closed-loop replan (every time step a new "
+            "state, velocity grid and time index), one sampling level of the workload's grid, production mode, Python included"}
+
+
+# --------------------------------------------------------------------------------------------------------------------
+class Barrier:
+    def __init__(self, torch, dist, device):
+        self.dist, self.t = dist, torch.zeros(1, dtype=torch.float64, device=device)
+
+    def __call__(self):
+        self.dist.barrier()
+
+    def max_over_ranks(self, v):
+        self.t[0] = v
+        self.dist.all_reduce(self.t, op=self.dist.ReduceOp.MAX)
+        return float(self.t.item())
+
+
+def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    from commonroad_rp_amd.distributed import shard_range, make_exchange
+    device = torch.device("cuda", local_rank)
+    bar = Barrier(torch, dist, torch.device("cpu") if rehearse else device)
+    sync = torch.cuda.synchronize
+    ctx = RpContext(local_rank)
+
+    def bcast(obj):
+        box = [obj]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def sharded(w, seq, mode, steps, transport):
+        """every rank evaluates its contiguous range of every cycle's grid and joins the winner exchange"""
+        inputs = with_mode(seq, mode)
+        n1 = inputs[0].params.N + 1
+        ex = make_exchange(dist, device, n1, transport)
+        kms, t_ex = [], []
+        ctx.set_profiling(4)
+
+        def step(k):
+            q = inputs[k]
+            lo, hi = shard_range(q.n_candidates, rank, world)
+            out = ctx.plan(q, lo, hi)
+            if out.kernel_ms > 0:
+                kms.append(out.kernel_ms)
+            t0 = time.perf_counter()
+            ex(ctx, out)
+            t_ex.append(time.perf_counter() - t0)
+        regions = measure(step, len(inputs), steps, args.warmup, args.min_seconds, sync, bar)
+        ctx.set_profiling(0)
+        sp = spread(regions)
+        cand = float(np.mean([q.n_candidates for q in inputs]))
+        loc = cand / world
+        kernel_ms = float(np.mean(kms)) if kms else float("nan")
+        return {"mode": mode, "candidates_per_step": cand, "candidates_per_gpu": loc, "ms_per_step": sp["median"],
+                "value": cand / (sp["median"] * 1e-3), "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms,
+                "exchange": type(ex).__name__, "exchange_ms_per_step": float(np.median(t_ex) * 1e3) if t_ex else None,
+                "roofline": roofline_record(w.name, mode, n1, loc, 0.0, kernel_ms, single_gpu=False)}
+
+    def sequence(w, n, nL=None):
+        """rank 0 drives the closed loop, every rank gets the same inputs"""
+        seq = None
+        if rank == 0:
+            w.setup(ctx)
+            s = W.replan_sequence(w, n, device=local_rank, nL=nL)
+            seq = [(bytes(q.params), bytes(q.cost), q.T, q.traj_len, q.L, q.D) for q in s]
+        seq = bcast(seq)
+        from commonroad_rp_amd._capi import PlanInputs, RpParams, RpCost
+        return [PlanInputs(RpParams.from_buffer_copy(a), RpCost.from_buffer_copy(b), T, tl, L, D) for a, b, T, tl, L, D in seq]
+
+    # ---- strong scaling: BASELINE.json configs[3], the same grid whatever N
+    sname = args.workload or "cfg4"
+    ws = W.WORKLOADS[sname]()
+    seq_s = sequence(ws, min(args.sequence, 16))
+    ws.setup(ctx)
+    k_s = steps_for(1.8 / world if sname == "cfg4" else 0.05, args.steps)
+    default_transport = os.environ.get("RP_AMD_EXCHANGE", "auto")
+    strong = sharded(ws, seq_s, args.mode, k_s, default_transport)
+    other = "collective" if strong["exchange"] == "MailboxExchange" else "mailbox"
+    try:
+        strong_other = sharded(ws, seq_s, args.mode, k_s, other)
+    except Exception as e:   # (e.g. no shared memory for the mailbox)
+        strong_other = {"error": f"{type(e).__name__}: {e}"}
+    # rank 0 alone on the whole grid: the N = 1 point of the same workload, measured in the same run
+    alone = None
+    if rank == 0:
+        alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync)
+    dist.barrier()
+    # ---- weak scaling: cfg2-sized shard per rank (longitudinal grid densified N times)
+    ww = W.cfg2()
+    seq_w = sequence(ww, args.sequence, nL=len(ww.inputs.L) * world)
+    ww.setup(ctx)
+    weak = sharded(ww, seq_w, args.mode, args.steps, default_transport)
+    try:
+        weak_other = sharded(ww, seq_w, args.mode, args.steps, other)
+    except Exception as e:
+        weak_other = {"error": f"{type(e).__name__}: {e}"}
+    ctx.close()
+    if rank != 0:
+        return None
+    head, hw, kind = (strong, ws, "strong") if args.scaling == "strong" else (weak, ww, "weak")
+    return {
+        "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
+        "value": head["value"], "unit": "candidates/s", "n_gpus": world, "steps": head["steps"], "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": kind, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"{hw.name}: {hw.description}" + (f", L densified x{world}" if kind == "weak" else ""),
+                   "mode": args.mode, "candidates_per_step": head["candidates_per_step"], "candidates_per_gpu": head["candidates_per_gpu"],
+                   "horizon_steps": int(hw.inputs.params.N),
+                   "inputs": "replanning sequence (closed loop over the scenario, driven by rank 0, same inputs on every rank)",
+                   "parallelism": f"candidate-range sharding x{world}", "exchange": head["exchange"]},
+        "timing": dict(head["spread_ms"], what="K-step regions bracketed by barrier + device sync, max over ranks, repeated until min-seconds; median region"),
+        "roofline": head["roofline"],
+        "strong": {"sharded": strong, "sharded_other_transport": strong_other, "one_gpu_same_grid": alone},
+        "weak": {"sharded": weak, "sharded_other_transport": weak_other},
+        "rehearsal": bool(rehearse),
     }
 
-    if rank == 0 and world == 1 and not args.main_only:
-        # production-mode rate beside the headline (same workload, early exits, 12 B / candidate)
-        if args.mode != "fused":
-            pf = copy_params(w.inputs.params)
-            inf = PlanInputs(pf, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
-            for _ in range(5):
-                ctx.plan(inf)
-            t1 = time.perf_counter()
-            kk = []
-            for _ in range(max(20, args.steps // 4)):
-                km = ctx.plan(inf).kernel_ms
-                if km > 0:
-                    kk.append(km)
-            el = time.perf_counter() - t1
-            result["fused_mode"] = {"value": C_total * max(20, args.steps // 4) / el, "unit": "candidates/s",
-                                    "ms_per_step": el / max(20, args.steps // 4) * 1e3, "kernel_ms": float(np.mean(kk))}
-        # second half of BASELINE.json's metric: p50 latency of a whole planner.plan() call, Python boundary and
-        # output packing included (production mode), >= 200 replans after 20 warm-ups
-        if base.n_candidates <= 100000:
-            rp = W.make_planner(base, device=local_rank)
-            for _ in range(20):
-                rp.plan()
-            lat = []
-            for _ in range(200):
-                t1 = time.perf_counter()
-                res = rp.plan()
-                lat.append(time.perf_counter() - t1)
-            rp.close()
-            result["plan_latency_ms"] = {"p50": float(np.percentile(lat, 50) * 1e3), "p90": float(np.percentile(lat, 90) * 1e3),
-                                         "n": len(lat), "planned": res is not None,
-                                         "what": "ReactivePlanner.plan() wall time, one sampling level, fused mode"}
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(w, inp, args.cpu_seconds)
-    ctx.close()
-    if dist is not None:
-        close_exchanges()
-        dist.destroy_process_group()
-    return json.dumps(result) if rank == 0 else None
 
-
+# --------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, inp, budget_s: float):
     """The CPU oracle (C port of the reference's algorithm, oracle/rp_oracle.c) timed on one host
     core on the same workload and mode, repeated for about ``budget_s`` seconds."""
@@ -245,7 +489,7 @@ def cpu_baseline(w, inp, budget_s: float):
         oracle.plan(inp, tb, 0, sample, want_states=True)
     el = time.perf_counter() - t0
     out = {"value": sample * reps / el, "unit": "candidates/s", "cores": 1, "kind": "port",
-           "sample": f"first {sample} candidates of the same workload and mode, {reps} repetitions, "
+           "sample": f"first {sample} candidates of the first cycle of the same sequence and mode, {reps} repetitions, "
                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores (C port; the Python reference itself ran "
                      f"~3.9e3 candidates/s/core in the build container, BASELINE.md)"}
     # the same port on the GPU box's CPU share (OpenMP over candidates), a few seconds ("1 core and all cores")

@@ -121,6 +121,7 @@ class PlanOutput:
     best_lat_T: float
     kernel_ms: float
     best_states: Optional[np.ndarray]  # [14, N+1] or None
+    serial: int = 0                    # RpContext: which call on the context produced this result (0: not from a context)
 
     @classmethod
     def from_c(cls, r: RpResult, best_states):
@@ -208,6 +209,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                           C.POINTER(RpResult), dp, ip]),
         "rp_mailbox_sum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.c_int64,
                                      C.POINTER(C.c_int64)]),
+        "rp_mailbox_set_timeout": (C.c_int, [C.c_double]),
+        "rp_mailbox_stalled_rank": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError here = the library does not export the header's symbol
@@ -222,7 +225,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_cost_range", "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum")
+                    "rp_cost_range", "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
+                    "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
 
 
 class RpContext:
@@ -238,7 +242,9 @@ class RpContext:
         self.device = device
         self._N = None
         self._last_count = 0
-        self._res = RpResult()
+        self._res = RpResult()    # C result of the last plan / plan_coeffs / select on this context ...
+        self._last_best = None    # ... and its winner state block (what the intra-node exchange posts as they are)
+        self._serial = 0          # ... and the number of that call (PlanOutput.serial)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -294,8 +300,15 @@ class RpContext:
             self._check(rc, "rp_plan")
         self._N = inp.params.N
         self._last_count = res.n_candidates
-        self._last_best = best        # (raw result of the last plan: what the intra-node exchange posts)
-        return PlanOutput.from_c(res, best)
+        return self._output(res, best)
+
+    def _output(self, res: RpResult, best) -> PlanOutput:
+        """``res`` (== ``self._res``) and ``best`` stay with the context as the raw result of call number ``serial``."""
+        self._last_best = best
+        self._serial += 1
+        out = PlanOutput.from_c(res, best)
+        out.serial = self._serial
+        return out
 
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,
                     want_best_states: bool = True) -> PlanOutput:
@@ -303,7 +316,7 @@ class RpContext:
         traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
         cnt = len(traj_len)
         assert lon_coeffs.shape == (cnt, 6) and lat_coeffs.shape == (cnt, 6) and lon_T.shape == (cnt,)
-        res = RpResult()
+        res = self._res
         best = np.empty((N_ARRAYS, params.N + 1)) if want_best_states else None
         self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs),
                                              dptr(lat_coeffs), dptr(lon_T),
@@ -311,7 +324,7 @@ class RpContext:
                     "rp_plan_coeffs")
         self._N = params.N
         self._last_count = cnt
-        return PlanOutput.from_c(res, best)
+        return self._output(res, best)
 
     def fetch_status(self, first: int = 0, count: Optional[int] = None):
         count = self._last_count - first if count is None else count
@@ -360,7 +373,7 @@ class RpContext:
 
     def select(self, costs, want_best_states: bool = True) -> PlanOutput:
         costs = f64(costs)
-        res = RpResult()
+        res = self._res
         best = np.empty((N_ARRAYS, self._N + 1)) if want_best_states else None
         self._check(self._lib.rp_select(self._h, dptr(costs), len(costs), C.byref(res), dptr(best)), "rp_select")
-        return PlanOutput.from_c(res, best)
+        return self._output(res, best)

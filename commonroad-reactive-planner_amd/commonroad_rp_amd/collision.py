@@ -21,7 +21,7 @@ from typing import Iterable, Optional, Sequence
 
 import numpy as np
 
-__all__ = ["ObstacleTables", "triangulate_polygon_fan", "road_boundary_obb", "SimpleLanelet", "lanelets_from_arrays"]
+__all__ = ["ObstacleTables", "obb_sum", "obb_sum_rows", "triangulate_polygon_fan", "road_boundary_obb", "SimpleLanelet", "lanelets_from_arrays"]
 
 
 def _arr(a, cols: int) -> np.ndarray:
@@ -59,14 +59,19 @@ class ObstacleTables:
     # ------------------------------------------------------------------------------------------
     @classmethod
     def from_scenario(cls, scenario, road_boundary_triangles: Optional[np.ndarray] = None,
-                      road_boundary: bool = False) -> "ObstacleTables":
+                      road_boundary: bool = False, continuous: bool = False) -> "ObstacleTables":
         """Extract tables from a CommonRoad ``Scenario`` (duck-typed: ``static_obstacles`` /
         ``dynamic_obstacles`` with ``obstacle_shape``, ``initial_state`` and
         ``prediction.trajectory.state_list``), mirroring what ``set_collision_checker`` feeds to
         pycrcc (reactive_planner.py:234-251).  Rectangles and circles are supported directly,
         polygons are fan-triangulated (convex polygons only).  ``road_boundary=True`` adds the
         rectangles of ``road_boundary_obb(scenario.lanelet_network.lanelets)`` (the reference calls
-        ``create_road_boundary_obstacle(scenario)``, reactive_planner.py:246-248)."""
+        ``create_road_boundary_obstacle(scenario)``, reactive_planner.py:246-248).
+        ``continuous=True`` (``planning.continuous_collision_check``): every dynamic obstacle is replaced by
+        ``trajectory_preprocess_obb_sum`` of itself, as the reference does before adding it to the checker
+        (reactive_planner.py:238-245) -- the rectangle of time step k becomes the tight rectangle around the
+        obstacle's rectangles of steps k and k + 1 (``obb_sum``), the obstacle's last step has no shape.  Both the
+        per-pose test and the swept test of the ego vehicle then run against these."""
         sobb, stri, scirc = [], [], []
         for ob in getattr(scenario, "static_obstacles", []):
             st = ob.initial_state
@@ -88,12 +93,60 @@ class ObstacleTables:
             for s in states:
                 tab[j, int(s.time_step) - t0] = (s.position[0], s.position[1], s.orientation,
                                                   0.5 * shape.length, 0.5 * shape.width)
+        if continuous:
+            tab = obb_sum_rows(tab)
         if road_boundary_triangles is not None:
             stri.extend(np.asarray(road_boundary_triangles, dtype=np.float64).reshape(-1, 6).tolist())
         if road_boundary:
             sobb.extend(road_boundary_obb(scenario.lanelet_network.lanelets).tolist())
         return cls(static_obb=sobb or None, static_tri=stri or None, static_circ=scirc or None,
                    dyn_obb=tab, dyn_t0=t0)
+
+
+def obb_sum(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Tight rectangle around rectangles ``a`` and ``b`` (rows cx, cy, theta, half_length, half_width; vectorised
+    over leading axes): what commonroad-dc's ``trajectory_preprocess_obb_sum`` puts in place of two consecutive
+    shapes.  commonroad-dc is not under /root/reference; the definition used by this build -- the planar form of
+    FCL's OBB sum, identical in csrc/rp_device.h (``merge_swept``), oracle/rp_oracle.c and the fixtures' stand-in --
+    is: orientation = bisector of the two headings (the second one flipped when they point apart), or the line
+    through the centres when those are farther apart than twice the sum of the larger half extents; extents = both
+    rectangles projected on the two axes."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    aux, auy, bux, buy = np.cos(a[..., 2]), np.sin(a[..., 2]), np.cos(b[..., 2]), np.sin(b[..., 2])
+    dx, dy = b[..., 0] - a[..., 0], b[..., 1] - a[..., 1]
+    lim = 2.0 * (np.maximum(a[..., 3], a[..., 4]) + np.maximum(b[..., 3], b[..., 4]))
+    far = dx * dx + dy * dy > lim * lim
+    sgn = np.where(aux * bux + auy * buy < 0.0, -1.0, 1.0)
+    nx, ny = np.where(far, dx, aux + sgn * bux), np.where(far, dy, auy + sgn * buy)
+    nrm = np.sqrt(nx * nx + ny * ny)
+    nx, ny = nx / nrm, ny / nrm
+    mx, my = -ny, nx
+
+    def extent(ex, ey):
+        ea = a[..., 3] * np.abs(aux * ex + auy * ey) + a[..., 4] * np.abs(auy * ex - aux * ey)
+        eb = b[..., 3] * np.abs(bux * ex + buy * ey) + b[..., 4] * np.abs(buy * ex - bux * ey)
+        pb = dx * ex + dy * ey
+        return np.minimum(-ea, pb - eb), np.maximum(ea, pb + eb)
+
+    lo0, hi0 = extent(nx, ny)
+    lo1, hi1 = extent(mx, my)
+    c0, c1 = 0.5 * (lo0 + hi0), 0.5 * (lo1 + hi1)
+    return np.stack((a[..., 0] + (c0 * nx + c1 * mx), a[..., 1] + (c0 * ny + c1 * my), np.arctan2(ny, nx),
+                     0.5 * (hi0 - lo0), 0.5 * (hi1 - lo1)), axis=-1)
+
+
+def obb_sum_rows(dyn_obb: np.ndarray) -> np.ndarray:
+    """``trajectory_preprocess_obb_sum`` applied to every row of a (n_dyn, n_steps, 5) table: step k holds the sum of
+    the obstacle's rectangles of steps k and k + 1; where either is absent (NaN) -- in particular at the obstacle's
+    last step -- there is no shape (the reference's object is one shape shorter, reactive_planner.py:241)."""
+    dyn = np.asarray(dyn_obb, dtype=np.float64)
+    out = np.full_like(dyn, np.nan)
+    if dyn.shape[0] and dyn.shape[1] > 1:
+        both = ~np.isnan(dyn[:, :-1, 0]) & ~np.isnan(dyn[:, 1:, 0])
+        with np.errstate(invalid="ignore"):
+            merged = obb_sum(dyn[:, :-1], dyn[:, 1:])
+        out[:, :-1][both] = merged[both]
+    return out
 
 
 def triangulate_polygon_fan(vertices: Sequence[Sequence[float]]) -> np.ndarray:

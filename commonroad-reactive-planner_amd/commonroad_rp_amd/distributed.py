@@ -144,6 +144,7 @@ class MailboxExchange:
         self._region = C.c_void_p(C.addressof(tmp))   #  would keep SharedMemory.close() from releasing the buffer)
         del tmp
         self.seq = 0
+        self._broken = ""
         self._local, self._glob = _capi.RpResult(), _capi.RpResult()
         self._states = np.empty((N_ARRAYS, n))
         self._owner = C.c_int32(0)
@@ -165,9 +166,11 @@ class MailboxExchange:
         import ctypes as C
         self.seq += 1
         lo, dp = self._local, self._capi.dptr
+        if self._broken:
+            raise RuntimeError(f"MailboxExchange: unusable after a time-out ({self._broken})")
         raw = getattr(ctx, "_res", None)
-        if raw is not None and int(raw.best_index) == out.best_index and int(raw.n_candidates) == out.n_candidates:
-            # the context still holds the C result of this very plan: post it as it is
+        if raw is not None and out.serial and out.serial == getattr(ctx, "_serial", None):
+            # the context still holds the C result of the very call that produced `out`: post it as it is
             raw_states = getattr(ctx, "_last_best", None) if out.best_index >= 0 else None
             rc = self._lib.rp_mailbox_exchange(self._region, self.world, self.rank, self.seq, self.n, C.byref(raw),
                                                dp(raw_states) if raw_states is not None else None, C.byref(self._glob),
@@ -190,16 +193,24 @@ class MailboxExchange:
                                            dp(self._states), C.byref(self._owner))
         return self._finish(ctx, rc, out)
 
+    def _timeout(self, what: str, rc: int, item: str) -> TimeoutError:
+        """After a time-out the ranks' sequence numbers no longer agree (a late rank posts into a slot nobody reads):
+        the mailbox is marked unusable; the caller is expected to tear the process group down."""
+        stalled = int(self._lib.rp_mailbox_stalled_rank())
+        self._broken = f"{what} -> {rc}: rank {stalled} did not post {item} for exchange {self.seq} within the wait budget " \
+                       f"(RP_AMD_MAILBOX_TIMEOUT_S / rp_mailbox_set_timeout)"
+        return TimeoutError(f"rank {self.rank}: {self._broken}")
+
     def _finish(self, ctx, rc: int, out: PlanOutput) -> PlanOutput:
         import ctypes as C
         if rc != 0:
-            raise TimeoutError(f"rp_mailbox_exchange -> {rc}: a peer rank did not post its result")
+            raise self._timeout("rp_mailbox_exchange", rc, "its result")
         glob = PlanOutput.from_c(self._glob, self._states.copy() if self._glob.best_index >= 0 else None)
         if glob.n_collision > 0:   # second message only when some rank saw a colliding candidate
             n_before = local_collisions_before(ctx, out, glob, int(self._owner.value) == self.rank)
             rc = self._lib.rp_mailbox_sum(self._region, self.world, self.rank, self.seq, self.n, int(n_before), C.byref(self._total))
             if rc != 0:
-                raise TimeoutError(f"rp_mailbox_sum -> {rc}: a peer rank did not post its count")
+                raise self._timeout("rp_mailbox_sum", rc, "its count")
             glob.n_collision_before_best = int(self._total.value)
         return glob
 

@@ -111,14 +111,24 @@ class GpuTrajectoryBundle:
         return _CostView(np.float64(r[1])) if r else None
 
 
-def _tables_from_scenario(scenario, road_boundary_obstacle=None) -> ObstacleTables:
+def _tables_from_scenario(scenario, road_boundary_obstacle=None, continuous: bool = False) -> ObstacleTables:
     """What ``set_collision_checker(scenario=...)`` puts into the checker (reactive_planner.py:234-251): the
-    obstacles and the road boundary -- the caller's ((n, 6) triangles), or generated from the lanelet network when
-    none is given, as the reference calls ``create_road_boundary_obstacle(scenario)`` (:246-248)."""
-    tri = road_boundary_obstacle if isinstance(road_boundary_obstacle, (np.ndarray, list, tuple)) else None
+    obstacles -- dynamic ones as OBB sums of consecutive steps when ``planning.continuous_collision_check`` is on
+    (:238-245) -- and the road boundary: the caller's ((n, 6) triangles), or generated from the lanelet network when
+    none is given, as the reference calls ``create_road_boundary_obstacle(scenario)`` (:246-248).
+    The reference's ``road_boundary_obstacle`` is an opaque ``pycrcc.CollisionObject``; its content cannot be read
+    from here, so anything but triangles is refused instead of being dropped silently."""
+    tri = None
+    if road_boundary_obstacle is not None:
+        if not isinstance(road_boundary_obstacle, (np.ndarray, list, tuple)):
+            raise TypeError(
+                "GPU backend: road_boundary_obstacle must be an (n, 6) array of triangles (or None: the boundary is "
+                f"generated from the lanelet network); an opaque {type(road_boundary_obstacle).__name__} cannot be "
+                "turned into obstacle tables (INTEGRATION.md, Obstacles)")
+        tri = road_boundary_obstacle
     net = getattr(scenario, "lanelet_network", None)
-    generate = tri is None and road_boundary_obstacle is None and net is not None and len(getattr(net, "lanelets", [])) > 0
-    return ObstacleTables.from_scenario(scenario, tri, road_boundary=generate)
+    generate = tri is None and net is not None and len(getattr(net, "lanelets", [])) > 0
+    return ObstacleTables.from_scenario(scenario, tri, road_boundary=generate, continuous=continuous)
 
 
 class GpuBackendMixin:
@@ -140,6 +150,9 @@ class GpuBackendMixin:
             ctx.set_coordinate_system(co)
             self._rp_ref_id = co
         tables = getattr(self, "_obstacle_tables", None)
+        if tables is None and getattr(self, "_rp_tables_refused", False):
+            raise TypeError("GPU backend: the planner holds a collision checker whose content could not be read "
+                            "(set_collision_checker refused it); refusing to plan without a collision check")
         if self._rp_obs_id is not tables or tables is None:
             if tables is None:
                 tables = self._obstacle_tables = ObstacleTables()
@@ -149,17 +162,48 @@ class GpuBackendMixin:
 
     def set_collision_checker(self, scenario=None, collision_checker=None, road_boundary_obstacle=None):
         """When mixed into the reference class: keep its pycrcc checker (other code may use it) and, in
-        addition, extract the obstacle tables the GPU check needs from the same scenario."""
+        addition, keep the obstacle tables the GPU check needs in step with it:
+          * ``scenario=...``: tables extracted from the same scenario (what the reference feeds to pycrcc, :234-251);
+          * ``collision_checker=`` an ``ObstacleTables``: taken as they are;
+          * ``collision_checker=`` the very checker object the current tables were extracted for -- what ``reset()``
+            hands back every replanning cycle (reactive_planner.py:190-195, run_planner.py:99-107) --: tables kept;
+          * any other (opaque pycrcc) checker: its content cannot be read, and planning against stale or empty
+            tables would silently skip the collision check -- refused with a ``TypeError``.  Attach the matching
+            tables as ``checker.obstacle_tables`` or call ``set_obstacle_tables`` to use such a checker."""
+        if road_boundary_obstacle is not None and not isinstance(road_boundary_obstacle, (np.ndarray, list, tuple)):
+            _tables_from_scenario(None, road_boundary_obstacle)   # raises: an opaque pycrcc object cannot become tables
         parent = getattr(super(), "set_collision_checker", None)
         if parent is not None:
             parent(scenario=scenario, collision_checker=collision_checker, road_boundary_obstacle=road_boundary_obstacle)
-        if scenario is not None:
-            self.set_obstacle_tables(_tables_from_scenario(scenario, road_boundary_obstacle))
+        if collision_checker is None:
+            if scenario is not None:
+                cont = bool(getattr(getattr(self.config, "planning", None), "continuous_collision_check", False))
+                self.set_obstacle_tables(_tables_from_scenario(scenario, road_boundary_obstacle, continuous=cont))
+                self._rp_tables_checker = getattr(self, "_cc", None)
+            return
+        if isinstance(collision_checker, ObstacleTables):
+            self.set_obstacle_tables(collision_checker)
+        elif getattr(self, "_obstacle_tables", None) is not None and \
+                collision_checker is getattr(self, "_rp_tables_checker", None):
+            pass   # the checker the tables mirror, handed back by reset(): nothing changed
+        elif isinstance(getattr(collision_checker, "obstacle_tables", None), ObstacleTables):
+            self.set_obstacle_tables(collision_checker.obstacle_tables)
+        else:
+            self._obstacle_tables = None
+            self._rp_tables_checker = None
+            self._rp_tables_refused = True
+            raise TypeError(
+                f"GPU backend: cannot read the content of {type(collision_checker).__name__}; pass the scenario, an "
+                "ObstacleTables object, or attach the matching tables as `collision_checker.obstacle_tables` "
+                "(INTEGRATION.md, Obstacles)")
+        self._rp_tables_checker = collision_checker
 
     def set_obstacle_tables(self, tables: Optional[ObstacleTables]):
         """Obstacle content for the GPU collision check (what the reference keeps inside the opaque
         pycrcc checker, reactive_planner.py:234-251)."""
         self._obstacle_tables = tables if tables is not None else ObstacleTables()
+        self._rp_tables_refused = False
+        self._rp_tables_checker = getattr(self, "_cc", None)   # (drop-in mode: these tables stand for the planner's checker)
 
     def close(self):
         ctx = getattr(self, "_rp_ctx", None)
@@ -402,7 +446,9 @@ class ReactivePlanner(GpuBackendMixin):
         checker); from a scenario the tables are extracted as ``set_collision_checker`` feeds pycrcc
         (reactive_planner.py:234-251); ``road_boundary_obstacle``: (n, 6) triangles."""
         if collision_checker is None:
-            tables = _tables_from_scenario(scenario, road_boundary_obstacle) if scenario is not None else ObstacleTables()
+            tables = _tables_from_scenario(scenario, road_boundary_obstacle,
+                                           continuous=bool(self.config.planning.continuous_collision_check)) \
+                if scenario is not None else ObstacleTables()
         else:
             assert isinstance(collision_checker, ObstacleTables), "pass commonroad_rp_amd.collision.ObstacleTables"
             tables = collision_checker

@@ -157,14 +157,14 @@ def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired
     return Workload(name, description, inp, co, obstacles)
 
 
-def cfg1(level: int = 3) -> Workload:
+def cfg1(level: int = 3, flags: int = 0, road_boundary: bool = False) -> Workload:
     """ZAM_Over-1_1, reference sampling levels (N = 20, t_min 0.2, configurations/ZAM_Over-1_1.yaml)."""
     dt, N, t_min = 0.1, 20, 0.2
     step = int((1 / (level + 1)) / dt)
     T = sorted(set(np.arange(t_min, round(N * dt + dt, 2), step * dt)) - {round(N * dt + dt, 2)})
     n = 2 ** (level + 1) + 1
-    return _scenario_workload("cfg1", "ZAM_Over-1_1", N, T, n, n, low_vel_threshold=4.0,
-                              description=f"ZAM_Over-1_1, sampling level {level}, N=20")
+    return _scenario_workload("cfg1", "ZAM_Over-1_1", N, T, n, n, low_vel_threshold=4.0, flags=flags, road_boundary=road_boundary,
+                              description=f"ZAM_Over-1_1, sampling level {level}, N=20" + (", road boundary" if road_boundary else ""))
 
 
 def cfg2(flags: int = 0, road_boundary: bool = False) -> Workload:
@@ -231,13 +231,22 @@ def replicate_for_ranks(w: Workload, world_size: int) -> Workload:
     return Workload(w.name, w.description + f", L densified x{world_size}", inp, w.coordinate_system, w.obstacles)
 
 
-def make_planner(w: Workload, backend_factory=None, device: int = 0, draw: bool = False):
+def make_planner(w: Workload, backend_factory=None, device: int = 0, draw: bool = False, nL: Optional[int] = None):
     """A ``ReactivePlanner`` set up for a workload: same reference path, obstacles, initial state, cost
     parameters and -- through explicit sample sets at level 1 -- the same (T, L, D) grids, so that
-    ``planner.plan()`` evaluates exactly the workload's candidate batch (used for the p50 plan() latency)."""
+    ``planner.plan()`` evaluates exactly the workload's candidate batch (used for the p50 plan() latency).
+    The grid density survives ``set_desired_velocity`` (which the replanning loop calls every cycle and which rebuilds
+    the velocity samples from the current speed, reactive_planner.py:332-335): the level-1 sample set is rebuilt with
+    the workload's number of samples (``nL`` overrides it) over the new interval."""
     from .config import ReactivePlannerConfiguration
-    from .reactive_planner import ReactivePlanner
+    from .reactive_planner import ReactivePlanner as _Base
     from .state import ReactivePlannerState
+    n_lon = int(nL or len(w.inputs.L))
+
+    class ReactivePlanner(_Base):
+        def set_v_sampling_parameters(self, v_min, v_max):
+            super().set_v_sampling_parameters(v_min, v_max)
+            self.sampling_space.samples_v._dict_level_to_sample_set[1] = set(np.linspace(v_min, v_max, n_lon).tolist())
     p = w.inputs.params
     cfg = ReactivePlannerConfiguration.from_dict(dict(
         planning=dict(dt=p.dt, time_steps_computation=p.N, factor=p.factor,
@@ -259,10 +268,61 @@ def make_planner(w: Workload, backend_factory=None, device: int = 0, draw: bool 
                             current_speed=p.x0_lon[1])
     sp = rp.sampling_space
     sp.samples_t._dict_level_to_sample_set[1] = set(float(t) for t in w.inputs.T)
-    sp.samples_v._dict_level_to_sample_set[1] = set(float(v) for v in w.inputs.L)
-    sp.samples_s._dict_level_to_sample_set[1] = set(float(v) for v in w.inputs.L)
-    sp.samples_d._dict_level_to_sample_set[1] = set(float(d) for d in w.inputs.D)
+    L = w.inputs.L if n_lon == len(w.inputs.L) else np.linspace(w.inputs.L.min(), w.inputs.L.max(), n_lon)
+    sp.samples_v._dict_level_to_sample_set[1] = set(float(v) for v in L)
+    sp.samples_s._dict_level_to_sample_set[1] = set(float(v) for v in L)
+    D = w.inputs.D   # (_with_d0 appended the current offset: the planner's own grid is the one without it, sampling.py:226)
+    if len(D) > 1 and D[-1] == p.x0_lat[0] and not np.any(D[:-1] == p.x0_lat[0]):
+        D = D[:-1]
+    sp.samples_d._dict_level_to_sample_set[1] = set(float(d) for d in D)
     return rp
+
+
+def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_factory=None, nL: Optional[int] = None):
+    """The inputs of ``n_states`` consecutive replanning cycles of a workload ("replan sequence = closed
+    loop over the scenario (cfg1-4) or a fixed list of initial states drawn with seed 1 (cfg5)"), as a list of
+    ``PlanInputs``: what the benchmark steps through instead of repeating one input.
+
+    Scenario workloads: the planner drives the scenario in closed loop, replanning every time step
+    (``harness.run_closed_loop``, the loop of run_planner.py:61-107): the winner's next state becomes the initial state,
+    the velocity grid is re-centred on the current speed (reactive_planner.py:332-335) at the workload's density, the current
+    offset d0 joins the lateral grid (sampling.py:226), time advances against the obstacles' trajectories.  The inputs
+    of every ``rp_plan`` call are recorded.  The loop ends early when no candidate survives (end of the route, blocked
+    road); the recorded states are then what the sequence holds.  ``nL``: longitudinal samples per cycle (default: the
+    workload's; weak-scaling runs densify it).
+    Needs the device: the loop runs on the product path (no CPU fallback)."""
+    from ._capi import RpContext, copy_params
+    from .harness import run_closed_loop
+    inp0 = w.inputs
+    nL = int(nL or len(inp0.L))
+    if w.name == "cfg5":
+        rng = np.random.default_rng(1)
+        seq = []
+        for _ in range(n_states):
+            p = copy_params(inp0.params)
+            v0 = 15.0 + rng.uniform(-1.0, 1.0)
+            p.x0_lon[:] = [20.0 + rng.uniform(-5.0, 5.0), v0, rng.uniform(-0.3, 0.3)]
+            p.x0_lat[:] = [rng.uniform(-0.5, 0.5), rng.uniform(-0.1, 0.1), 0.0]
+            D = _with_d0(np.linspace(-3.0, 3.0, len(inp0.D) - (0 if np.any(np.linspace(-3.0, 3.0, len(inp0.D)) == 0.0) else 1)), p.x0_lat[0])
+            seq.append(PlanInputs(p, inp0.cost, inp0.T, inp0.traj_len, np.linspace(v0 - 3.0, v0 + 3.0, nL), D))
+        return seq
+    recorded = []
+    factory = backend_factory or RpContext
+
+    class Recording(factory):
+        def plan(self, inp, *a, **k):
+            recorded.append(PlanInputs(copy_params(inp.params), inp.cost, inp.T.copy(), inp.traj_len.copy(), inp.L.copy(),
+                                       inp.D.copy()))
+            return super().plan(inp, *a, **k)
+
+    rp = make_planner(w, backend_factory=Recording, device=device, nL=nL)
+    c = inp0.cost
+    run_closed_loop(rp, max_steps=n_states, replanning_frequency=1,
+                    desired_velocity=None if math.isnan(c.desired_speed) else float(c.desired_speed))
+    rp.close()
+    if not recorded:
+        raise RuntimeError(f"{w.name}: the closed loop produced no replanning step")
+    return recorded[:n_states]
 
 
 WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}

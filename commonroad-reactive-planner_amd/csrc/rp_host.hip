@@ -424,9 +424,18 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     int G = lanes_per_candidate(c, ka.N, count, mat);
     // small batches: one launch computes the longitudinal profiles and evaluates (rp_eval_kernel<.., LON_FUSED>)
     int fused_pairs = 0;
-    const size_t fused_lds = (skip_eval || std::getenv("RP_AMD_NO_FUSED_LON")) ? 0 : fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
-    // (16 lanes per candidate for mid-size batches of up to 64 steps only pay in the single-launch variant)
-    if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
+    size_t fused_lds = 0;
+    if (skip_eval) {
+        // rp_select: nothing is evaluated again except, possibly, the winner -- on the launch path of the plan the costs
+        // belong to (its profile rows exist only if that plan took the two-kernel path; same code path, same bits)
+        fused_lds = c->last_fused_lds;
+        fused_pairs = ka.lds_pairs;
+        if (c->last_G) G = c->last_G;
+    } else {
+        if (!std::getenv("RP_AMD_NO_FUSED_LON")) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
+        // (16 lanes per candidate for mid-size batches of up to 64 steps only pay in the single-launch variant)
+        if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
+    }
     ka.lds_pairs = fused_pairs;
     if (!skip_eval) { c->last_fused_lds = fused_lds; c->last_G = G; }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
@@ -1110,13 +1119,30 @@ MailboxLayout mailbox_layout(int n_steps) {
 inline char *mailbox_slot(void *region, const MailboxLayout &l, int world, uint64_t seq, int rank) {
     return static_cast<char *>(region) + ((size_t)(seq & 1) * (size_t)world + (size_t)rank) * l.slot_bytes;
 }
+// wait budget per peer (seconds; rp_mailbox_set_timeout, or RP_AMD_MAILBOX_TIMEOUT_S read once) and the rank the last
+// failed wait of this thread was spinning on
+double g_mailbox_timeout_s = -1.0;
+thread_local int t_mailbox_stalled = -1;
+double mailbox_timeout_s() {
+    if (g_mailbox_timeout_s < 0.0) {
+        const char *e = std::getenv("RP_AMD_MAILBOX_TIMEOUT_S");
+        const double v = e ? std::atof(e) : 0.0;
+        g_mailbox_timeout_s = v > 0.0 ? v : 30.0;
+    }
+    return g_mailbox_timeout_s;
+}
 bool mailbox_wait(void *region, const MailboxLayout &l, int world, uint64_t seq, size_t off) {
-    const auto t0 = std::chrono::steady_clock::now();
+    const auto budget = std::chrono::duration<double>(mailbox_timeout_s());
+    t_mailbox_stalled = -1;
     for (int r = 0; r < world; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();   // every peer gets the whole budget
         const uint64_t *w = reinterpret_cast<const uint64_t *>(mailbox_slot(region, l, world, seq, r) + off);
         for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) != seq; ++spins) {
             __builtin_ia32_pause();
-            if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return false;
+            if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > budget) {
+                t_mailbox_stalled = r;
+                return false;
+            }
         }
     }
     return true;
@@ -1169,6 +1195,14 @@ int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq,
     if (owner_rank) *owner_rank = owner;
     return RP_OK;
 }
+
+int rp_mailbox_set_timeout(double seconds) {
+    if (!(seconds > 0.0)) return RP_EINVAL;
+    g_mailbox_timeout_s = seconds;
+    return RP_OK;
+}
+
+int rp_mailbox_stalled_rank(void) { return t_mailbox_stalled; }
 
 int rp_mailbox_sum(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, int64_t value, int64_t *total) {
     if (!region || !total || world < 1 || rank < 0 || rank >= world || n_steps < 1 || seq == 0) return RP_EINVAL;

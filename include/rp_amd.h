@@ -228,12 +228,17 @@ int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const 
    it) and combine: global (cost, index) min-loc, summed counters, the winner's coefficients and state block.
    `seq` must increase by one per exchange, the same on every rank.  rp_mailbox_sum is the second pass
    (colliding candidates before the global winner).  Both spin until every rank has posted; return RP_OK, or
-   RP_ESTATE after ~10 s without progress. */
+   RP_ESTATE when some peer has not posted within the wait budget (per peer; 30 s unless set through
+   rp_mailbox_set_timeout or the environment variable RP_AMD_MAILBOX_TIMEOUT_S, read once) -- rp_mailbox_stalled_rank
+   then names the peer this thread was waiting for.  After a time-out the sequence numbers of the ranks no longer
+   agree: the region must not be used again (the caller tears the group down). */
 size_t rp_mailbox_bytes(int32_t world, int32_t n_steps /* N + 1 */);
 int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, const rp_result *local,
                         const double *local_best_states /* [14][n_steps] or NULL */, rp_result *global,
                         double *global_best_states /* [14][n_steps] or NULL */, int32_t *owner_rank);
 int rp_mailbox_sum(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, int64_t value, int64_t *total);
+int rp_mailbox_set_timeout(double seconds);   /* wait budget per peer, process-wide; seconds > 0 */
+int rp_mailbox_stalled_rank(void);            /* peer the calling thread's last failed wait was spinning on; -1: none */
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
         _lib.rp_oracle_count_collisions_before.argtypes = [C.c_int64, C.c_int64, up, dp, C.c_double, C.c_int64]
         _lib.rp_oracle_check_swept.restype = C.c_int
         _lib.rp_oracle_check_swept.argtypes = [C.POINTER(RpParams), C.POINTER(RpoTables), C.c_int, dp, dp, dp, dp]
+        _lib.rp_oracle_obb_sum_rows.restype = None
+        _lib.rp_oracle_obb_sum_rows.argtypes = [C.c_int, dp, dp]
         _lib.rpo_np_sum.restype = C.c_double
         _lib.rpo_np_sum.argtypes = [dp, C.c_long]
         _lib.rpo_quintic_coeffs.restype = None
@@ -161,3 +163,14 @@ def check_swept(params, tables: OracleTables, x, y, theta, want_boxes: bool = Fa
     first = lib().rp_oracle_check_swept(C.byref(params), C.byref(tb), n, dptr(x), dptr(y), dptr(theta),
                                         dptr(boxes) if want_boxes else None)
     return int(first), boxes
+
+
+def obb_sum_rows(dyn_obb) -> np.ndarray:
+    """trajectory_preprocess_obb_sum of every dynamic obstacle of a (n_dyn, n_steps, 5) table
+    (commonroad_rp/reactive_planner.py:238-245)."""
+    dyn = np.ascontiguousarray(dyn_obb, dtype=np.float64)
+    out = np.full_like(dyn, np.nan)
+    for j in range(dyn.shape[0]):
+        lib().rp_oracle_obb_sum_rows(dyn.shape[1], dyn[j].ctypes.data_as(C.POINTER(C.c_double)),
+                                     out[j].ctypes.data_as(C.POINTER(C.c_double)))
+    return out

@@ -603,6 +603,24 @@ static obb_t merge_swept(const obb_t *a, const obb_t *b) {
     return m;
 }
 
+/* trajectory_preprocess_obb_sum of a dynamic OBSTACLE (commonroad_rp/reactive_planner.py:238-245, applied by
+ * set_collision_checker when planning.continuous_collision_check is on): rows of (cx, cy, theta, hl, hw), one per time
+ * step, NaN cx = absent.  out[k] = rectangle around rows k and k + 1 (same definition as merge_swept above); where
+ * either is absent, and at the last step, out[k] is absent: the reference's object is one shape shorter (:241). */
+void rp_oracle_obb_sum_rows(int n_steps, const double *rows, double *out) {
+    for (int k = 0; k < n_steps; ++k) {
+        double *o = out + 5 * (size_t)k;
+        o[0] = o[1] = o[2] = o[3] = o[4] = NAN;
+        if (k + 1 >= n_steps) continue;
+        const double *ra = rows + 5 * (size_t)k, *rb = ra + 5;
+        if (isnan(ra[0]) || isnan(rb[0])) continue;
+        obb_t a = {ra[0], ra[1], cos(ra[2]), sin(ra[2]), ra[3], ra[4]};
+        obb_t b = {rb[0], rb[1], cos(rb[2]), sin(rb[2]), rb[3], rb[4]};
+        obb_t m = merge_swept(&a, &b);
+        o[0] = m.cx; o[1] = m.cy; o[2] = atan2(m.uy, m.ux); o[3] = m.hl; o[4] = m.hw;
+    }
+}
+
 /* first colliding segment or -1; boxes: optional [n-1][6] (cx, cy, ux, uy, hl, hw).  Segment i is tested at scenario
  * time index time_step0 + i: the ego object of :1050 starts at x_0.time_step, one shape per index, no factor. */
 int rp_oracle_check_swept(const rp_params *p, const rpo_tables *tb, int n, const double *x, const double *y,

@@ -53,6 +53,34 @@ class Golden:
         ctx.set_obstacles(self.obstacles)
 
 
+def scenario_from_tables(tb: ObstacleTables, road_boundary_triangles=None):
+    """A duck-typed CommonRoad scenario (``static_obstacles`` / ``dynamic_obstacles`` with ``obstacle_shape``,
+    ``initial_state``, ``prediction.trajectory.state_list``) holding the content of obstacle tables: what
+    ``set_collision_checker(scenario=...)`` reads (reference: commonroad_rp/reactive_planner.py:233-251).  Dynamic
+    rows must be present over one contiguous range of steps, with constant extents."""
+    from types import SimpleNamespace as NS
+    static = []
+    for r in tb.static_obb:
+        static.append(NS(obstacle_shape=NS(length=2.0 * r[3], width=2.0 * r[4]), prediction=None,
+                         initial_state=NS(time_step=0, position=np.array(r[0:2]), orientation=float(r[2]))))
+    for r in tb.static_circ:
+        static.append(NS(obstacle_shape=NS(radius=float(r[2])), prediction=None,
+                         initial_state=NS(time_step=0, position=np.array(r[0:2]), orientation=0.0)))
+    dynamic = []
+    for row in tb.dyn_obb:
+        present = np.flatnonzero(~np.isnan(row[:, 0]))
+        if len(present) == 0:
+            continue
+        assert np.array_equal(present, np.arange(present[0], present[-1] + 1)), "contiguous steps expected"
+        states = [NS(time_step=int(tb.dyn_t0 + k), position=np.array(row[k, 0:2]), orientation=float(row[k, 2])) for k in present]
+        dynamic.append(NS(obstacle_shape=NS(length=2.0 * row[present[0], 3], width=2.0 * row[present[0], 4]),
+                          initial_state=states[0],
+                          prediction=NS(trajectory=NS(state_list=states[1:])) if len(states) > 1 else NS(trajectory=NS(state_list=[]))))
+    tri = tb.static_tri if road_boundary_triangles is None else road_boundary_triangles
+    return NS(static_obstacles=static, dynamic_obstacles=dynamic, lanelet_network=None,
+              road_boundary_triangles=np.asarray(tri, dtype=float).reshape(-1, 6))
+
+
 def plan_case_names():
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "plan_*.npz"))))
 
@@ -72,9 +100,15 @@ def build_planner_from_plan_golden(name: str, backend_factory, planner_cls=None)
     cls = planner_cls or ReactivePlanner
     rp = cls(cfg, backend_factory=backend_factory)
     rp.set_reference_path(coordinate_system=CoordinateSystem(z["ref_path"], float(z["proj_d_limit"])))
-    rp.set_collision_checker(collision_checker=ObstacleTables(static_obb=z["static_obb"], static_tri=z["static_tri"],
-                                                              static_circ=z["static_circ"], dyn_obb=z["dyn_obb"],
-                                                              dyn_t0=int(z["dyn_t0"])))
+    tables = ObstacleTables(static_obb=z["static_obb"], static_tri=z["static_tri"], static_circ=z["static_circ"],
+                            dyn_obb=z["dyn_obb"], dyn_t0=int(z["dyn_t0"]))
+    if int(z.get("via_scenario", 0)):
+        # the reference built its checker from a scenario (reactive_planner.py:233-251): same entry here, so that
+        # planning.continuous_collision_check reaches the obstacle side as well (:238-245)
+        sc = scenario_from_tables(tables)
+        rp.set_collision_checker(scenario=sc, road_boundary_obstacle=sc.road_boundary_triangles)
+    else:
+        rp.set_collision_checker(collision_checker=tables)
     x0 = ReactivePlannerState(time_step=int(z["time_step0"]), position=z["x0_position"], orientation=float(z["x0_orientation"]),
                               velocity=float(z["x0_velocity"]), steering_angle=0.0, acceleration=0.0, yaw_rate=0.0)
     rp.reset(initial_state_cart=x0, initial_state_curv=(list(z["x0_lon"]), list(z["x0_lat"])),

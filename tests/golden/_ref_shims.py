@@ -279,17 +279,78 @@ def trajectory_preprocess_obb_sum(tvo: TimeVariantCollisionObject):
     return out, 0
 
 
+class StaticShapeGroup:
+    """What the stand-in ``create_collision_object`` / ``create_road_boundary_obstacle`` return for time-invariant
+    content: rows in the layout of ``ObstacleTables`` (static_obb (n, 5), static_tri (n, 6), static_circ (n, 3))."""
+
+    def __init__(self, obb=(), tri=(), circ=()):
+        self.obb, self.tri, self.circ = [list(r) for r in obb], [list(r) for r in tri], [list(r) for r in circ]
+
+
+def create_collision_object(obstacle):
+    """Stand-in for commonroad_dc...pycrcc_collision_dispatch.create_collision_object (call sites
+    reactive_planner.py:235,238): a static obstacle becomes its shape at the initial state, a dynamic obstacle a
+    ``TimeVariantCollisionObject`` that starts at the initial state's time step and holds one rectangle per state
+    (initial state + prediction).  Obstacles are duck-typed CommonRoad objects (``obstacle_shape``,
+    ``initial_state``, ``prediction.trajectory.state_list``)."""
+    shape, st0 = obstacle.obstacle_shape, obstacle.initial_state
+    pred = getattr(obstacle, "prediction", None)
+    if pred is None:   # static
+        if hasattr(shape, "length"):
+            return StaticShapeGroup(obb=[[st0.position[0], st0.position[1], getattr(st0, "orientation", 0.0),
+                                          0.5 * shape.length, 0.5 * shape.width]])
+        if hasattr(shape, "radius"):
+            return StaticShapeGroup(circ=[[st0.position[0], st0.position[1], shape.radius]])
+        raise TypeError("stand-in create_collision_object: rectangle / circle static obstacles only")
+    tvo = TimeVariantCollisionObject(int(st0.time_step))
+    states = [st0] + list(pred.trajectory.state_list)
+    for k, st in enumerate(states):
+        assert int(st.time_step) == int(st0.time_step) + k, "stand-in: contiguous time steps expected"
+        tvo.append_obstacle(RectOBB(0.5 * shape.length, 0.5 * shape.width, st.orientation, st.position[0], st.position[1]))
+    return tvo
+
+
+def create_road_boundary_obstacle(scenario):
+    """Stand-in for commonroad_dc.boundary.boundary.create_road_boundary_obstacle (call site
+    reactive_planner.py:247): returns (obstacle, collision object).  The fixtures' scenarios carry their road
+    boundary, if any, as ready-made triangles (``scenario.road_boundary_triangles``)."""
+    tri = getattr(scenario, "road_boundary_triangles", None)
+    return None, StaticShapeGroup(tri=[] if tri is None else np.asarray(tri, dtype=float).reshape(-1, 6).tolist())
+
+
 class CollisionChecker:
-    """Holds obstacle tables in the layout of ``commonroad_rp_amd.collision.ObstacleTables``."""
+    """Holds obstacle tables in the layout of ``commonroad_rp_amd.collision.ObstacleTables`` -- handed over ready-made,
+    or collected through ``add_collision_object`` from the objects the stand-ins above create (the path
+    ``set_collision_checker(scenario=...)`` takes, reactive_planner.py:233-251)."""
 
     def __init__(self, tables=None):
         self.tables = tables
+        self._static = StaticShapeGroup()
+        self._tvos: List[TimeVariantCollisionObject] = []
         self.n_queries = 0
         self.n_swept_queries = 0   # queries with the output of trajectory_preprocess_obb_sum, and how many of them hit
         self.n_swept_hits = 0
 
     def add_collision_object(self, obj):
-        raise NotImplementedError("fake checker is built from tables")
+        if isinstance(obj, np.ndarray):   # ready-made road-boundary triangles, (n, 6)
+            obj = StaticShapeGroup(tri=obj.reshape(-1, 6).tolist())
+        if isinstance(obj, StaticShapeGroup):
+            self._static.obb += obj.obb
+            self._static.tri += obj.tri
+            self._static.circ += obj.circ
+        elif isinstance(obj, TimeVariantCollisionObject):
+            self._tvos.append(obj)
+        else:
+            raise TypeError(f"fake checker: cannot add {type(obj).__name__}")
+        from commonroad_rp_amd.collision import ObstacleTables
+        t0 = min((o.time_start_idx for o in self._tvos), default=0)
+        t1 = max((o.time_start_idx + len(o.shapes) for o in self._tvos), default=0)
+        dyn = np.full((len(self._tvos), max(t1 - t0, 0), 5), np.nan)
+        for j, o in enumerate(self._tvos):
+            for k, sh in enumerate(o.shapes):
+                dyn[j, o.time_start_idx - t0 + k] = sh.t
+        self.tables = ObstacleTables(static_obb=self._static.obb or None, static_tri=self._static.tri or None,
+                                     static_circ=self._static.circ or None, dyn_obb=dyn, dyn_t0=t0)
 
     def collide(self, tvo: TimeVariantCollisionObject) -> bool:
         hit = self._collide(tvo)
@@ -355,10 +416,10 @@ def install():
          TimeVariantCollisionObject=TimeVariantCollisionObject)
     _mod("commonroad_dc.pycrccosy", CurvilinearCoordinateSystem=_Anything)
     _mod("commonroad_dc.boundary")
-    _mod("commonroad_dc.boundary.boundary", create_road_boundary_obstacle=None)
+    _mod("commonroad_dc.boundary.boundary", create_road_boundary_obstacle=create_road_boundary_obstacle)
     _mod("commonroad_dc.collision")
     _mod("commonroad_dc.collision.collision_detection")
-    _mod("commonroad_dc.collision.collision_detection.pycrcc_collision_dispatch", create_collision_object=None)
+    _mod("commonroad_dc.collision.collision_detection.pycrcc_collision_dispatch", create_collision_object=create_collision_object)
     _mod("commonroad_dc.collision.trajectory_queries")
     _mod("commonroad_dc.collision.trajectory_queries.trajectory_queries", trajectory_preprocess_obb_sum=trajectory_preprocess_obb_sum)
     _mod("commonroad_dc.feasibility")

@@ -30,6 +30,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, os.path.join(REPO, "commonroad-reactive-planner_amd"))
 
 import _ref_shims  # noqa: E402
@@ -101,7 +102,14 @@ def make_planner(case):
     rp.config = cfg
     rp._co = CoordinateSystem(case["ref_path"], proj_domain_d_limit=case.get("proj_d_limit", 20.0))
     tables = case.get("obstacles")
-    rp._cc = _ref_shims.CollisionChecker(tables)
+    if case.get("via_scenario"):
+        # the reference's own set_collision_checker(scenario=...) (reactive_planner.py:218-251) on a duck-typed
+        # scenario with this content: create_collision_object per obstacle, trajectory_preprocess_obb_sum of every
+        # dynamic obstacle when planning.continuous_collision_check is on, road boundary last
+        from _golden import scenario_from_tables
+        rp.set_collision_checker(scenario=scenario_from_tables(tables or ObstacleTables()))
+    else:
+        rp._cc = _ref_shims.CollisionChecker(tables)
     rp._infeasible_count_collision = 0
     rp._infeasible_count_kinematics = 0
     rp._infeasible_reason_dict = dict()
@@ -495,7 +503,40 @@ def plan_cases():
         swept_trap(dict(base, name="plan_arc_swept_hit", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3],
                         x0_lat=[0.4, 0.2, -0.1], x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3,
                         obstacles=obstacles_arc(), continuous=True), step=8),
+        # continuous collision check on the OBSTACLE side (reactive_planner.py:238-245): a small obstacle that exists
+        # for two time indices and jumps across the lane between them, through the place the per-pose winner occupies
+        # at the first of the two.  Per-pose rectangles never touch that winner (first fixture: it stays the winner);
+        # with the flag on the checker holds the rectangle around both obstacle poses instead, the per-pose test of
+        # that trajectory hits it and the planner settles on another sample (second fixture).
+        crossing_trap(dict(base, name="plan_arc_cross_perpose", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3],
+                           x0_lat=[0.4, 0.2, -0.1], x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3,
+                           obstacles=obstacles_arc(), continuous=False, via_scenario=True), step=16),
+        crossing_trap(dict(base, name="plan_arc_cross_obbsum", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3],
+                           x0_lat=[0.4, 0.2, -0.1], x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3,
+                           obstacles=obstacles_arc(), continuous=True, via_scenario=True), step=16),
     ]
+
+
+def crossing_trap(case, step, side=1.3):
+    """Add a 0.6 m x 0.4 m obstacle with two states: at time index time_step0 + step it stands `side` metres to the
+    left of the centre the level-1 winner (per-pose test, no trap) has at that index, one index later `side` metres to
+    the right of the same point."""
+    probe = dict(case, continuous=False, via_scenario=False)
+    rp = make_planner(probe)
+    bundle = rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], samp_level=1)
+    opt = rp._get_optimal_trajectory(bundle)
+    assert opt is not None
+    th = opt.cartesian.theta[step]
+    cx = opt.cartesian.x[step] + VEH["wb_rear_axle"] * np.cos(th)
+    cy = opt.cartesian.y[step] + VEH["wb_rear_axle"] * np.sin(th)
+    tb = case["obstacles"]
+    row = np.full((1,) + tb.dyn_obb.shape[1:], np.nan)
+    k = case.get("time_step0", 0) + step - tb.dyn_t0
+    row[0, k] = (cx - side * np.sin(th), cy + side * np.cos(th), th + 0.5 * np.pi, 0.3, 0.2)
+    row[0, k + 1] = (cx + side * np.sin(th), cy - side * np.cos(th), th + 0.5 * np.pi, 0.3, 0.2)
+    case["obstacles"] = ObstacleTables(static_obb=tb.static_obb, static_tri=tb.static_tri, static_circ=tb.static_circ,
+                                       dyn_obb=np.concatenate((tb.dyn_obb, row)), dyn_t0=tb.dyn_t0)
+    return case
 
 
 def swept_trap(case, step):
@@ -523,6 +564,7 @@ def run_plan_case(case):
     rp = make_planner(case)
     res = rp.plan()
     out = dict(case_inputs(rp, case), planned=int(res is not None), continuous=int(bool(case.get("continuous", False))),
+               via_scenario=int(bool(case.get("via_scenario", False))),
                n_swept_checks=rp._cc.n_swept_queries, n_swept_hits=rp._cc.n_swept_hits,
                n_infeasible_kinematics=rp._infeasible_count_kinematics, n_infeasible_collision=rp._infeasible_count_collision,
                reason_counts=np.array([rp._infeasible_reason_dict.get(k, 0) for k in REASONS], dtype=np.int64),

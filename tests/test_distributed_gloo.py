@@ -116,3 +116,52 @@ def test_local_share_of_the_collision_count_without_the_second_pass(name):
             assert got == direct, (world, r)
             total += got
         assert total == full.n_collision_before_best == int(g["n_infeasible_collision"])
+
+
+def test_mailbox_timeout_names_the_stalled_rank():
+    """A peer that never posts: the wait ends after the configured budget with RP_ESTATE and the library names the rank
+    it was waiting for (host-only entry points of librp_amd.so: no GPU involved)."""
+    import ctypes as C
+    import time
+    from commonroad_rp_amd import _capi
+    lib = _capi.load_library()
+    n, world = 21, 3
+    size = int(lib.rp_mailbox_bytes(world, n))
+    region = (C.c_char * size)()
+    assert lib.rp_mailbox_set_timeout(-1.0) != 0
+    assert lib.rp_mailbox_set_timeout(0.15) == 0
+    try:
+        loc, glob = _capi.RpResult(), _capi.RpResult()
+        loc.best_index = -1
+        owner = C.c_int32(-5)
+        # ranks 0 and 1 post, rank 2 never does: whoever waits is told "rank 2"
+        st = np.zeros((14, n))
+        t0 = time.perf_counter()
+        rc0 = lib.rp_mailbox_exchange(C.addressof(region), world, 1, 1, n, C.byref(loc), _capi.dptr(st), C.byref(glob), _capi.dptr(st), C.byref(owner))
+        assert rc0 != 0 and lib.rp_mailbox_stalled_rank() == 0          # nobody else there yet: rank 0 is the first it waits for
+        rc1 = lib.rp_mailbox_exchange(C.addressof(region), world, 0, 1, n, C.byref(loc), _capi.dptr(st), C.byref(glob), _capi.dptr(st), C.byref(owner))
+        assert rc1 != 0 and lib.rp_mailbox_stalled_rank() == 2
+        assert 0.25 < time.perf_counter() - t0 < 5.0
+        total = C.c_int64(0)
+        assert lib.rp_mailbox_sum(C.addressof(region), 1, 0, 1, n, 7, C.byref(total)) == 0 and total.value == 7   # world of one: no wait
+        assert lib.rp_mailbox_stalled_rank() == -1
+    finally:
+        lib.rp_mailbox_set_timeout(30.0)
+
+
+def test_exchange_posts_only_the_result_it_was_given():
+    """MailboxExchange may post the context's raw C result instead of re-packing `out` only when `out` IS that result (same
+    call serial) -- a later select() / plan_coeffs() on the context, or an `out` from elsewhere, must not be confused with it
+    even when winner index and candidate count happen to agree."""
+    from commonroad_rp_amd._capi import PlanOutput, RpContext, RpResult
+    ctx = object.__new__(RpContext)
+    ctx._res, ctx._last_best, ctx._serial = RpResult(), None, 0
+    r = ctx._res
+    r.best_index, r.n_candidates, r.best_cost = 4, 10, 1.5
+    a = ctx._output(r, np.zeros((14, 3)))
+    assert a.serial == 1 == ctx._serial
+    r.best_cost = 9.0                       # a select() with external costs rewrites the same C struct ...
+    b = ctx._output(r, np.ones((14, 3)))
+    assert b.serial == 2 and a.serial != ctx._serial and b.best_index == a.best_index and b.n_candidates == a.n_candidates
+    foreign = PlanOutput.from_c(r, None)
+    assert foreign.serial == 0              # ... and a result that did not come from this context never matches

@@ -187,6 +187,46 @@ def test_select_with_external_costs(ctx):
     np.testing.assert_array_equal(out.best_states, st)
 
 
+@pytest.mark.parametrize("name", ["arc_hv_l2_obs", "arc_n70_factor2", "scurve_hv_l3"])
+def test_select_after_plan_without_states(ctx, name):
+    """rp_plan with best_states = NULL (nothing materialised; small batches take the single-launch path, which keeps
+    its profile rows in LDS) followed by rp_select WITH states: the winner is re-evaluated on the launch path of the
+    plan the costs belong to (this sequence dereferenced a null profile pointer)."""
+    g = Golden(name)
+    g.setup_context(ctx)
+    ctx.plan(g.inputs, want_best_states=False)
+    status, cost = ctx.fetch_status()
+    lab = status & 3
+    feas = np.flatnonzero(lab == 1)
+    if len(feas) == 0:
+        pytest.skip("no feasible candidate")
+    user = np.where((lab == 1) | (lab == 3), 10.0 + np.arange(len(lab)) * 1e-3, np.nan)
+    pick = int(feas[len(feas) // 2])
+    user[pick] = 1.0
+    out = ctx.select(user)
+    assert out.best_index == pick and out.best_cost == 1.0
+    assert out.n_collision_before_best == 0
+    st, s1, _ = ctx.eval_one(pick)
+    np.testing.assert_array_equal(out.best_states, st)
+    assert s1 & 3 == 1
+    # the winner's rows against the materialised run of the same plan
+    ctx.plan(_with_flags(g.inputs, FLAG_MATERIALIZE_ALL))
+    np.testing.assert_allclose(out.best_states, ctx.fetch_states(pick, 1)[0], rtol=0, atol=1e-12)
+    # and a shard: plan without states, select without states, then with
+    C = g.inputs.n_candidates
+    lo, hi = C // 4, C // 4 + max(1, C // 2)
+    ctx.plan(g.inputs, lo, hi, want_best_states=False)
+    s2, c2 = ctx.fetch_status()
+    u2 = np.where(((s2 & 3) == 1) | ((s2 & 3) == 3), 5.0, np.nan)
+    o2 = ctx.select(u2, want_best_states=False)
+    f2 = np.flatnonzero((s2 & 3) == 1)
+    assert o2.best_index == (lo + int(f2[0]) if len(f2) else -1)     # ties: smallest index
+    o3 = ctx.select(u2)
+    assert o3.best_index == o2.best_index
+    if o3.best_index >= 0:
+        np.testing.assert_array_equal(o3.best_states, ctx.eval_one(o3.best_index)[0])
+
+
 def test_edge_cases(ctx):
     g = Golden("arc_hv_l1")
     g.setup_context(ctx)
@@ -428,14 +468,40 @@ def test_collision_mask_edge_paths(ctx, kind):
     assert orun.out.n_collision > 0
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg4"])
-def test_full_size_workloads(ctx, name):
-    """BASELINE.json's cfg3 / cfg4 at full size (62 496 and 512 064 candidates): every label, first-failure reason and
-    cost, the counters and the winner against the oracle (OpenMP over candidates); profiles/full_scale_parity.py does
-    the same for all workloads including cfg5 with 50 obstacles."""
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_cfg1_reference_example_all_levels(ctx, level):
+    """BASELINE.json configs[0]: ZAM_Over-1_1 with the reference's own sampling levels (120 / 630 / 3 060 candidates,
+    N = 20, one static obstacle), production and draw mode, with and without the road boundary: every label, reason, cost,
+    the counters, the winner and every state row against the oracle."""
     from oracle import oracle
     from commonroad_rp_amd import workloads as W
-    w = W.WORKLOADS[name]()
+    for rb in (False, True):
+        w = W.cfg1(level=level, road_boundary=rb)
+        assert w.n_candidates == {1: 120, 2: 630, 3: 3060}[level]
+        w.setup(ctx)
+        tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+        for extra in (0, FLAG_MATERIALIZE_ALL, FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL):
+            inp = _with_flags(w.inputs, extra)
+            orun = oracle.plan(inp, tb, want_states=True, nthreads=4)
+            out = ctx.plan(inp)
+            status, cost = ctx.fetch_status()
+            _compare_status(status, cost, orun)
+            _compare_out(out, orun.out)
+            if extra:
+                lab = orun.status & 3
+                defined = np.ones_like(lab, dtype=bool) if extra & FLAG_DRAW_ALL else ((lab == 1) | (lab == 3))
+                np.testing.assert_allclose(ctx.fetch_states()[defined], orun.states[defined], rtol=0, atol=STATE_ATOL)
+        assert orun.out.n_feasible > 0
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5", "cfg5obs"])
+def test_full_size_workloads(ctx, name):
+    """BASELINE.json's cfg3 / cfg4 / cfg5 at full size (62 496, 512 064 and 1 009 899 candidates; cfg5 without and with 50
+    synthetic obstacles): every label, first-failure reason and cost, the counters and the winner against the oracle
+    (OpenMP over candidates)."""
+    from oracle import oracle
+    from commonroad_rp_amd import workloads as W
+    w = W.cfg5(obstacles=50) if name == "cfg5obs" else W.WORKLOADS[name]()
     w.setup(ctx)
     tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
     orun = oracle.plan(w.inputs, tb, want_states=False, nthreads=8)

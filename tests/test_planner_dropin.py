@@ -27,6 +27,7 @@ from commonroad_rp.reactive_planner import ReactivePlanner as RefPlanner  # noqa
 from commonroad_rp.cost_function import DefaultCostFunction as RefDefaultCost  # noqa: E402
 from commonroad_rp_amd.reactive_planner import GpuBackendMixin  # noqa: E402
 from _oracle_ctx import OracleContext  # noqa: E402
+from _golden import scenario_from_tables  # noqa: E402
 
 
 class DropInPlanner(GpuBackendMixin, RefPlanner):
@@ -37,7 +38,14 @@ def _planner(case, cls):
     rp = mg.make_planner(dict(case))
     if cls is not RefPlanner:
         rp.__class__ = cls       # same attributes, methods of the mixin in front of the reference's
-        rp.set_obstacle_tables(case.get("obstacles"))
+        if case.get("via_scenario"):
+            # the reference's own entry: its (stand-in) pycrcc checker is rebuilt from the scenario by the parent class,
+            # the mixin extracts the tables of the GPU check from the same scenario -- including the OBB sums of the
+            # dynamic obstacles when planning.continuous_collision_check is on (reactive_planner.py:238-245)
+            sc = scenario_from_tables(case["obstacles"])
+            rp.set_collision_checker(scenario=sc, road_boundary_obstacle=sc.road_boundary_triangles)
+        else:
+            rp.set_obstacle_tables(case.get("obstacles"))
     return rp
 
 
@@ -100,3 +108,24 @@ def test_draw_traj_set_stores_every_trajectory():
         kin_ref = t.feasibility_label is not None and t.feasibility_label.value == "infeasible_kinematic"
         kin_me = m.feasibility_label is not None and m.feasibility_label.value == "infeasible_kinematic"
         assert kin_ref == kin_me
+
+
+def test_opaque_collision_checker_is_refused_not_ignored():
+    """set_collision_checker(collision_checker=<pycrcc checker>) -- what reset(collision_checker=...) triggers -- must
+    not leave the GPU path with stale or empty tables: the checker the tables were extracted for passes, a foreign one
+    raises, and a planner left in that state refuses to plan."""
+    case = CASES["plan_arc_cross_obbsum"]
+    gpu = _planner(case, DropInPlanner)
+    tables = gpu._obstacle_tables
+    gpu.reset(initial_state_cart=gpu.x_0, initial_state_curv=gpu.x_0_cl, collision_checker=gpu._cc, coordinate_system=gpu._co)
+    assert gpu._obstacle_tables is tables            # same checker handed back (run_planner.py:99-107): tables kept
+    foreign = mg._ref_shims.CollisionChecker(case["obstacles"])
+    with pytest.raises(TypeError, match="cannot read the content"):
+        gpu.set_collision_checker(collision_checker=foreign)
+    with pytest.raises(TypeError, match="refusing to plan"):
+        gpu.plan()
+    foreign.obstacle_tables = tables                 # documented way to use a ready-made checker
+    gpu.set_collision_checker(collision_checker=foreign)
+    assert gpu.plan() is not None
+    with pytest.raises(TypeError, match="road_boundary_obstacle"):
+        gpu.set_collision_checker(scenario=scenario_from_tables(case["obstacles"]), road_boundary_obstacle=object())

@@ -172,3 +172,65 @@ def test_gpu_matches_oracle():
     with pytest.raises(ValueError):
         ctx.check_swept(_params(n=3), [0.0, 1.0, 2.0], [0.0, 1.0], [0.0, 0.0, 0.0])
     ctx.close()
+
+
+# ---- obstacle side: planning.continuous_collision_check replaces every dynamic obstacle by its OBB sum
+#      (reference: reactive_planner.py:238-245) -------------------------------------------------------------------
+def test_obstacle_obb_sum_rows_against_oracle_and_rules():
+    from commonroad_rp_amd.collision import obb_sum_rows
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    dyn = np.full((6, 12, 5), np.nan)
+    for j in range(6):
+        a, b = sorted(rng.integers(0, 13, 2))
+        for k in range(a, b):
+            dyn[j, k] = (rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-3.2, 3.2), rng.uniform(0.2, 3.0), rng.uniform(0.2, 1.5))
+    dyn[0, :, :] = np.nan                      # never present
+    dyn[1, 3:9] = dyn[1, 3]                    # standing still: the sum is the rectangle itself
+    dyn[1, 3:9, 0] = 4.0
+    dyn[2, 2:8, 2] = np.linspace(3.0, 3.3, 6)  # headings across +-pi
+    mine, ref = obb_sum_rows(dyn), oracle.obb_sum_rows(dyn)
+    np.testing.assert_array_equal(np.isnan(mine[..., 0]), np.isnan(ref[..., 0]))
+    ok = ~np.isnan(ref[..., 0])
+    np.testing.assert_allclose(mine[ok][:, [0, 1, 3, 4]], ref[ok][:, [0, 1, 3, 4]], rtol=0, atol=1e-12)
+    dth = np.angle(np.exp(1j * (mine[ok][:, 2] - ref[ok][:, 2])))
+    np.testing.assert_allclose(dth, 0.0, atol=1e-12)
+    # one shape shorter: a step has a shape only if the obstacle exists at that step AND the next one
+    present = ~np.isnan(dyn[..., 0])
+    expect = np.zeros_like(present)
+    expect[:, :-1] = present[:, :-1] & present[:, 1:]
+    np.testing.assert_array_equal(ok, expect)
+    np.testing.assert_allclose(mine[1, 3:8, [0, 1, 3, 4]], dyn[1, 3:8, [0, 1, 3, 4]], atol=1e-12)
+    # enclosure: all eight corners of both rectangles lie inside their sum
+    for j, k in zip(*np.nonzero(ok)):
+        m = mine[j, k]
+        box = (m[0], m[1], math.cos(m[2]), math.sin(m[2]), m[3], m[4])
+        for r in (dyn[j, k], dyn[j, k + 1]):
+            for c in _corners(r[0], r[1], math.cos(r[2]), math.sin(r[2]), r[3], r[4]):
+                assert _inside(box, c, 1e-9)
+
+
+def test_from_scenario_continuous_flag_reaches_the_tables():
+    """ObstacleTables.from_scenario(continuous=True) == OBB sums of the per-step rectangles; a crossing obstacle that misses
+    a parked ego at both of its poses hits it in between."""
+    from _golden import scenario_from_tables
+    from commonroad_rp_amd.collision import obb_sum_rows
+    dyn = np.full((1, 6, 5), np.nan)
+    dyn[0, 2] = (10.0, 3.0, -0.5 * math.pi, 0.4, 0.2)
+    dyn[0, 3] = (10.0, -3.0, -0.5 * math.pi, 0.4, 0.2)
+    tb = ObstacleTables(dyn_obb=dyn, dyn_t0=4)
+    sc = scenario_from_tables(tb)
+    plain = ObstacleTables.from_scenario(sc)
+    swept = ObstacleTables.from_scenario(sc, continuous=True)
+    assert plain.dyn_t0 == swept.dyn_t0 == 6         # tables start at the obstacle's first time step
+    np.testing.assert_allclose(plain.dyn_obb[0, :2], dyn[0, 2:4])
+    np.testing.assert_allclose(swept.dyn_obb, obb_sum_rows(plain.dyn_obb))
+    m = swept.dyn_obb[0, 0]
+    np.testing.assert_allclose([m[0], m[1], m[3], m[4]], [10.0, 0.0, 3.4, 0.2], atol=1e-12)
+    assert np.isnan(swept.dyn_obb[0, 1, 0])
+    # oracle: a parked ego at x = 10 - WB (centre at 10, 0) collides only with the swept table, and only at time index 6
+    from oracle import oracle
+    x, y, th = np.full(3, 10.0 - WB), np.zeros(3), np.zeros(3)
+    for tables, t0, hit in ((plain, 5, -1), (swept, 5, 1), (swept, 6, 0), (swept, 7, -1)):
+        first = oracle.check_swept(_params(time_step0=t0, n=3), _oracle_tables(tables), x, y, th)[0]
+        assert first == hit, (t0, first, hit)
