@@ -150,12 +150,12 @@ def measure(step, n_inputs, steps, warmup, min_seconds, sync, barrier=None, max_
             el = barrier.max_over_ranks(el)   # every rank sees the same number -> the same number of regions
         regions.append(el / steps * 1e3)
         total += el
-    return regions
+    return regions, total
 
 
-def spread(regions):
-    r = np.asarray(regions)
-    return {"regions": int(len(r)), "timed_s": float(r.sum() * 1e-3) if len(r) else 0.0, "median": float(np.median(r)),
+def spread(measured):
+    r, total = np.asarray(measured[0]), measured[1]
+    return {"regions": int(len(r)), "timed_s": float(total), "median": float(np.median(r)),
             "min": float(r.min()), "p10": float(np.percentile(r, 10)), "p90": float(np.percentile(r, 90)), "max": float(r.max())}
 
 
@@ -193,11 +193,11 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
             "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch}
 
 
-def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=4):
+def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=8):
     """One measured record on one GPU: the sequence in one mode."""
     inputs = with_mode(seq, mode)
     kms, feas = [], []
-    ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 4th step (a bracket costs ~8 us of stream time)
+    ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 8th step (a bracket costs ~8 us of stream time)
 
     def step(k):
         out = ctx.plan(inputs[k])
@@ -374,7 +374,8 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     from commonroad_rp_amd._capi import RpContext
     from commonroad_rp_amd.distributed import shard_range, make_exchange
     device = torch.device("cuda", local_rank)
-    bar = Barrier(torch, dist, torch.device("cpu") if rehearse else device)
+    xdev = torch.device("cpu") if rehearse else device   # (rehearsal: gloo group, host tensors)
+    bar = Barrier(torch, dist, xdev)
     sync = torch.cuda.synchronize
     ctx = RpContext(local_rank)
 
@@ -387,9 +388,9 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
         """every rank evaluates its contiguous range of every cycle's grid and joins the winner exchange"""
         inputs = with_mode(seq, mode)
         n1 = inputs[0].params.N + 1
-        ex = make_exchange(dist, device, n1, transport)
+        ex = make_exchange(dist, xdev, n1, transport)
         kms, t_ex = [], []
-        ctx.set_profiling(4)
+        ctx.set_profiling(8)
 
         def step(k):
             q = inputs[k]

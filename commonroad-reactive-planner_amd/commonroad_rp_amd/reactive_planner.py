@@ -40,7 +40,7 @@ from .cost_function import CostFunction, DefaultCostFunction, DefaultCostFunctio
 from .polynomial_trajectory import QuarticTrajectory, QuinticTrajectory
 from .sampling import (FixedIntervalSampling, PositionSampling, SamplingSpace, TimeSampling, VelocitySampling,
                        sampling_space_factory)
-from .state import CustomState, ReactivePlannerState, Trajectory
+from .state import CustomState, LazyStateList, ReactivePlannerState, Trajectory
 from .trajectories import FeasibilityStatus, TrajectorySample, bind_states, label_from_status
 
 logger = logging.getLogger("RP_LOGGER")
@@ -131,6 +131,24 @@ def _tables_from_scenario(scenario, road_boundary_obstacle=None, continuous: boo
     return ObstacleTables.from_scenario(scenario, tri, road_boundary=generate, continuous=continuous)
 
 
+class _WinnerSample(TrajectorySample):
+    """The winner as a ``TrajectorySample`` whose two polynomial objects are built when somebody reads them: ``plan()`` itself
+    only reads the states and the cost, and two polynomial objects per replanning cycle were a tenth of its Python time."""
+
+    def __init__(self, horizon, dt, make_polys):
+        self._make_polys = make_polys
+        self._polys = None
+        super().__init__(horizon, dt, None, None)
+
+    def _get(self, k):
+        if self._polys is None:
+            self._polys = self._make_polys()
+        return self._polys[k]
+
+    trajectory_long = property(lambda self: self._get(0), lambda self, v: None)
+    trajectory_lat = property(lambda self: self._get(1), lambda self, v: None)
+
+
 class GpuBackendMixin:
     """Routes the per-level hot path of ``plan()`` through the HIP library."""
 
@@ -213,17 +231,31 @@ class GpuBackendMixin:
 
     # ---- per-call inputs ---------------------------------------------------------------------------
     def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
+        """The ``rp_params`` of this call.  The struct is kept between calls and only what changes from one replanning cycle to
+        the next is written again (filling all 25 fields through ctypes costs more than the rest of the call's set-up)."""
         cfg, vp = self.config, self.vehicle_params
-        mask = 0
-        for c in cfg.planning.constraints_to_check:
-            mask |= CHECK_BITS[c]
-        return make_params(dt=self.dt, N=self.N, factor=cfg.planning.factor, time_step0=int(self.x_0.time_step),
-                           low_vel_mode=self._low_vel_mode,
-                           lon_mode=LON_STOPPING if cfg.sampling.longitudinal_mode == "stopping" else LON_VELOCITY_KEEPING,
-                           constraint_mask=mask, flags=flags, x0_lon=x_0_lon, x0_lat=x_0_lat,
-                           x0_orientation=self.x_0.orientation, wheelbase=vp.wheelbase, wb_rear_axle=vp.wb_rear_axle,
-                           length=vp.length, width=vp.width, a_max=vp.a_max, v_switch=vp.v_switch,
-                           delta_max=vp.delta_max, v_delta_max=vp.v_delta_max)
+        key = (id(cfg), id(vp), self.dt, self.N, cfg.planning.factor, cfg.sampling.longitudinal_mode,
+               tuple(cfg.planning.constraints_to_check), vp.wheelbase, vp.wb_rear_axle, vp.length, vp.width, vp.a_max,
+               vp.v_switch, vp.delta_max, vp.v_delta_max)
+        cached = getattr(self, "_rp_params_cache", None)
+        if cached is None or cached[0] != key:
+            mask = 0
+            for c in cfg.planning.constraints_to_check:
+                mask |= CHECK_BITS[c]
+            p = make_params(dt=self.dt, N=self.N, factor=cfg.planning.factor, time_step0=0, low_vel_mode=False,
+                            lon_mode=LON_STOPPING if cfg.sampling.longitudinal_mode == "stopping" else LON_VELOCITY_KEEPING,
+                            constraint_mask=mask, flags=0, x0_lon=(0.0, 0.0, 0.0), x0_lat=(0.0, 0.0, 0.0), x0_orientation=0.0,
+                            wheelbase=vp.wheelbase, wb_rear_axle=vp.wb_rear_axle, length=vp.length, width=vp.width,
+                            a_max=vp.a_max, v_switch=vp.v_switch, delta_max=vp.delta_max, v_delta_max=vp.v_delta_max)
+            cached = self._rp_params_cache = (key, p)
+        p = _capi.copy_params(cached[1])     # (a fresh struct per call: callers may keep the inputs of a plan)
+        p.time_step0 = int(self.x_0.time_step)
+        p.low_vel_mode = 1 if self._low_vel_mode else 0
+        p.flags = flags
+        p.x0_lon[0], p.x0_lon[1], p.x0_lon[2] = x_0_lon
+        p.x0_lat[0], p.x0_lat[1], p.x0_lat[2] = x_0_lat
+        p.x0_orientation = self.x_0.orientation
+        return p
 
     def _gpu_cost(self):
         """Cost parameters for the fused path, or ``None`` for a plug-in cost function."""
@@ -339,7 +371,13 @@ class GpuBackendMixin:
         return TrajectorySample(self.horizon, self.dt, lon, lat)
 
     def _gpu_winner_sample(self, bundle, out: PlanOutput) -> TrajectorySample:
-        s = self._gpu_candidate_sample(bundle, out.best_index, out.best_lon_coeffs, out.best_lat_coeffs, out.best_lat_T)
+        if bundle.grids is None:
+            s = bundle.trajectories[out.best_index]      # foreign sampling space: its own object
+        else:
+            def polys(b=bundle, o=out):
+                t = self._gpu_candidate_sample(b, o.best_index, o.best_lon_coeffs, o.best_lat_coeffs, o.best_lat_T)
+                return t.trajectory_long, t.trajectory_lat
+            s = _WinnerSample(self.horizon, self.dt, polys)
         bind_states(s, out.best_states, 1, out.best_cost)
         s._cost_function = self.cost_function
         return s
@@ -601,43 +639,49 @@ class ReactivePlanner(GpuBackendMixin):
         return p
 
     def _compute_trajectory_pair(self, trajectory: TrajectorySample):
-        """Output packing, reactive_planner.py:514-568."""
+        """Output packing, reactive_planner.py:514-568: (Cartesian trajectory, curvilinear trajectory, lon list, lat list).
+        Same values as the reference's; the two state lists build their state objects on access (``LazyStateList``)."""
         ca, cu = trajectory.cartesian, trajectory.curvilinear
         n = len(ca.x)
         t0, factor, dt = self.x_0.time_step, self.config.planning.factor, self.dt
         theta = np.asarray(ca.theta, dtype=float)
+        kappa = np.asarray(ca.kappa, dtype=float)
+        v, acc = np.asarray(ca.v, dtype=float), np.asarray(ca.a, dtype=float)
         yaw = np.empty(n)
-        yaw[1:] = (theta[1:] - theta[:-1]) / dt
-        steer = np.arctan2(self.vehicle_params.wheelbase * np.asarray(ca.kappa, dtype=float), 1.0)
-        pos = np.stack((ca.x, ca.y), axis=1)
-        sd = np.stack((cu.s, cu.d), axis=1)
-        th, v, a, ka = theta.tolist(), np.asarray(ca.v).tolist(), np.asarray(ca.a).tolist(), np.asarray(ca.kappa).tolist()
-        yawl, steerl = yaw.tolist(), steer.tolist()
-        yawl[0] = self.x_0.yaw_rate
+        yaw[0] = self.x_0.yaw_rate
+        yaw[1:] = (theta[1:] - theta[:-1]) / dt                                   # :531-537
+        steer = np.arctan2(self.vehicle_params.wheelbase * kappa, 1.0)            # :539
         # shift_orientation (utility/general.py:49-55) on the Cartesian trajectory only; the curvilinear states keep theta
         lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
-        th_c = th
-        if np.any((theta < lo) | (theta > hi)):
-            th_c = list(th)
+        th_c = theta
+        if theta.min() < lo or theta.max() > hi:
+            th_c = theta.copy()
             for i, o in enumerate(th_c):
                 while o < lo:
                     o += 2 * np.pi
                 while o > hi:
                     o -= 2 * np.pi
                 th_c[i] = o
-        # (states are filled through __dict__: 2 x (N+1) dataclass __init__ calls are a third of this function)
+        pos = np.empty((n, 2))
+        pos[:, 0], pos[:, 1] = ca.x, ca.y
+        sd = np.empty((n, 2))
+        sd[:, 0], sd[:, 1] = cu.s, cu.d
+        # (states are filled through __dict__: a dataclass __init__ call costs three times as much)
         new_state, RS, CS = object.__new__, ReactivePlannerState, CustomState
-        cart_list, cl_list = [], []
-        for i in range(n):
-            ts = t0 + factor * i
+
+        def cart_state(i):
             st = new_state(RS)
-            st.__dict__ = {"time_step": ts, "position": pos[i], "orientation": th_c[i], "velocity": v[i],
-                           "steering_angle": steerl[i], "acceleration": a[i], "yaw_rate": yawl[i]}
-            cart_list.append(st)
+            st.__dict__ = {"time_step": t0 + factor * i, "position": pos[i], "orientation": float(th_c[i]), "velocity": float(v[i]),
+                           "steering_angle": float(steer[i]), "acceleration": float(acc[i]), "yaw_rate": float(yaw[i])}
+            return st
+
+        def curv_state(i):
             sc = new_state(CS)
-            sc.__dict__ = {"time_step": ts, "position": sd[i], "orientation": th[i], "velocity": v[i], "acceleration": a[i],
-                           "yaw_rate": ka[i]}
-            cl_list.append(sc)
-        lon_list = np.stack((cu.s, cu.s_dot, cu.s_ddot), axis=1).tolist()
-        lat_list = np.stack((cu.d, cu.d_dot, cu.d_ddot), axis=1).tolist()
-        return Trajectory(self.x_0.time_step, cart_list), Trajectory(self.x_0.time_step, cl_list), lon_list, lat_list
+            sc.__dict__ = {"time_step": t0 + factor * i, "position": sd[i], "orientation": float(theta[i]), "velocity": float(v[i]),
+                           "acceleration": float(acc[i]), "yaw_rate": float(kappa[i])}
+            return sc
+        lon = np.empty((n, 3))
+        lon[:, 0], lon[:, 1], lon[:, 2] = cu.s, cu.s_dot, cu.s_ddot
+        lat = np.empty((n, 3))
+        lat[:, 0], lat[:, 1], lat[:, 2] = cu.d, cu.d_dot, cu.d_ddot
+        return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)), lon.tolist(), lat.tolist())

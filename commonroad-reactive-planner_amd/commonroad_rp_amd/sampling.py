@@ -132,7 +132,8 @@ class FixedIntervalSampling(SamplingSpace):
         if d0 in d_set:
             D = self._cached_array(d_set)
         else:   # set.union({d0}) keeps the iteration order of the copy and appends / hashes d0 in
-            D = np.array([float(d) for d in d_set.union({d0})], dtype=np.float64)
+            u = d_set.union({d0})
+            D = np.fromiter(u, dtype=np.float64, count=len(u))
         return T, traj_len, L, D
 
     # The sample sets only change when a set_*_sampling_parameters call replaces them, so their array form

@@ -51,3 +51,44 @@ class Trajectory:
     def __init__(self, initial_time_step, state_list):
         self.initial_time_step = initial_time_step
         self.state_list = state_list
+
+
+class LazyStateList:
+    """The ``state_list`` of a planned trajectory as a read-only sequence whose state objects are built when they are
+    asked for.  The replanning loop reads one or two states of the optimal trajectory per cycle
+    (run_planner.py:81-86,102-107: ``optimal[0].state_list[1 + temp]``); building all 2 (N + 1) objects of both output
+    trajectories on every ``plan()`` was the largest single item of its Python time.  Indexing, slicing, ``len``,
+    iteration, ``list(...)`` and comparison with lists work; a built state is kept, so repeated access returns the
+    same object as a list would."""
+
+    __slots__ = ("_n", "_make", "_built")
+
+    def __init__(self, n: int, make):
+        self._n, self._make, self._built = n, make, [None] * n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(self._n))]
+        if k < 0:
+            k += self._n
+        if not 0 <= k < self._n:
+            raise IndexError("state index out of range")
+        st = self._built[k]
+        if st is None:
+            st = self._built[k] = self._make(k)
+        return st
+
+    def __iter__(self):
+        return (self[k] for k in range(self._n))
+
+    def __eq__(self, other):
+        try:
+            return len(other) == self._n and all(a is b or a == b for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    def __repr__(self):
+        return f"LazyStateList({self._n} states, {sum(s is not None for s in self._built)} built)"

@@ -36,18 +36,22 @@ def bind_states(sample, block: np.ndarray, label_code: int, cost=None):
     ``TrajectorySample`` and for foreign sample classes with the reference's interface (e.g. the
     reference's own objects coming out of a plug-in sampling space): the containers and the label
     enum are taken from the module that defines the sample's class."""
-    import sys
-    mod = sys.modules[type(sample).__module__]
-    cart_cls = getattr(mod, "CartesianSample", CartesianSample)
-    curv_cls = getattr(mod, "CurviLinearSample", CurviLinearSample)
-    status_cls = getattr(mod, "FeasibilityStatus", FeasibilityStatus)
     n = block.shape[1]
-    r = dict(zip(ARRAY_NAMES, block))
-    sample.cartesian = cart_cls(r["x"], r["y"], r["theta"], r["v"], r["a"], r["kappa"], r["kappa_dot"], current_time_step=n)
-    sample.curvilinear = curv_cls(r["s"], r["d"], r["theta_cl"], dd=r["d_dot"], ddd=r["d_ddot"], ss=r["s_dot"],
-                                  sss=r["s_ddot"], current_time_step=n)
+    x, y, theta, v, a, kappa, kappa_dot, s, d, theta_cl, s_dot, s_ddot, d_dot, d_ddot = block   # ARRAY_NAMES order
     lab = _LABELS[int(label_code) & 3]
-    sample.feasibility_label = None if lab is None else status_cls[lab.name]
+    if isinstance(sample, TrajectorySample):   # this module's classes
+        sample.cartesian = CartesianSample(x, y, theta, v, a, kappa, kappa_dot, current_time_step=n)
+        sample.curvilinear = CurviLinearSample(s, d, theta_cl, dd=d_dot, ddd=d_ddot, ss=s_dot, sss=s_ddot, current_time_step=n)
+        sample.feasibility_label = lab
+    else:
+        import sys
+        mod = sys.modules[type(sample).__module__]
+        cart_cls = getattr(mod, "CartesianSample", CartesianSample)
+        curv_cls = getattr(mod, "CurviLinearSample", CurviLinearSample)
+        status_cls = getattr(mod, "FeasibilityStatus", FeasibilityStatus)
+        sample.cartesian = cart_cls(x, y, theta, v, a, kappa, kappa_dot, current_time_step=n)
+        sample.curvilinear = curv_cls(s, d, theta_cl, dd=d_dot, ddd=d_ddot, ss=s_dot, sss=s_ddot, current_time_step=n)
+        sample.feasibility_label = None if lab is None else status_cls[lab.name]
     if cost is not None:
         sample._cost = cost
     return sample

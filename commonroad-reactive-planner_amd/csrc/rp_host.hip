@@ -49,6 +49,7 @@ struct rp_ctx {
     int n_ref = 0, search_iters = 0, n_buckets = 0, table_words = 0;
     double bucket_inv_h = 0.0;
     double proj_d_limit = 20.0;
+    std::vector<double> h_pos;    // host copy of ref_pos (table window of the single-launch variant)
     // obstacles
     double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr;
     int32_t *d_clus_info = nullptr;
@@ -57,7 +58,8 @@ struct rp_ctx {
     // per-call staging (pinned host + device mirror)
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t cap_stage = 0;
-    std::vector<char> staged;   // bytes currently resident in d_stage (skip the copy when unchanged)
+    std::vector<char> staged;   // grids of the last rp_plan (host copy); staged_on_device: also what d_stage holds (skip the copy when unchanged)
+    bool staged_on_device = false;
     // work buffers
     uint32_t *d_status = nullptr;
     double *d_cost = nullptr, *d_user = nullptr;
@@ -89,6 +91,7 @@ struct rp_ctx {
     int last_G = 0;              // lanes per candidate of the last plan
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
+    KArgsG kargs_g{};            // launch block of the evaluation / profile kernels: KArgs + the grids of the last rp_plan (if they fit)
     std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
 };
 
@@ -151,6 +154,7 @@ int ensure_stage(rp_ctx *c, size_t need) {
     HIP_TRY(c, hipHostMalloc((void **)&c->h_stage, want, hipHostMallocDefault));
     c->cap_stage = want;
     c->staged.clear();
+    c->staged_on_device = false;
     return RP_OK;
 }
 
@@ -158,7 +162,13 @@ constexpr size_t kStageOutLimit = 65536;   // LDS bytes per workgroup up to whic
 
 // Launch of a kernel whose only parameter is the KArgs block, through hipModuleLaunchKernel with the argument
 // buffer handed over as it is (no per-launch symbol look-up and argument marshalling of hipLaunchKernelGGL).
+void launch_block(rp_ctx *c, const void *kernel, int grid, int block, size_t lds, const void *args, size_t bytes);
 void launch_kargs(rp_ctx *c, const void *kernel, int grid, int block, size_t lds, const KArgs &ka) {
+    c->kargs_g.k = ka;   // (the grid part was filled by rp_plan and stays until the next one: winner re-evaluation, rp_eval_one)
+    launch_block(c, kernel, grid, block, lds, &c->kargs_g, sizeof(KArgsG));
+}
+// (any kernel whose only parameter is one struct passed by value)
+void launch_block(rp_ctx *c, const void *kernel, int grid, int block, size_t lds, const void *args_block, size_t bytes) {
     hipFunction_t f = nullptr;
     auto it = c->functions.find(kernel);
     if (it == c->functions.end()) {
@@ -167,11 +177,10 @@ void launch_kargs(rp_ctx *c, const void *kernel, int grid, int block, size_t lds
     } else {
         f = it->second;
     }
-    size_t bytes = sizeof(KArgs);
-    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<KArgs *>(&ka), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void *>(args_block), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
     if (!f || hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, c->stream, nullptr, extra) != hipSuccess) {
         (void)hipGetLastError();
-        void *args[] = {const_cast<KArgs *>(&ka)};
+        void *args[] = {const_cast<void *>(args_block)};
         (void)hipLaunchKernel(kernel, dim3(grid), dim3(block), args, lds, c->stream);   // error, if any, surfaces through hipGetLastError
     }
 }
@@ -208,7 +217,7 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
     // reference tables + profile rows + pair headers + pre-filter votes + time sample per pair
     const size_t bytes = (size_t)ka.table_words * sizeof(double) +
-                         (size_t)P * ((size_t)PF_FIELDS * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 8;
+                         (size_t)P * ((size_t)PF_STRIDE * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 8;
     if (bytes > kFusedLonLdsLimit) return 0;
     *pairs = P;
     return (bytes + 15) & ~(size_t)15;
@@ -344,12 +353,56 @@ void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs
     }
     ka.tables = c->d_tables; ka.n_ref = c->n_ref; ka.search_iters = c->search_iters;
     ka.n_buckets = c->n_buckets; ka.table_words = c->table_words; ka.bucket_inv_h = c->bucket_inv_h;
+    ka.pos_first = c->h_pos.empty() ? 0.0 : c->h_pos.front();
+    ka.pos_last = c->h_pos.empty() ? 0.0 : c->h_pos.back();
     ka.c_yaw = 1e5 / p->dt;
     ka.c_kdot = p->dt * p->v_delta_max / p->wheelbase;
     ka.proj_d_limit = c->proj_d_limit;
     ka.obs = c->obs;
     ka.debug = c->d_debug;
     ka.has_obstacles = (c->obs.n_sobb + c->obs.n_tri + c->obs.n_circ > 0 || (c->obs.n_dyn > 0 && c->obs.n_steps > 0)) ? 1 : 0;
+}
+
+// Part of the reference-table block a grid plan can touch (single-launch variant: every workgroup stages the block in
+// LDS -- 28 KB x 465 workgroups on cfg2 -- although one replanning cycle moves over a few dozen metres of a route of
+// hundreds).  s of every valid step lies between the bounds the Hermite form of the longitudinal polynomial gives:
+//   velocity keeping (quartic, v cubic from (v0, a0) to (vd, 0)):  v in [min(v0, vd) - c T |a0|, max(v0, vd) + c T |a0|], c = 4/27
+//   stopping (quintic to (sf, 0, 0)):  s in [min(s0, sf), max(s0, sf)] -+ (0.2 |v0| T + 0.0173 |a0| T^2)
+// An estimate, not a guarantee the kernel relies on: the kernel checks every item against [win_s_lo, win_s_hi) and stages
+// the whole block when one falls outside (steps beyond the end of the route, NaN samples, ...).
+void table_window(const rp_ctx *c, const rp_params *p, const rp_grids *g, KArgs &ka) {
+    ka.win_n = 0;   // whole block
+    const int n = c->n_ref;
+    if (n < 96 || c->n_buckets <= 0 || g->nT <= 0 || g->nL <= 0 || std::getenv("RP_AMD_NO_TABLE_WINDOW")) return;
+    double Tmax = g->T[0], Lmin = g->L[0], Lmax = g->L[0];
+    for (int i = 1; i < g->nT; ++i) Tmax = std::max(Tmax, g->T[i]);
+    for (int i = 1; i < g->nL; ++i) { Lmin = std::min(Lmin, g->L[i]); Lmax = std::max(Lmax, g->L[i]); }
+    const double s0 = p->x0_lon[0], v0 = p->x0_lon[1], a0 = std::fabs(p->x0_lon[2]);
+    double lo, hi;
+    if (p->lon_mode == RP_LON_STOPPING) {
+        const double over = 0.2 * std::fabs(v0) * Tmax + 0.0173 * a0 * Tmax * Tmax;
+        lo = std::min(s0, Lmin) - over; hi = std::max(s0, Lmax) + over;
+    } else {
+        const double dv = (4.0 / 27.0) * Tmax * a0;
+        lo = s0 + std::min(0.0, (std::min(v0, Lmin) - dv) * Tmax); hi = s0 + std::max(0.0, (std::max(v0, Lmax) + dv) * Tmax);
+    }
+    if (!(lo <= hi) || !(hi - lo < 1e300)) return;   // NaN / inf samples
+    const double *pos = c->h_pos.data();
+    const int seg_lo = (int)(std::upper_bound(pos, pos + n, lo) - pos) - 1, seg_hi = (int)(std::upper_bound(pos, pos + n, hi) - pos) - 1;
+    // an item in segment seg reads vertices seg - 2 .. seg + 3 (bucket fix-ups, both interpolation pairs)
+    int w0 = std::max(0, seg_lo - 3), w1 = std::min(n, seg_hi + 5);
+    int shift = 4;
+    while ((1 << shift) < w1 - w0) ++shift;
+    const int wn = 1 << shift;
+    if (wn * 2 > n || wn > 128) return;              // not worth a window | the kernel holds at most 5 pieces per lane
+    if (w0 + wn > n) w0 = n - wn;
+    ka.win_k0 = w0; ka.win_n = wn; ka.win_shift = shift;
+    ka.win_s_lo = w0 == 0 ? pos[0] : pos[w0 + 2];
+    ka.win_s_hi = w0 + wn == n ? pos[n - 1] : pos[w0 + wn - 4];
+    // bucket entries of [win_s_lo, win_s_hi): the kernel's index is (int)((s - pos[0]) * bucket_inv_h), clamped to n_buckets - 1
+    const int b0 = std::max(0, (int)((ka.win_s_lo - pos[0]) * c->bucket_inv_h) - 1);
+    const int b1 = std::min(c->n_buckets - 1, (int)((ka.win_s_hi - pos[0]) * c->bucket_inv_h) + 1);
+    ka.win_b0 = b0; ka.win_nb = b1 - b0 + 1;
 }
 
 int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result *res) {
@@ -502,8 +555,12 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             n_partials = kFoldPartials;
         }
         const auto tf0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        hipLaunchKernelGGL(rp_finalize_kernel, dim3(1), dim3(RP_FIN_THREADS), 0, c->stream, ka, fin_in, n_partials,
-                           small ? 1 : 0, copy_states ? 1 : 0, drb, hrb_dev, fin_seq);
+        FinArgs fa;
+        fa.status = ka.status; fa.cost = ka.cost; fa.states = ka.states; fa.partials = fin_in;
+        fa.dev_out = drb; fa.host_out = hrb_dev;
+        fa.count = ka.count; fa.cand_begin = ka.cand_begin; fa.seq = fin_seq;
+        fa.N = ka.N; fa.n_partials = n_partials; fa.count_inline = small ? 1 : 0; fa.copy_states = copy_states ? 1 : 0;
+        launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
         if (c->timing) c->t_sum[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count();
     }
     if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
@@ -554,7 +611,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         unsigned long long st[32];
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
-        for (int k = 1; k < 17; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        for (int k = 1; k < 26; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
         std::fprintf(stderr, "\n");
     }
 #endif
@@ -723,6 +780,7 @@ int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *
     if (rc != RP_OK) return rc;
     c->n_buckets = nb;
     c->bucket_inv_h = 1.0 / hmin;
+    c->h_pos.assign(ref_pos, ref_pos + n);
     c->table_words = (int)t.size();
     c->n_ref = n;
     c->proj_d_limit = proj_domain_d_limit;
@@ -848,9 +906,15 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     std::memcpy(hs + g->nT, g->L, sizeof(double) * g->nL);
     std::memcpy(hs + g->nT + g->nL, g->D, sizeof(double) * g->nD);
     std::memcpy(hs + nd, g->traj_len, sizeof(int32_t) * g->nT);
-    if (sbytes && (c->staged.size() != sbytes || std::memcmp(c->staged.data(), c->h_stage, sbytes) != 0)) {
+    const bool grids_inline = sbytes <= sizeof(c->kargs_g.grid) && !std::getenv("RP_AMD_NO_INLINE_GRIDS");
+    if (grids_inline) {   // the grids ride in the kernarg segment of the launches: no copy on the stream
+        std::memcpy(c->kargs_g.grid, c->h_stage, sbytes);
+        c->staged.assign(c->h_stage, c->h_stage + sbytes);   // (host copy: the winner's coefficients are worked out from it)
+        c->staged_on_device = false;
+    } else if (sbytes && (!c->staged_on_device || c->staged.size() != sbytes || std::memcmp(c->staged.data(), c->h_stage, sbytes) != 0)) {
         HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
         c->staged.assign(c->h_stage, c->h_stage + sbytes);
+        c->staged_on_device = true;
     }
 
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
@@ -860,7 +924,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     KArgs ka;
     fill_common(c, p, cost, ka);
     const double *ds = reinterpret_cast<const double *>(c->d_stage);
-    ka.nT = g->nT; ka.nL = g->nL; ka.nD = g->nD;
+    ka.nT = g->nT; ka.nL = g->nL; ka.nD = g->nD; ka.grids_inline = grids_inline ? 1 : 0;
     ka.T = ds; ka.L = ds + g->nT; ka.D = ds + g->nT + g->nL;
     ka.traj_len = reinterpret_cast<const int32_t *>(ds + nd);
     ka.cand_begin = cand_begin; ka.count = count;
@@ -875,6 +939,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     // (NaN / inf samples: pair_step_bound reports "no bound" and the masks come out all ones.  The evaluation kernels of grid
     //  plans always take the masked query: use_near_mask only tells the profile kernels whether there is anything to mask.)
     if (c->obs.n_dyn <= 0 && c->obs.n_clus == 0) ka.use_near_mask = 0;
+    table_window(c, p, g, ka);
     c->have_last = false;
     rc = run_pipeline(c, ka, mat, false, false, result, best_states);
     if (rc != RP_OK) return rc;
@@ -900,6 +965,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     std::memcpy(hs + 12 * C, traj_len, sizeof(int32_t) * C);
     if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
     c->staged.clear();
+    c->staged_on_device = false;
     c->last_lon.assign(lon_coeffs, lon_coeffs + 6 * C);
     c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;

@@ -50,7 +50,7 @@ struct KArgs {
     int32_t cost_kind, has_speed, has_s, pad0_;
     double w_a, desired_speed, desired_d, desired_s;
     // grids (device pointers) or explicit polynomials
-    int32_t nT, nL, nD, pad1_;
+    int32_t nT, nL, nD, grids_inline;   // grids_inline: [T | L | D | traj_len] travel in the kernarg segment (KArgsG), not in device memory
     const double *T;
     const int32_t *traj_len;
     const double *L;
@@ -66,6 +66,12 @@ struct KArgs {
     int32_t n_ref, search_iters, n_buckets, table_words;
     double bucket_inv_h;
     double proj_d_limit;
+    // single-launch variant: the part of the table block a launch can touch (rp_host.hip: table_window), staged instead of the
+    // whole block; win_n == 0: the whole block.  Items whose s lies in [win_s_lo, win_s_hi) read staged entries only; any other
+    // item makes its workgroup stage the whole block and start over.
+    int32_t win_k0, win_n, win_shift, win_b0, win_nb, pad3_;   // vertices [win_k0, win_k0 + win_n), win_n = 1 << win_shift; bucket entries [win_b0, win_b0 + win_nb)
+    double win_s_lo, win_s_hi;
+    double pos_first, pos_last;   // ref_pos[0], ref_pos[n_ref - 1]
     ObsTables obs;         // obstacle table descriptor, by value: a pointer to a device copy costs a dependent
                            // memory round trip before the first obstacle row can be requested
     int32_t has_obstacles, pad2_;
@@ -86,6 +92,29 @@ struct KArgs {
     unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
     unsigned long long seq_value;
 };
+
+// What the evaluation and profile kernels take: the KArgs block and, behind it, room for the sample grids of the launch
+// [T (nT doubles) | L (nL) | D (nD) | traj_len (nT int32)].  A replanning cycle changes the grids every time (the velocity
+// samples follow the current speed, the current offset joins the lateral samples), and staging ~0.5 KB through a
+// host-to-device copy put a 5-us blit kernel in front of every step; the kernarg segment is written by the launch anyway.
+// Grids that do not fit (RP_GRID_INLINE doubles) are staged in device memory as before (KArgs.T / L / D / traj_len): those are the
+// large batches, where a 5-us copy does not show; the room is kept small because the launch cost of a kernel grows with its
+// kernarg segment (measured: 3.8 KB instead of 0.6 KB put ~1 us between the dispatch and the first wavefront).
+#define RP_GRID_INLINE 96
+struct KArgsG {
+    KArgs k;
+    double grid[RP_GRID_INLINE];
+};
+static_assert(sizeof(KArgsG) <= 4096 - 256, "kernarg segment: at most 4 KB including the hidden arguments");
+
+// base of the launch's grids: [T | L | D | traj_len]
+__device__ __forceinline__ const double *grid_base(const KArgs &a) {
+    typedef const char __attribute__((address_space(4))) *kchar;
+    typedef const double __attribute__((address_space(1))) *gdouble;
+    const gdouble inl = (gdouble)(uintptr_t)((kchar)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(KArgs));
+    const gdouble staged = (gdouble)(uintptr_t)a.T;
+    return (const double *)(a.grids_inline ? inl : staged);
+}
 
 // fields of one step of a longitudinal profile
 enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_NEAR_S, PF_COS_REF, PF_SIN_REF,
@@ -175,6 +204,26 @@ __device__ __forceinline__ void touch_kernargs() {
         : "memory");
 }
 
+// The same for `lines` more 64-byte lines from byte offset `first` on (the inline grids behind the KArgs block): scalar
+// loads whose results nobody reads -- they pull the lines into L2 / the scalar cache while the prologue computes indices,
+// so that the per-lane vector loads of grid values that follow do not go to memory one by one.
+__device__ __forceinline__ void touch_kernarg_lines(int first, int lines) {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    for (int k = 0; k < lines; k += 4) {   // (wave-uniform trip count; the last group may touch up to 3 lines beyond: same 4 KB segment)
+        unsigned t0, t1, t2, t3;
+        const int off = first + k * 64;
+        asm volatile(
+            "s_load_dword %0, %4, %5\n\t"
+            "s_load_dword %1, %4, %6\n\t"
+            "s_load_dword %2, %4, %7\n\t"
+            "s_load_dword %3, %4, %8"
+            : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3)
+            : "s"(kp), "s"(off), "s"(off + 64), "s"(off + 128), "s"(off + 192)
+            : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t bi) {
     return bi < 0 || c < bc || (c == bc && i < bi);
 }
@@ -239,22 +288,54 @@ __device__ __forceinline__ void wave_min_pair(double &c, long long &i) {
     i = (long long)(((unsigned long long)ih << 32) | il);
 }
 
-// Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).
-__device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial *partials, int n_partials, int count_inline,
-                                              int copy_states, FinalizeOut *dev_out, FinalizeOut *host_out,
-                                              unsigned long long seq) {
+// Arguments of rp_finalize_kernel: the handful of KArgs fields it reads (the whole 584-byte block by value was nine cold
+// kernarg lines to fetch for one workgroup that lives 4 us).
+struct FinArgs {
+    const uint32_t *status;      // [count]
+    const double *cost;          // [count]
+    const double *states;        // [count][14][N+1] or nullptr
+    const BlockPartial *partials;
+    FinalizeOut *dev_out, *host_out;
+    int64_t count, cand_begin;
+    unsigned long long seq;      // completion ticket for the host (0: none)
+    int32_t N, n_partials, count_inline, copy_states;
+};
+
+// Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).  Memory round trips are the cost of this kernel (one workgroup,
+// a few hundred bytes of arithmetic): the block partials AND the first slice of status / cost words are requested together at
+// entry; the winner's state rows are requested as soon as the winner is known and travel while the colliding candidates
+// before it are counted.
+__device__ __forceinline__ void finalize_body(const FinArgs &a) {
     __shared__ double sh_cost[RP_FIN_THREADS / 64];
     __shared__ long long sh_idx[RP_FIN_THREADS / 64];
     __shared__ unsigned long long sh_cnt[10];
     __shared__ unsigned long long sh_before;
     __shared__ FinalizeOut sh_out;
     const int tid = threadIdx.x;
+    const int n_partials = a.n_partials;
     double bc = 0.0;
     long long bi = -1;
     unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tid == 0) sh_before = 0;
+    // first slice of the status / cost words (needed only if something collided -- not known yet; 12 B per candidate)
+    constexpr int kUnroll = 8;
+    const int ccount = a.count_inline ? (int)a.count : 0;   // count_inline: at most RP_FINALIZE_MAX
+    uint32_t st0[kUnroll];
+    double cs0[kUnroll];
+    // (RP_FIN_PREFETCH: the first slice of status / cost words requested at entry together with the partials.  Measured
+    //  SLOWER, 6.4 -> 8.2 us: two more buffers on the critical path of a one-workgroup kernel are two more cold address
+    //  translations; most cycles have no colliding candidate and never read the words.  Kept for the record, off.)
+#ifndef RP_FIN_PREFETCH
+#define RP_FIN_PREFETCH 0
+#endif
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const int i = tid + u * RP_FIN_THREADS, ic = i < ccount ? i : (ccount > 0 ? ccount - 1 : 0);
+        st0[u] = (RP_FIN_PREFETCH && ccount > 0) ? a.status[ic] : 0u;
+        cs0[u] = (RP_FIN_PREFETCH && ccount > 0) ? a.cost[ic] : 0.0;
+    }
     for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
-        const BlockPartial p = partials[k];
+        const BlockPartial p = a.partials[k];
         if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
         cnt[0] += (unsigned long long)p.n_feasible;
         cnt[1] += (unsigned long long)p.n_collision;
@@ -278,64 +359,65 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
     }
     if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
     __syncthreads();
-    if (tid < 10) {
-        double t = 0.0;
-        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
-        sh_cnt[tid] = (unsigned long long)t;
-    }
-    __syncthreads();
     double wcost = sh_cost[0];
     long long widx_ = sh_idx[0];
 #pragma unroll
     for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
         if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
     const int64_t widx = (int64_t)widx_;
-    const unsigned long long n_coll = sh_cnt[1];
-    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
-    if (count_inline && n_coll > 0) {
-        // status and cost of kUnroll candidates per lane are requested together (both unconditionally, 12 B per candidate):
-        // one candidate per trip with the cost load behind the label test was a chain of dependent round trips -- 12 of
-        // them for 3 060 candidates, 7 us of a 14 us epilogue on the reference's own example scenario
-        constexpr int kUnroll = 8;
-        const int cnt = (int)a.count;   // count_inline: at most RP_FINALIZE_MAX
-        int nloc = 0;
-        for (int i0 = tid; i0 < cnt; i0 += RP_FIN_THREADS * kUnroll) {
-            uint32_t st[kUnroll];
-            double cs[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int i = i0 + u * RP_FIN_THREADS, ic = i < cnt ? i : cnt - 1;
-                st[u] = a.status[ic];
-                cs[u] = a.cost[ic];
-            }
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int i = i0 + u * RP_FIN_THREADS;
-                const bool coll = i < cnt && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
-                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
-            }
-        }
-        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
-    }
-    __syncthreads();
     const int n = a.N + 1;
-    // the winner's state rows are requested now, so that their round trip overlaps the coefficient section below
+    // the winner's state rows are requested now: their round trip overlaps the count below
     constexpr int kRowsPerThread = 4;   // covers 14 (N+1) <= 1024 doubles in registers; longer blocks loop at the end
     double wrow[kRowsPerThread];
-    const bool want_rows = copy_states && widx >= 0;
+    const bool want_rows = a.copy_states && widx >= 0;
     const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n : nullptr;
 #pragma unroll
     for (int q = 0; q < kRowsPerThread; ++q) {
         const int k = tid + q * RP_FIN_THREADS;
         wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[k] : 0.0;
     }
+    double n_coll_d = 0.0;
+    for (int w = 0; w < RP_FIN_THREADS / 64; ++w) n_coll_d += sh_wcnt[w][1];
+    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
+    if (ccount > 0 && n_coll_d > 0.0) {
+        int nloc = 0;
+        auto tally = [&](const uint32_t *st, const double *cs, int i0) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = i0 + u * RP_FIN_THREADS;
+                const bool coll = i < ccount && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
+                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
+            }
+        };
+        if (RP_FIN_PREFETCH) tally(st0, cs0, tid);
+        // status and cost of kUnroll candidates per lane are requested together (both unconditionally, 12 B per candidate):
+        // one candidate per trip with the cost load behind the label test was a chain of dependent round trips
+        for (int i0 = tid + (RP_FIN_PREFETCH ? RP_FIN_THREADS * kUnroll : 0); i0 < ccount; i0 += RP_FIN_THREADS * kUnroll) {
+            uint32_t st[kUnroll];
+            double cs[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = i0 + u * RP_FIN_THREADS, ic = i < ccount ? i : ccount - 1;
+                st[u] = a.status[ic];
+                cs[u] = a.cost[ic];
+            }
+            tally(st, cs, i0);
+        }
+        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
+    }
+    if (tid < 10) {
+        double t = 0.0;
+        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
+        sh_cnt[tid] = (unsigned long long)t;
+    }
+    __syncthreads();
     if (tid == 0) {
         FinalizeOut &o = sh_out;
         o.r.best_index = widx;
         o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
         o.r.n_candidates = a.count;
         o.r.n_feasible = (int64_t)sh_cnt[0];
-        o.r.n_collision = (int64_t)n_coll;
+        o.r.n_collision = (int64_t)sh_cnt[1];
         o.r.n_collision_before_best = (int64_t)sh_before;
         for (int r = 0; r < 8; ++r) o.r.reason_counts[r] = (int64_t)sh_cnt[2 + r];
         o.r.kernel_ms = 0.0;
@@ -349,14 +431,8 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
         //  computing them here cost a dependent round trip for T, L, D plus ~60 serial FP64 instructions)
         if (widx >= 0) o.w_status = RP_LABEL_FEASIBLE;
     }
-    __syncthreads();
-    {   // result header: cooperative copy (8-byte words), everything except the ticket
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
-        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
-        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
-        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
-    }
-    if (want_rows) {   // winner's state block straight from the materialised states
+    FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
+    if (want_rows) {   // winner's state block straight from the materialised states (ahead of the header: it does not wait for thread 0)
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
 #pragma unroll
         for (int q = 0; q < kRowsPerThread; ++q) {
@@ -369,20 +445,25 @@ __device__ __forceinline__ void finalize_body(const KArgs &a, const BlockPartial
             d2[k] = v;
         }
     }
-    if (seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
+    __syncthreads();
+    {   // result header: cooperative copy (8-byte words), everything except the ticket
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
+        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
+        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
+    }
+    if (a.seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
         __threadfence_system();
         __syncthreads();
         if (tid == 0) {
-            __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
 
-__global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const KArgs a, const BlockPartial *partials, int n_partials,
-                                                                      int count_inline, int copy_states, FinalizeOut *dev_out,
-                                                                      FinalizeOut *host_out, unsigned long long seq) {
-    touch_kernargs<10>();
-    finalize_body(a, partials, n_partials, count_inline, copy_states, dev_out, host_out, seq);
+__global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const FinArgs a) {
+    touch_kernargs<2>();
+    finalize_body(a);
 }
 
 // Per-group LDS scratch of the evaluation kernel.  Values that are identical in all lanes of a group
@@ -430,6 +511,19 @@ __device__ __forceinline__ RefTab ref_tab(const double *tab, int n_ref) {
     return r;
 }
 
+// the same over a block whose end vertices need not be staged (single-launch variant with a table window)
+__device__ __forceinline__ RefTab ref_tab(const double *tab, int n_ref, double pos_first, double pos_last) {
+    RefTab r;
+    r.pos = tab + TB_POS * n_ref; r.theta = tab + TB_THETA * n_ref; r.curv = tab + TB_CURV * n_ref;
+    r.curv_d = tab + TB_CURV_D * n_ref; r.x = tab + TB_X * n_ref; r.y = tab + TB_Y * n_ref;
+    r.tx = tab + TB_TX * n_ref; r.ty = tab + TB_TY * n_ref; r.inv = tab + TB_INVLEN * n_ref;
+    r.bucket = reinterpret_cast<const int *>(tab + TB_ROWS * n_ref);
+    r.n_ref = n_ref;
+    r.pos_first = pos_first;
+    r.pos_last = pos_last;
+    return r;
+}
+
 struct LonPair {
     Poly lon;
     double lat_T;   // delta_tau of the pair's lateral polynomials (sampling.py:229-237); 0 with COEFFS_IN
@@ -453,9 +547,10 @@ __device__ __forceinline__ LonPairIn lon_pair_fetch(const KArgs &a, int64_t pair
         r.L = a.traj_len_c[pair];
     } else {
         const int iT = (int)((uint32_t)pair / (uint32_t)a.nL), iL = (int)((uint32_t)pair - (uint32_t)iT * (uint32_t)a.nL);
-        r.c[0] = a.T[iT];
-        r.c[1] = a.L[iL];
-        r.L = a.traj_len[iT];
+        const double *gb = grid_base(a);
+        r.c[0] = gb[iT];
+        r.c[1] = gb[a.nT + iL];
+        r.L = reinterpret_cast<const int32_t *>(gb + a.nT + a.nL + a.nD)[iT];
     }
     return r;
 }
@@ -529,6 +624,55 @@ __device__ __forceinline__ void lon_step(const KArgs &a, const RefTab &rt, const
     rp_sincos(th_ref, &f[PF_SIN_REF], &f[PF_COS_REF]);
 }
 
+// The same step, cut into three independent instruction chains (single-launch variant: a lone wavefront issues one
+// instruction every ~10 cycles whatever its kind, so the profile rows of a workgroup's one or two pairs -- at most a
+// wavefront's worth of items -- cost the LENGTH of lon_step's chain; three wavefronts of the workgroup each run one part for
+// every item, the fourth clears the mask rows).  Same expressions as lon_step, field for field.
+//   part 0: theta_ref and its cos / sin (+ s)      part 1: s_dot, s_ddot, 1 / s_dot, k_r, k_r'      part 2: foot point, unit normal, in-domain
+template <int PART>
+__device__ __forceinline__ void lon_step_part(const KArgs &a, const RefTab &rt, const Poly &lon, int i, double s, double *o, size_t n0) {
+    const int n_ref = rt.n_ref;
+    const int ub = a.n_buckets > 0
+                       ? upper_bound_bucket(rt.pos, rt.bucket, n_ref, a.n_buckets, a.bucket_inv_h, rt.pos_first, rt.pos_last, s)
+                       : upper_bound(rt.pos, n_ref, a.search_iters, s);
+    if (PART == 2) {
+        int k = ub - 1;
+        k = k < 0 ? 0 : (k > n_ref - 2 ? n_ref - 2 : k);
+        const double lam2 = (s - rt.pos[k]) * rt.inv[k];
+        const double bx = rt.x[k], by = rt.y[k], ux0 = rt.tx[k], uy0 = rt.ty[k];
+        const double px = bx + lam2 * (rt.x[k + 1] - bx), py = by + lam2 * (rt.y[k + 1] - by);
+        const double ax = ux0 + lam2 * (rt.tx[k + 1] - ux0), ay = uy0 + lam2 * (rt.ty[k + 1] - uy0);
+        const double inv_tn = rp_rsqrt(ax * ax + ay * ay);
+        o[PF_PX * n0] = px; o[PF_PY * n0] = py;
+        o[PF_NX * n0] = -(ay * inv_tn); o[PF_NY * n0] = ax * inv_tn;
+        o[PF_INDOM * n0] = (s >= rt.pos_first && s <= rt.pos_last) ? 1.0 : 0.0;
+        return;
+    }
+    const int s_idx = (ub == n_ref) ? -1 : ub - 1;
+    const int k0 = s_idx < 0 ? n_ref - 1 : s_idx, k1 = s_idx + 1;
+    const double p0 = rt.pos[k0], inv_len = rt.inv[k0];
+    const double ds = s - p0;
+    if (PART == 0) {
+        const double th0 = rt.theta[k0];
+        const double th_ref = make_valid_orientation((rt.theta[k1] - th0) * ds * inv_len + th0);  // interpolate_angle
+        o[PF_S * n0] = s; o[PF_TH_REF * n0] = th_ref;
+        double sn, cs;
+        rp_sincos(th_ref, &sn, &cs);
+        o[PF_SIN_REF * n0] = sn; o[PF_COS_REF * n0] = cs;
+    } else {
+        const double t = (double)i * a.dt;
+        const double sdd = lon.acc(t);
+        double sd = lon.vel(t);
+        if (fabs(sd) < RP_EPS) sd = 0.0;
+        const double inv_sd = sd > 0.001 ? rp_rcp(sd) : 0.0;
+        const double lam = ds * inv_len;
+        const double c0 = rt.curv[k0], cd0 = rt.curv_d[k0];
+        o[PF_SD * n0] = sd; o[PF_SDD * n0] = sdd; o[PF_INV_SD * n0] = inv_sd;
+        o[PF_KR * n0] = (rt.curv[k1] - c0) * lam + c0;              // :876-880
+        o[PF_KRD * n0] = (rt.curv_d[k1] - cd0) * lam + cd0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Broad phase of the collision query, once per (pair, step) instead of once per (candidate, step, obstacle).
 // All nD candidates of a pair are, at step i, inside a circle that follows from the pair's profile alone:
@@ -550,7 +694,7 @@ struct BoundIn {
     int L;
     double T, lat_T, s0;                                   // pair
     double s_i, px_i, py_i;                                // step i (used when i < L)
-    double sd1, sdd1, kr1, krd1, px1, py1, th1, inv_sd1;   // step L - 1 (used when i >= L)
+    double sd1, sdd1, kr1, krd1, px1, py1, cs1, sn1, inv_sd1;   // step L - 1 (used when i >= L); cs1, sn1 = cos / sin theta_ref
 };
 
 // circle (cx, cy, R) that contains the ego rectangle of every candidate of the pair at step i; false: no bound
@@ -575,10 +719,8 @@ __device__ __forceinline__ bool pair_step_bound(const KArgs &a, int i, const Bou
         const int m = i - L + 1;
         const double c_lo = ext_travel(fmin(v0, v1), fmin(a0, a1), m, a.dt) * (1.0 - 1e-9);
         const double c_hi = ext_travel(fmax(v0, v1), fmax(a0, a1), m, a.dt) * (1.0 + 1e-9);
-        double sn, cs;
-        rp_sincos(in.th1, &sn, &cs);
         const double along = 0.5 * (c_lo + c_hi) + wb;
-        cx = in.px1 + along * cs; cy = in.py1 + along * sn;
+        cx = in.px1 + along * in.cs1; cy = in.py1 + along * in.sn1;   // (cos / sin of theta_ref(L - 1): profile fields)
         R = 0.5 * (c_hi - c_lo) + fmax(fabs(d0), fabs(d1)) + a.ego_radius;
     }
     R = R * (1.0 + 1e-9) + 1e-6;
@@ -593,12 +735,12 @@ __device__ __forceinline__ bool pair_step_bound_fields(const KArgs &a, const Ref
     BoundIn in;
     in.L = lp.L; in.T = lp.T; in.lat_T = lp.lat_T; in.s0 = lp.lon.c0;
     in.s_i = f[PF_S]; in.px_i = f[PF_PX]; in.py_i = f[PF_PY];
-    in.sd1 = in.sdd1 = in.kr1 = in.krd1 = in.px1 = in.py1 = in.th1 = in.inv_sd1 = 0.0;
+    in.sd1 = in.sdd1 = in.kr1 = in.krd1 = in.px1 = in.py1 = in.cs1 = in.sn1 = in.inv_sd1 = 0.0;
     if (i >= lp.L) {
         double g[PF_FIELDS];
         lon_step(a, rt, lp.lon, lp.L - 1, g);
         in.sd1 = g[PF_SD]; in.sdd1 = g[PF_SDD]; in.kr1 = g[PF_KR]; in.krd1 = g[PF_KRD];
-        in.px1 = g[PF_PX]; in.py1 = g[PF_PY]; in.th1 = g[PF_TH_REF]; in.inv_sd1 = g[PF_INV_SD];
+        in.px1 = g[PF_PX]; in.py1 = g[PF_PY]; in.cs1 = g[PF_COS_REF]; in.sn1 = g[PF_SIN_REF]; in.inv_sd1 = g[PF_INV_SD];
     }
     return pair_step_bound(a, i, in, cx, cy, R);
 }
@@ -662,7 +804,8 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
 // and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
-__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgs a) {
+__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsG ag) {
+    const KArgs &a = ag.k;
     extern __shared__ double lds[];
     touch_kernargs<10>();
     const int tid = threadIdx.x;
@@ -738,11 +881,30 @@ __device__ __forceinline__ void st_row(double *p, double v) {
 struct ProfStep { double f[PF_FIELDS]; };
 
 // rows of one profile step: wave-uniform base + 32-bit byte offset per lane (one scalar-operand add per row)
-template <int FIELDS = PF_FIELDS>   // the first FIELDS rows (kernels without a collision query do not read cos / sin of theta_ref)
+// MULV: k * n8 formed per lane (v_mad_u32_u24) instead of 16 hoisted scalar registers (see row_at) -- pays in the variants
+// that run out of scalar registers (16 lanes per candidate), costs a few percent in those that do not (measured: cfg5 draw).
+template <int FIELDS = PF_FIELDS, bool MULV = false>   // the first FIELDS rows (kernels without a collision query do not read cos / sin of theta_ref)
 __device__ __forceinline__ ProfStep load_profile(const char *base, uint32_t off8, uint32_t n8) {
     ProfStep p;
+    if (MULV) asm volatile("" : "+v"(n8));
 #pragma unroll
-    for (int k = 0; k < FIELDS; ++k) p.f[k] = *reinterpret_cast<const double *>(base + (size_t)(off8 + (uint32_t)k * n8));
+    for (int k = 0; k < FIELDS; ++k)
+        p.f[k] = *reinterpret_cast<const double *>(base + (size_t)(MULV ? __umul24((uint32_t)k, n8) + off8 : off8 + (uint32_t)k * n8));
+#pragma unroll
+    for (int k = FIELDS; k < PF_FIELDS; ++k) p.f[k] = 0.0;
+    return p;
+}
+
+// Single-launch variant: the workgroup's own profile rows live in LDS item by item -- [pair][step][PF_STRIDE] doubles,
+// fields of one (pair, step) next to each other -- so that every field sits at a compile-time offset from ONE address per
+// lane (the field-major layout of the global rows costs a scalar row offset per field, 16 registers held across the step
+// loop and spilled).  PF_STRIDE = 17 doubles: lanes of consecutive steps start 17 eight-byte banks apart, conflict-free.
+#define PF_STRIDE (PF_FIELDS + 1)
+template <int FIELDS = PF_FIELDS>
+__device__ __forceinline__ ProfStep load_profile_item(const double *item) {
+    ProfStep p;
+#pragma unroll
+    for (int k = 0; k < FIELDS; ++k) p.f[k] = item[k];
 #pragma unroll
     for (int k = FIELDS; k < PF_FIELDS; ++k) p.f[k] = 0.0;
     return p;
@@ -769,7 +931,7 @@ __device__ __forceinline__ void fetch_lateral(const KArgs &a, int64_t gidx, Cand
         const uint32_t g32 = (uint32_t)gidx, nd = (uint32_t)a.nD;   // candidate indices fit 32 bits (checked by the host)
         const uint32_t p32 = g32 / nd;
         pair = p32;
-        ci.v[0] = a.D[g32 - p32 * nd];
+        ci.v[0] = grid_base(a)[a.nT + a.nL + (int)(g32 - p32 * nd)];
     }
     ci.pair_slot = pair - hdr_pair0;
 }
@@ -812,11 +974,13 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
 // a.lds_pairs) pairs its own candidates belong to into LDS -- the work of rp_lon_kernel without the
 // launch, the global round trip of the profile rows and the kernel boundary.
 template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
-__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgs a) {
+__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgsG ag) {
+    const KArgs &a = ag.k;
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
     constexpr bool RP_WT = LON_FUSED && RP_WRITE_THROUGH;
     touch_kernargs<10>();
+
     const int tid = threadIdx.x;
     RP_STAMP(0);
     RP_TL(0);
@@ -854,7 +1018,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int n0 = a.N + 1;
         double *const lds_tab = lds_out;
         double *const lds_prof = lds_tab + a.table_words;   // table_words is even: 16-byte aligned
-        PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_FIELDS * (size_t)n0);
+        PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_STRIDE * (size_t)n0);   // (PF_STRIDE * 8 * pairs * n0: a multiple of 8)
         int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
         double *const lds_T = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs] time sample of the pair
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
@@ -867,49 +1031,153 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         int P = (int)(p_last - p_first) + 1;
         P = P > a.lds_pairs ? a.lds_pairs : P;   // (cannot happen: the host sizes lds_pairs for the worst alignment)
         const int items = P * n0;                // item = (pair, step)
-        // -- every global load of the prologue is requested here, one round trip for all of them:
-        //    this lane's candidate input, the grid values of its first item, the table block
-        {
-            const int64_t slot0 = wave_first + group_in_wave;
-            const int64_t g0 = a.single_index ? g_first : a.cand_begin + (slot0 < count ? slot0 : (wave_first < count ? wave_first : s_first));
-            fetch_lateral<COEFFS_IN>(a, g0, cin, p_first);
-        }
-        int j = tid;
+        // -- every global load of the prologue is requested here, one round trip for all of them: the grid values of the
+        //    workgroup's pairs and candidates (grid plans: ONE request per value and workgroup, handed on through LDS -- the
+        //    grids may sit in the kernarg segment, which the L2 does not keep: per-lane requests from every wavefront of
+        //    465 workgroups for the same nine lines cost the kernel 1.1 us), the table block
+        __shared__ double sh_gT[GPB], sh_gL[GPB], sh_gD[GPB];
+        __shared__ int sh_gtl[GPB];
+        const int64_t slot0 = wave_first + group_in_wave;
+        const int64_t g0 = a.single_index ? g_first : a.cand_begin + (slot0 < count ? slot0 : (wave_first < count ? wave_first : s_first));
+        int j = lane;   // items are spread over the lanes of every wavefront alike: wavefront w runs part w of lon_step for all of them
         LonPairIn lin;
-        if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
+        double g_T = 0.0, g_L = 0.0, g_D = 0.0;
+        int g_tl = 0;
+        if (COEFFS_IN) {
+            fetch_lateral<COEFFS_IN>(a, g0, cin, p_first);
+            if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
+        } else {
+            cin.pair_slot = (int64_t)((uint32_t)g0 / (uint32_t)a.nD) - p_first;
+            if (tid < P) {
+                const LonPairIn q = lon_pair_fetch<COEFFS_IN>(a, p_first + tid);
+                g_T = q.c[0]; g_L = q.c[1]; g_tl = q.L;
+            } else if (tid >= 64 && tid < 64 + GPB) {
+                const int64_t gq = g_first + (tid - 64);
+                const uint32_t g32 = (uint32_t)(gq <= g_last ? gq : g_last), nd = (uint32_t)a.nD;
+                g_D = grid_base(a)[a.nT + a.nL + (int)(g32 - (g32 / nd) * nd)];
+            }
+        }
         RP_STAMP(15);   // single-launch prologue: candidate / grid loads requested
-        {
+        __shared__ int sh_miss;
+        const bool windowed = a.win_n > 0;
+        if (windowed) {
+            // the vertices [win_k0, win_k0 + win_n) of every row and the bucket entries that point into them, at the places
+            // they have in the whole block (8-byte pieces: rows start at multiples of n_ref doubles)
+            const int wn = a.win_n, total = TB_ROWS * wn;
+            for (int idx = tid; idx < total; idx += RP_BLOCK) {
+                const int at = (idx >> a.win_shift) * a.n_ref + a.win_k0 + (idx & (wn - 1));
+                lds_tab[at] = a.tables[at];
+            }
+            const int *bsrc = reinterpret_cast<const int *>(a.tables + TB_ROWS * a.n_ref) + a.win_b0;
+            int *bdst = reinterpret_cast<int *>(lds_tab + TB_ROWS * a.n_ref) + a.win_b0;
+            for (int idx = tid; idx < a.win_nb; idx += RP_BLOCK) bdst[idx] = bsrc[idx];
+        } else {
             const double2 *src = reinterpret_cast<const double2 *>(a.tables);
             double2 *dst = reinterpret_cast<double2 *>(lds_tab);
             const int nw2 = a.table_words >> 1;
 #pragma unroll 4
             for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
         }
+        if (!COEFFS_IN) {
+            if (tid < P) { sh_gT[tid] = g_T; sh_gL[tid] = g_L; sh_gtl[tid] = g_tl; }
+            else if (tid >= 64 && tid < 64 + GPB) sh_gD[tid - 64] = g_D;
+        }
         RP_STAMP(16);   // table copy issued (this wave's share)
         if (tid < P) lds_flags[tid] = 0;
         if (tid < 10) sh_cnt[tid] = 0;
         if (tid < GPB) { sh_best_cost[tid] = 0.0; sh_best_idx[tid] = -1; }
+        if (tid == 0) sh_miss = 0;
         __syncthreads();
         RP_STAMP(4);    // single-launch prologue: inputs and tables have arrived
-        const RefTab rt = ref_tab(lds_tab, a.n_ref);
-        while (j < items) {
-            const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
-            const LonPair lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
-            double f[PF_FIELDS];
-            lon_step(a, rt, lp.lon, i, f);
-            f[PF_NEAR] = f[PF_NEAR_S] = mask_as_double(0);   // filled by the whole workgroup after the barrier
-            if (i == 0) lds_T[p] = lp.T;
-            double *o = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0 + i;
-#pragma unroll
-            for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n0] = f[k];
-            int fl = 0;   // pre-filter votes, reactive_planner.py:798,802
-            if (i < lp.L) fl = (fabs(f[PF_SDD]) > a.a_max ? 1 : 0) | (f[PF_SD] < -RP_EPS ? 2 : 0);
-            if (fl) atomicOr(&lds_flags[p], fl);
-            if (i == 0) { lds_hdr[p].lat_T = lp.lat_T; lds_hdr[p].s0 = lp.lon.c0; lds_hdr[p].L = lp.L; }
-            j += RP_BLOCK;
-            if (j < items) lin = lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)j / (uint32_t)n0));
+        const RefTab rt = ref_tab(lds_tab, a.n_ref, a.pos_first, a.pos_last);
+        auto item_input = [&](int jj) {   // grid plans: from the workgroup's LDS copy
+            if (COEFFS_IN) return lon_pair_fetch<COEFFS_IN>(a, p_first + (int)((uint32_t)jj / (uint32_t)n0));
+            const int p = (int)((uint32_t)jj / (uint32_t)n0);
+            LonPairIn q;
+            q.c[0] = sh_gT[p]; q.c[1] = sh_gL[p]; q.L = sh_gtl[p];
+            return q;
+        };
+        if (!COEFFS_IN) {
+            cin.v[0] = sh_gD[(int)(g0 - g_first)];
+            if (j < items) lin = item_input(j);
         }
-        __syncthreads();
+        LonPair lp;
+        double s_it = 0.0;
+        if (j < items) {
+            lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
+            s_it = lp.lon.pos((double)(j - (int)((uint32_t)j / (uint32_t)n0) * n0) * a.dt);
+        }
+#pragma nounroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {   // (workgroup-uniform) some item left the window: the whole block, then everything again
+                if (!windowed || !sh_miss) break;
+                const double2 *src = reinterpret_cast<const double2 *>(a.tables);
+                double2 *dst = reinterpret_cast<double2 *>(lds_tab);
+                const int nw2 = a.table_words >> 1;
+                for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+                if (tid < P) lds_flags[tid] = 0;
+                __syncthreads();
+                j = lane;
+                if (j < items) {
+                    lin = item_input(j);
+                    lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
+                    s_it = lp.lon.pos((double)(j - (int)((uint32_t)j / (uint32_t)n0) * n0) * a.dt);
+                }
+            }
+            const bool whole = !windowed || pass == 1;
+            while (j < items) {
+                const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
+                RP_STAMP(18);
+                const double s = s_it;
+                const bool inside = whole || (s >= a.win_s_lo && s < a.win_s_hi);
+                double *o = lds_prof + (size_t)j * PF_STRIDE;   // item j = (p, i): [p][i][field]
+                RP_STAMP(19);
+                if (wave_in_block == 0) {
+                    if (inside) lon_step_part<0>(a, rt, lp.lon, i, s, o, (size_t)1);
+                    else sh_miss = 1;
+                    RP_STAMP(20);
+                } else if (wave_in_block == 1) {
+                    if (inside) lon_step_part<1>(a, rt, lp.lon, i, s, o, (size_t)1);
+                    int fl = 0;   // pre-filter votes, reactive_planner.py:798,802 (the profile's s_ddot, s_dot: polynomial values)
+                    if (i < lp.L) {
+                        const double t = (double)i * a.dt;
+                        double sd = lp.lon.vel(t);
+                        if (fabs(sd) < RP_EPS) sd = 0.0;
+                        fl = (fabs(lp.lon.acc(t)) > a.a_max ? 1 : 0) | (sd < -RP_EPS ? 2 : 0);
+                    }
+                    if (fl) atomicOr(&lds_flags[p], fl);
+                    if (i == 0) { lds_T[p] = lp.T; lds_hdr[p].lat_T = lp.lat_T; lds_hdr[p].s0 = lp.lon.c0; lds_hdr[p].L = lp.L; }
+                } else if (wave_in_block == 2) {
+                    if (inside) lon_step_part<2>(a, rt, lp.lon, i, s, o, (size_t)1);
+                } else {
+                    o[PF_NEAR] = o[PF_NEAR_S] = mask_as_double(0);   // filled by the whole workgroup after the barrier
+                }
+                j += 64;
+                if (j < items) {
+                    lin = item_input(j);
+                    lp = lon_pair_make<COEFFS_IN>(a, lin, n0);
+                    s_it = lp.lon.pos((double)(j - (int)((uint32_t)j / (uint32_t)n0) * n0) * a.dt);
+                }
+            }
+            RP_STAMP(21);
+            __syncthreads();
+        }
+        RP_STAMP(17);   // single-launch prologue: profile rows computed (before the broad-phase masks)
+        // header of this lane's candidate (the pre-filter verdict comes from the votes), its first profile step and its lateral
+        // polynomial (sampling.py:226-238, 268-270) -- here, ahead of the mask phase, whose lanes mostly wait for obstacle rows
+        {
+            const PairHdr h = lds_hdr[cin.pair_slot];
+            const int fl = lds_flags[cin.pair_slot];
+            cin.lat_T = h.lat_T;
+            cin.s0 = h.s0;
+            cin.L = h.L;
+            cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
+                             : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
+            Poly lat;
+            if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
+            else lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
+            if (gl == 0) park_poly(sh_grp[grp].poly, lat);   // same-wave LDS ordering makes it visible to the group
+        }
         if (!COEFFS_IN && a.use_near_mask && a.has_obstacles) {
             // Broad phase of the collision query (near_mask_step), spread over the whole workgroup: one lane per
             // (item, shape) test; every lane derives its item's bound from the profile rows in LDS (one lane per item
@@ -917,20 +1185,18 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             const ObsTables &ob = a.obs;
             auto item_bound = [&](int it, double &bx, double &by, double &bR) -> bool {
                 const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
-                const double *row = lds_prof + (size_t)p * PF_FIELDS * (size_t)n0;
+                const double *row = lds_prof + (size_t)p * PF_STRIDE * (size_t)n0;   // [step][field] of pair p
                 BoundIn in;
                 in.L = lds_hdr[p].L; in.T = lds_T[p]; in.lat_T = lds_hdr[p].lat_T; in.s0 = lds_hdr[p].s0;
-                in.s_i = row[(size_t)PF_S * n0 + i]; in.px_i = row[(size_t)PF_PX * n0 + i]; in.py_i = row[(size_t)PF_PY * n0 + i];
-                const int l1 = in.L - 1;
-                in.sd1 = row[(size_t)PF_SD * n0 + l1]; in.sdd1 = row[(size_t)PF_SDD * n0 + l1];
-                in.kr1 = row[(size_t)PF_KR * n0 + l1]; in.krd1 = row[(size_t)PF_KRD * n0 + l1];
-                in.px1 = row[(size_t)PF_PX * n0 + l1]; in.py1 = row[(size_t)PF_PY * n0 + l1];
-                in.th1 = row[(size_t)PF_TH_REF * n0 + l1]; in.inv_sd1 = row[(size_t)PF_INV_SD * n0 + l1];
+                const double *it_i = row + (size_t)i * PF_STRIDE, *it_1 = row + (size_t)(in.L - 1) * PF_STRIDE;
+                in.s_i = it_i[PF_S]; in.px_i = it_i[PF_PX]; in.py_i = it_i[PF_PY];
+                in.sd1 = it_1[PF_SD]; in.sdd1 = it_1[PF_SDD]; in.kr1 = it_1[PF_KR]; in.krd1 = it_1[PF_KRD];
+                in.px1 = it_1[PF_PX]; in.py1 = it_1[PF_PY]; in.cs1 = it_1[PF_COS_REF]; in.sn1 = it_1[PF_SIN_REF];
+                in.inv_sd1 = it_1[PF_INV_SD];
                 return pair_step_bound(a, i, in, bx, by, bR);
             };
             auto mask_word = [&](int it, int field) -> unsigned long long * {
-                const int p = (int)((uint32_t)it / (uint32_t)n0), i = it - p * n0;
-                return reinterpret_cast<unsigned long long *>(lds_prof + ((size_t)p * PF_FIELDS + field) * (size_t)n0 + i);
+                return reinterpret_cast<unsigned long long *>(lds_prof + (size_t)it * PF_STRIDE + field);
             };
             const gcdouble dyn = (gcdouble)ob.dyn;
             const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
@@ -944,17 +1210,32 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int i = it - (int)((uint32_t)it / (uint32_t)n0) * n0;
                 const int kk = a.time_step0 + i * a.factor - ob.dyn_t0;
                 const bool dyn_here = ob.n_dyn > 0 && kk >= 0 && kk < ob.n_steps;   // else: no dynamic obstacle at this scenario step
+                // this lane's first obstacle circle is requested before the bound is worked out (the bound is ~100 dependent
+                // instructions on LDS values: the round trip hides behind them)
+                const bool first = dyn_here && sub < ob.n_dyn;
+                double f_cx = 0.0, f_cy = 0.0, f_r = 0.0;
+                if (first) {
+                    const gcdouble o = dyn + (size_t)sub * ob.n_steps + kk;
+                    f_cx = o[0]; f_cy = o[plane]; f_r = o[6 * plane];
+                }
                 double bx, by, bR;
-                if (!item_bound(it, bx, by, bR)) {   // no bound: every bit
+                RP_STAMP(22);
+                const bool bounded = item_bound(it, bx, by, bR);
+                RP_STAMP(23);
+                if (!bounded) {   // no bound: every bit
                     if (sub == 0 && dyn_here) atomicOr(mask_word(it, PF_NEAR), ~0ull);
                     if (sub == 0 && slots > 0) atomicOr(mask_word(it, PF_NEAR_S), ~0ull);
                     continue;
                 }
                 if (dyn_here) {
                     uint64_t m = 0;
-                    for (int jo = sub; jo < ob.n_dyn; jo += lanes_per_item) {
+                    if (first) {
+                        const double dx = f_cx - bx, dy = f_cy - by, rr = bR + f_r;   // NaN centre: absent, no bit
+                        if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (sub < 63 ? sub : 63);
+                    }
+                    for (int jo = sub + lanes_per_item; jo < ob.n_dyn; jo += lanes_per_item) {
                         const gcdouble o = dyn + (size_t)jo * ob.n_steps + kk;
-                        const double dx = o[0] - bx, dy = o[plane] - by, rr = bR + o[6 * plane];   // NaN centre: absent, no bit
+                        const double dx = o[0] - bx, dy = o[plane] - by, rr = bR + o[6 * plane];
                         if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (jo < 63 ? jo : 63);
                     }
                     if (m) atomicOr(mask_word(it, PF_NEAR), m);
@@ -973,18 +1254,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         prof_base = lds_prof;
         hdr_base = lds_hdr;
         pair0 = p_first;
-        // header of this lane's candidate; the pre-filter verdict comes from the votes
-        {
-            const PairHdr h = lds_hdr[cin.pair_slot];
-            const int fl = lds_flags[cin.pair_slot];
-            cin.lat_T = h.lat_T;
-            cin.s0 = h.s0;
-            cin.L = h.L;
-            cin.pre_reason = (a.flags & RP_FLAG_DRAW_ALL) ? RP_REASON_NONE
-                             : ((fl & 1) ? RP_REASON_ACCELERATION : ((fl & 2) ? RP_REASON_VELOCITY : RP_REASON_NONE));
-            pf0 = load_profile<PFN>(reinterpret_cast<const char *>(lds_prof), (uint32_t)cin.pair_slot * PF_FIELDS * (uint32_t)n0 * 8u + (uint32_t)(gl <= a.N ? gl : a.N) * 8u,
-                               (uint32_t)n0 * 8u);
-        }
+        pf0 = load_profile_item<PFN>(lds_prof + ((size_t)cin.pair_slot * (size_t)n0 + (size_t)(gl <= a.N ? gl : a.N)) * PF_STRIDE);
     } else {
         // (lanes without a candidate shadow the first candidate of their wavefront: its profile rows exist and are close)
         const int64_t slot0 = wave_first + group_in_wave;
@@ -993,7 +1263,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int32_t ps0 = (int32_t)((COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0);
         const int32_t pw0 = __builtin_amdgcn_readfirstlane(ps0);   // pair of the wavefront's first candidate (wave-uniform)
         const uint32_t n80 = (uint32_t)(a.N + 1) * 8u;
-        pf0 = load_profile<PFN>(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
+        pf0 = load_profile<PFN, G == 16>(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
                            (uint32_t)(ps0 - pw0) * PF_FIELDS * n80 + (uint32_t)(gl <= a.N ? gl : a.N) * 8u, n80);
     }
 
@@ -1065,7 +1335,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const char *const pbase = reinterpret_cast<const char *>(prof_base + ((size_t)pair_w * PF_FIELDS) * (size_t)n);
         const uint32_t poff8 = (uint32_t)(pair_slot_ - pair_w) * PF_FIELDS * n8p;
         ProfStep pf = pf0;
-        {
+        if (!LON_FUSED) {   // (single-launch variant: parked in the prologue)
             Poly lat;
             if (COEFFS_IN) lat = {cin.v[0], cin.v[1], cin.v[2], cin.v[3], cin.v[4], cin.v[5]};
             else lat = quintic_coeffs(al.x0_lat[0], al.x0_lat[1], al.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
@@ -1093,8 +1363,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                                              : reinterpret_cast<char *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n));
             const uint32_t n8 = (uint32_t)n * 8u;
             const uint32_t lane_off8 = (uint32_t)group_in_wave * RP_N_ARRAYS * n8;   // this group's candidate inside the wavefront
+            // row * n8 is formed where it is used, from a per-lane copy of n8 the compiler cannot see through (one
+            // v_mad_u32_u24 per row): as a loop invariant it would be hoisted into 14 scalar registers that live across
+            // the whole step loop -- the kernel runs out of those first (spilled ones cost a v_readlane per use)
+            // (only where scalar registers are short: the single-launch variants; elsewhere the extra multiply costs ~4 %)
+            constexpr bool ROW_MULV = LON_FUSED;
+            uint32_t n8v = n8;
             auto row_at = [&](uint32_t off8, int row) -> double * {
-                return reinterpret_cast<double *>(obase + (size_t)(off8 + (uint32_t)row * n8));
+                return reinterpret_cast<double *>(obase + (size_t)(ROW_MULV ? __umul24((uint32_t)row, n8v) + off8 : off8 + (uint32_t)row * n8));
             };
 
 #pragma nounroll
@@ -1103,9 +1379,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const int i = base + gl;
                 const bool live = i <= N;
                 const bool act = i < L;
+                if (ROW_MULV) asm volatile("" : "+v"(n8v));   // (see row_at: keeps row * n8 out of the loop-invariant scalar registers)
 
                 // -- this step of the pair's longitudinal profile (coalesced: lanes = consecutive steps)
-                if (!ONE_CHUNK && c > 0) pf = load_profile<PFN>(pbase, poff8 + (uint32_t)(live ? i : N) * 8u, n8p);   // dead lanes clamp into the rows
+                if (!ONE_CHUNK && c > 0) {   // dead lanes clamp into the rows
+                    if (LON_FUSED) pf = load_profile_item<PFN>(prof_base + ((size_t)pair_slot_ * (size_t)n + (size_t)(live ? i : N)) * PF_STRIDE);
+                    else pf = load_profile<PFN, G == 16>(pbase, poff8 + (uint32_t)(live ? i : N) * 8u, n8p);
+                }
                 double s = pf.f[PF_S], sd = pf.f[PF_SD], sdd = pf.f[PF_SDD];
                 const double inv_sd = pf.f[PF_INV_SD], th_ref = pf.f[PF_TH_REF];
                 const double k_r = pf.f[PF_KR], k_r_d = pf.f[PF_KRD];
@@ -1380,20 +1660,22 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     // ---- block partial: lexicographic (cost, index) min + counters ----
     if (al.partials) {
         __syncthreads();
-        if (tid == 0) {
-            BlockPartial bp;
-            bp.best_cost = 0.0;
-            bp.best_index = -1;
-            for (int k = 0; k < GPB; ++k) {
-                if (sh_best_idx[k] >= 0 && better(sh_best_cost[k], (int64_t)sh_best_idx[k], bp.best_cost, bp.best_index)) {
-                    bp.best_cost = sh_best_cost[k];
-                    bp.best_index = (int64_t)sh_best_idx[k];
-                }
+        if (tid < 64) {   // first wavefront: the slots of the lane groups, the counters lane by lane
+            double bc = tid < GPB ? sh_best_cost[tid < GPB ? tid : 0] : 0.0;
+            long long bi = tid < GPB ? sh_best_idx[tid < GPB ? tid : 0] : -1;
+            if (GPB >= 16) {
+                wave_min_pair(bc, bi);   // one DPP reduction instead of a 16-trip walk by one lane (cfg2: 2.1 k -> 1.4 k cycles)
+            } else {                     // 4 or 8 slots: the walk is shorter than the reduction (cfg5 draw: 4 candidates per workgroup)
+                bc = 0.0; bi = -1;
+#pragma unroll
+                for (int k = 0; k < GPB; ++k)
+                    if (sh_best_idx[k] >= 0 && better(sh_best_cost[k], (int64_t)sh_best_idx[k], bc, (int64_t)bi)) { bc = sh_best_cost[k]; bi = sh_best_idx[k]; }
             }
-            bp.n_feasible = sh_cnt[0];
-            bp.n_collision = sh_cnt[1];
-            for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
-            al.partials[blockIdx.x] = bp;
+            BlockPartial *const bp = al.partials + blockIdx.x;
+            if (tid == 0) { bp->best_cost = bi >= 0 ? bc : 0.0; bp->best_index = (int64_t)bi; }
+            if (tid == 1) bp->n_feasible = sh_cnt[0];
+            if (tid == 2) bp->n_collision = sh_cnt[1];
+            if (tid >= 8 && tid < 16) bp->reasons[tid - 8] = sh_cnt[2 + tid - 8];
         }
     }
     RP_STAMP(14);

@@ -96,12 +96,14 @@ __device__ __forceinline__ void rp_sincos(double x, double *s, double *c) {
 __device__ __forceinline__ double ext_travel(double v, double acc, int m, double dt) {
     const double h = dt * acc;   // increment of the progression v + t h
     double t0 = 1.0, t1 = (double)m;   // the range of t whose terms are positive
+    // (quotients through the Newton-refined reciprocal: a quotient off by an ulp moves the clipping point by one term only
+    //  where that term is ~0 -- |v + t h| <= ulp(v) -- far inside the relative slack the callers add)
     if (h < 0.0) {
         if (!(v > 0.0)) return 0.0;
-        t1 = fmin(t1, floor(v / -h));             // v + t h >= 0  <=>  t <= v / -h
+        t1 = fmin(t1, floor(v * rp_rcp(-h)));     // v + t h >= 0  <=>  t <= v / -h
     } else if (v < 0.0) {
         if (!(h > 0.0)) return 0.0;
-        t0 = fmax(t0, floor(-v / h) + 1.0);       // v + t h > 0   <=>  t > -v / h
+        t0 = fmax(t0, floor(-v * rp_rcp(h)) + 1.0);   // v + t h > 0   <=>  t > -v / h
     }
     if (t1 < t0) return 0.0;
     const double cnt = t1 - t0 + 1.0;

@@ -3,6 +3,7 @@ FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI
 WRITE_SIZE is taken as is (exact for 16-B-per-lane streaming stores; 8-B stores are uncalibrated per the guide)."""
 import csv, glob, json, sys, collections
 wl, out = sys.argv[1], sys.argv[2]
+mode = sys.argv[3] if len(sys.argv) > 3 else "draw"
 res = {}
 for tag, sub in (("WRITE_SIZE", "w"), ("FETCH_SIZE", "r")):
     f = glob.glob(f"{out}/{sub}/*/*_counter_collection.csv")[0]
@@ -18,12 +19,12 @@ for tag, sub in (("WRITE_SIZE", "w"), ("FETCH_SIZE", "r")):
     res[tag] = {"kernel": name.split("(")[0], "median_KB": vals[len(vals) // 2], "n": len(vals)}
 w = res["WRITE_SIZE"]["median_KB"] * 1024.0
 r = res["FETCH_SIZE"]["median_KB"] * 1024.0 * 2.0
-summary = {"workload": wl, "mode": "draw", "write_bytes": w, "fetch_bytes_corrected_x2": r, "traffic_bytes": w + r, "detail": res}
+summary = {"workload": wl, "mode": mode, "write_bytes": w, "fetch_bytes_corrected_x2": r, "traffic_bytes": w + r, "detail": res}
 print(json.dumps(summary))
-path = "profiles/r01_pmc_traffic.json"
+path = "profiles/r02_pmc_traffic.json"   # read back by bench.py (roofline.traffic), key "<workload>:<mode>"
 try:
     allr = json.load(open(path))
 except Exception:
     allr = {}
-allr[wl] = summary
+allr[f"{wl}:{mode}"] = summary
 json.dump(allr, open(path, "w"), indent=1)
