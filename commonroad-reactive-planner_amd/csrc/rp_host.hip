@@ -559,6 +559,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         fa.status = ka.status; fa.cost = ka.cost; fa.states = ka.states; fa.partials = fin_in;
         fa.dev_out = drb; fa.host_out = hrb_dev;
         fa.count = ka.count; fa.cand_begin = ka.cand_begin; fa.seq = fin_seq;
+        fa.debug = c->d_debug;
         fa.N = ka.N; fa.n_partials = n_partials; fa.count_inline = small ? 1 : 0; fa.copy_states = copy_states ? 1 : 0;
         launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
         if (c->timing) c->t_sum[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count();
@@ -611,7 +612,9 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         unsigned long long st[32];
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
-        for (int k = 1; k < 26; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        for (int k = 1; k < 24; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+        std::fprintf(stderr, "\nfinalize stamps (cycles since its start):");
+        for (int k = 25; k < 31; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[24]));
         std::fprintf(stderr, "\n");
     }
 #endif

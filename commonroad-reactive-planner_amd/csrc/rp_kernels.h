@@ -299,64 +299,60 @@ struct FinArgs {
     int64_t count, cand_begin;
     unsigned long long seq;      // completion ticket for the host (0: none)
     int32_t N, n_partials, count_inline, copy_states;
+    unsigned long long *debug;   // diagnostic build (-DRP_STAMPS): s_memtime stamps of the phases, slots 26..31
 };
+#ifdef RP_STAMPS
+#define RP_FSTAMP(k)                                                                             \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (a.debug && threadIdx.x == 0) a.debug[(k)] = t_;                                      \
+    } while (0)
+#else
+#define RP_FSTAMP(k) do { } while (0)
+#endif
 
-// Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).  Memory round trips are the cost of this kernel (one workgroup,
-// a few hundred bytes of arithmetic): the block partials AND the first slice of status / cost words are requested together at
-// entry; the winner's state rows are requested as soon as the winner is known and travel while the colliding candidates
-// before it are counted.
+// order-preserving integer image of a double (sign flip): integer atomics then order costs
+__device__ __forceinline__ unsigned long long cost_key(double c) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).  One workgroup that lives a few microseconds: what it costs is
+// (a) memory round trips -- the winner's state rows are requested as soon as the winner is known and travel while the
+// colliding candidates before it are counted -- and (b) the LENGTH of its instruction chains (a lone wavefront issues an
+// instruction every ~10 cycles): only the (cost, index) reduction stands between the partials and the request for the rows,
+// the ten counters are summed while the rows travel; the result header is produced one word per lane instead of by one
+// thread; the host copy of the result leaves through system-scope stores followed by a plain wait -- a system-scope
+// release fence also writes the L2 back, 1.1 us for nothing here.  In-kernel stamps before / after:
+// profiles/r02_finalize_stamps.txt.
 __device__ __forceinline__ void finalize_body(const FinArgs &a) {
-    __shared__ double sh_cost[RP_FIN_THREADS / 64];
-    __shared__ long long sh_idx[RP_FIN_THREADS / 64];
-    __shared__ unsigned long long sh_cnt[10];
     __shared__ unsigned long long sh_before;
-    __shared__ FinalizeOut sh_out;
+    __shared__ unsigned int sh_c32[10];
     const int tid = threadIdx.x;
     const int n_partials = a.n_partials;
+    RP_FSTAMP(24);
     double bc = 0.0;
     long long bi = -1;
-    unsigned long long cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (tid == 0) sh_before = 0;
-    // first slice of the status / cost words (needed only if something collided -- not known yet; 12 B per candidate)
-    constexpr int kUnroll = 8;
-    const int ccount = a.count_inline ? (int)a.count : 0;   // count_inline: at most RP_FINALIZE_MAX
-    uint32_t st0[kUnroll];
-    double cs0[kUnroll];
-    // (RP_FIN_PREFETCH: the first slice of status / cost words requested at entry together with the partials.  Measured
-    //  SLOWER, 6.4 -> 8.2 us: two more buffers on the critical path of a one-workgroup kernel are two more cold address
-    //  translations; most cycles have no colliding candidate and never read the words.  Kept for the record, off.)
-#ifndef RP_FIN_PREFETCH
-#define RP_FIN_PREFETCH 0
-#endif
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-        const int i = tid + u * RP_FIN_THREADS, ic = i < ccount ? i : (ccount > 0 ? ccount - 1 : 0);
-        st0[u] = (RP_FIN_PREFETCH && ccount > 0) ? a.status[ic] : 0u;
-        cs0[u] = (RP_FIN_PREFETCH && ccount > 0) ? a.cost[ic] : 0.0;
-    }
+    unsigned int cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (a thread holds a few partials of < 2^23 candidates each)
     for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
         const BlockPartial p = a.partials[k];
         if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
-        cnt[0] += (unsigned long long)p.n_feasible;
-        cnt[1] += (unsigned long long)p.n_collision;
+        cnt[0] += (unsigned int)p.n_feasible;
+        cnt[1] += (unsigned int)p.n_collision;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned long long)p.reasons[r];
+        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned int)p.reasons[r];
     }
+    if (tid == 0) sh_before = 0;
+    if (tid < 10) sh_c32[tid] = 0;
+    RP_FSTAMP(25);     // partials have arrived
+    // the winner first -- its state rows are the next round trip; the counters are reduced while the rows travel.
+    // (LDS atomics on one address serialise lane by lane: 2 816 of them for the counters alone took 17 k cycles.)
     wave_min_pair(bc, bi);
-    // counters: wavefront sums through 32-bit DPP adds (a thread holds at most a few partials of at most 2^23
-    // candidates each: the sum over 64 lanes stays below 2^32), one LDS word per wave and counter
-    __shared__ double sh_wcnt[RP_FIN_THREADS / 64][10];
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        unsigned int t = (unsigned int)cnt[r];
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);      // lane 15 of every row: row total
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);   // rows 1, 3 += row 0, 2
-        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);   // lane 63: wavefront total
-        if ((tid & 63) == 63) sh_wcnt[tid >> 6][r] = (double)t;
-    }
+    __shared__ double sh_cost[RP_FIN_THREADS / 64];
+    __shared__ long long sh_idx[RP_FIN_THREADS / 64];
     if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
     __syncthreads();
     double wcost = sh_cost[0];
@@ -365,8 +361,9 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
         if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
     const int64_t widx = (int64_t)widx_;
+    const bool have = widx >= 0;
     const int n = a.N + 1;
-    // the winner's state rows are requested now: their round trip overlaps the count below
+    // the winner's state rows are requested now: their round trip overlaps the counter sums and the count below
     constexpr int kRowsPerThread = 4;   // covers 14 (N+1) <= 1024 doubles in registers; longer blocks loop at the end
     double wrow[kRowsPerThread];
     const bool want_rows = a.copy_states && widx >= 0;
@@ -376,23 +373,28 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
         const int k = tid + q * RP_FIN_THREADS;
         wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[k] : 0.0;
     }
-    double n_coll_d = 0.0;
-    for (int w = 0; w < RP_FIN_THREADS / 64; ++w) n_coll_d += sh_wcnt[w][1];
-    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
-    if (ccount > 0 && n_coll_d > 0.0) {
-        int nloc = 0;
-        auto tally = [&](const uint32_t *st, const double *cs, int i0) {
+    // counters: wavefront sums through 32-bit DPP adds, one LDS add per wavefront and counter
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                const int i = i0 + u * RP_FIN_THREADS;
-                const bool coll = i < ccount && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
-                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
-            }
-        };
-        if (RP_FIN_PREFETCH) tally(st0, cs0, tid);
+    for (int r = 0; r < 10; ++r) {
+        unsigned int t = cnt[r];
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);      // lane 15 of every row: row total
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);   // rows 1, 3 += row 0, 2
+        t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);   // lane 63: wavefront total
+        if ((tid & 63) == 63 && t) atomicAdd(&sh_c32[r], t);
+    }
+    __syncthreads();
+    RP_FSTAMP(26);   // winner known, rows requested
+    // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
+    const int ccount = a.count_inline ? (int)a.count : 0;   // count_inline: at most RP_FINALIZE_MAX
+    if (ccount > 0 && sh_c32[1] > 0) {
         // status and cost of kUnroll candidates per lane are requested together (both unconditionally, 12 B per candidate):
         // one candidate per trip with the cost load behind the label test was a chain of dependent round trips
-        for (int i0 = tid + (RP_FIN_PREFETCH ? RP_FIN_THREADS * kUnroll : 0); i0 < ccount; i0 += RP_FIN_THREADS * kUnroll) {
+        constexpr int kUnroll = 8;
+        int nloc = 0;
+        for (int i0 = tid; i0 < ccount; i0 += RP_FIN_THREADS * kUnroll) {
             uint32_t st[kUnroll];
             double cs[kUnroll];
 #pragma unroll
@@ -401,63 +403,61 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
                 st[u] = a.status[ic];
                 cs[u] = a.cost[ic];
             }
-            tally(st, cs, i0);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = i0 + u * RP_FIN_THREADS;
+                const bool coll = i < ccount && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
+                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
+            }
         }
         if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
+        __syncthreads();   // (uniform: sh_c32 is final)
     }
-    if (tid < 10) {
-        double t = 0.0;
-        for (int w = 0; w < RP_FIN_THREADS / 64; ++w) t += sh_wcnt[w][tid];
-        sh_cnt[tid] = (unsigned long long)t;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        FinalizeOut &o = sh_out;
-        o.r.best_index = widx;
-        o.r.best_cost = widx >= 0 ? wcost : __builtin_nan("");
-        o.r.n_candidates = a.count;
-        o.r.n_feasible = (int64_t)sh_cnt[0];
-        o.r.n_collision = (int64_t)sh_cnt[1];
-        o.r.n_collision_before_best = (int64_t)sh_before;
-        for (int r = 0; r < 8; ++r) o.r.reason_counts[r] = (int64_t)sh_cnt[2 + r];
-        o.r.kernel_ms = 0.0;
-        o.r.best_lat_T = __builtin_nan("");
-        for (int k = 0; k < 6; ++k) o.r.best_lon_coeffs[k] = o.r.best_lat_coeffs[k] = __builtin_nan("");
-        o.n_before = sh_before;
-        o.w_status = 0; o.pad_ = 0; o.w_cost = o.r.best_cost;
-        for (int k = 0; k < 13; ++k) o.w_coeffs[k] = __builtin_nan("");
-        o.seq = 0;
-        // (the winner's polynomial coefficients are filled in by the host from best_index and the grids it staged:
-        //  computing them here cost a dependent round trip for T, L, D plus ~60 serial FP64 instructions)
-        if (widx >= 0) o.w_status = RP_LABEL_FEASIBLE;
-    }
+    RP_FSTAMP(27);   // count done
     FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
-    if (want_rows) {   // winner's state block straight from the materialised states (ahead of the header: it does not wait for thread 0)
+    auto host_store = [](void *p, unsigned long long v) {   // system scope: past the L2, no write-back needed afterwards
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    {   // result header, one 8-byte word per lane: rp_result (28 words) | n_before | w_status, pad | w_cost | w_coeffs[13]
+        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+        static_assert(words == 44 && sizeof(rp_result) == 28 * 8, "FinalizeOut layout");
+        if (tid < words) {
+            const int k = tid;
+            const unsigned long long nanb = 0x7ff8000000000000ull;
+            const unsigned long long costb = have ? (unsigned long long)__double_as_longlong(wcost) : nanb;
+            const int ci = k == 3 ? 0 : (k == 5 ? 1 : k - 4);   // counter behind words 3, 5, 6..13
+            unsigned long long v = nanb;                        // coefficients, lat_T: filled in by the host
+            if (k == 0) v = (unsigned long long)widx;
+            else if (k == 1 || k == 30) v = costb;
+            else if (k == 2) v = (unsigned long long)a.count;
+            else if (k == 3 || k == 5 || (k >= 6 && k < 14)) v = (unsigned long long)sh_c32[ci];
+            else if (k == 4 || k == 28) v = sh_before;
+            else if (k == 27) v = 0ull;                                  // kernel_ms
+            else if (k == 29) v = have ? (unsigned long long)RP_LABEL_FEASIBLE : 0ull;   // w_status | pad
+            reinterpret_cast<unsigned long long *>(dev_out)[k] = v;
+            host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
+        }
+    }
+    RP_FSTAMP(28);   // header stored
+    if (want_rows) {   // winner's state block straight from the materialised states
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
 #pragma unroll
         for (int q = 0; q < kRowsPerThread; ++q) {
             const int k = tid + q * RP_FIN_THREADS;
-            if (k < RP_N_ARRAYS * n) { d1[k] = wrow[q]; d2[k] = wrow[q]; }
+            if (k < RP_N_ARRAYS * n) { d1[k] = wrow[q]; host_store(d2 + k, (unsigned long long)__double_as_longlong(wrow[q])); }
         }
         for (int k = tid + kRowsPerThread * RP_FIN_THREADS; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
             const double v = wsrc[k];
             d1[k] = v;
-            d2[k] = v;
+            host_store(d2 + k, (unsigned long long)__double_as_longlong(v));
         }
     }
-    __syncthreads();
-    {   // result header: cooperative copy (8-byte words), everything except the ticket
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&sh_out);
-        unsigned long long *d1 = reinterpret_cast<unsigned long long *>(dev_out), *d2 = reinterpret_cast<unsigned long long *>(host_out);
-        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
-        for (int k = tid; k < words; k += RP_FIN_THREADS) { const unsigned long long v = src[k]; d1[k] = v; d2[k] = v; }
-    }
-    if (a.seq) {   // completion ticket for the spinning host thread: after all result bytes, system scope
-        __threadfence_system();
+    RP_FSTAMP(29);   // rows stored
+    if (a.seq) {   // completion ticket for the spinning host thread: after every wavefront's result stores have been acknowledged
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's stores have left for the host
         __syncthreads();
-        if (tid == 0) {
-            __hip_atomic_store(&host_out->seq, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        RP_FSTAMP(30);   // stores acknowledged
+        if (tid == 0) __hip_atomic_store(&host_out->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1769,10 +1769,6 @@ __global__ __launch_bounds__(RP_SWEPT_THREADS) void rp_swept_kernel(ObsTables ob
 // _get_optimal_trajectory, reactive_planner.py:650-651).  out[0] = min key, out[1] = max key, out[2] = count; keys are the
 // order-preserving integer images of the doubles (sign flip), so that integer atomics order them.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long cost_key(double c) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
 __global__ __launch_bounds__(RP_BLOCK) void rp_cost_range_kernel(const uint32_t *status, const double *cost, int64_t count, unsigned long long *out) {
     __shared__ unsigned long long sh[3];
     if (threadIdx.x == 0) { sh[0] = ~0ull; sh[1] = 0ull; sh[2] = 0ull; }
