@@ -204,6 +204,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
         "rp_cost_range": (C.c_int, [ctx, dp, dp, C.POINTER(C.c_int64)]),
         "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
+        "rp_result_device": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), ip]),
+        "rp_combine_results": (C.c_int, [ctx, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(RpResult), dp, ip, ip]),
         "rp_mailbox_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
         "rp_mailbox_exchange": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_int32, C.POINTER(RpResult), dp,
                                           C.POINTER(RpResult), dp, ip]),
@@ -225,7 +227,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_cost_range", "rp_check_swept", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
+                    "rp_cost_range", "rp_check_swept", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
 
 
@@ -345,6 +347,7 @@ class RpContext:
         st = C.c_uint32()
         cost = C.c_double()
         self._check(self._lib.rp_eval_one(self._h, int(index), dptr(out), C.byref(st), C.byref(cost)), "rp_eval_one")
+        self._serial += 1   # (the device result block now holds this candidate's rows, not the last plan's winner)
         return out, int(st.value), float(cost.value)
 
     def count_collisions_before(self, cost: float, index: int) -> int:
@@ -370,6 +373,23 @@ class RpContext:
         self._check(self._lib.rp_check_swept(self._h, C.byref(params), len(x), dptr(x), dptr(y), dptr(theta),
                                              C.byref(first), dptr(boxes)), "rp_check_swept")
         return (int(first.value), boxes) if want_boxes else int(first.value)
+
+    def result_device(self):
+        """(device address, bytes, rows_valid) of the result block the last plan left in device memory: header + winner
+        state rows, what the device-side winner exchange gathers."""
+        ptr, nbytes, ok = C.c_void_p(), C.c_size_t(), C.c_int32()
+        self._check(self._lib.rp_result_device(self._h, C.byref(ptr), C.byref(nbytes), C.byref(ok)), "rp_result_device")
+        return int(ptr.value or 0), int(nbytes.value), bool(ok.value)
+
+    def combine_results(self, d_msgs_ptr: int, world: int, stream: int = 0):
+        """Global result from the gathered per-rank result blocks (device memory, [world][bytes]): (PlanOutput, owner rank,
+        rows_valid -- False: the owner's state rows were on its host only, exchange host-packed messages for this step)."""
+        res = RpResult()
+        best = np.empty((N_ARRAYS, self._N + 1))
+        owner, rows_ok = C.c_int32(-1), C.c_int32(1)
+        self._check(self._lib.rp_combine_results(self._h, C.c_void_p(d_msgs_ptr), int(world), C.c_void_p(stream or None),
+                                                 C.byref(res), dptr(best), C.byref(owner), C.byref(rows_ok)), "rp_combine_results")
+        return PlanOutput.from_c(res, best), int(owner.value), bool(rows_ok.value)
 
     def select(self, costs, want_best_states: bool = True) -> PlanOutput:
         costs = f64(costs)

@@ -223,11 +223,27 @@ def same_host(dist) -> bool:
     return all(nm == names[0] for nm in names)
 
 
+class _DeviceBlock:
+    """A device address range as an object ``torch.as_tensor`` can alias (``__cuda_array_interface__``, float64 words)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
 class CollectiveExchange:
-    """Persistent buffers + the two collectives of one sharded replanning step."""
+    """The two messages of one sharded replanning step over ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the
+    GPU box, "gloo" in CPU tests).
+
+    Device path (GPU group, real ``RpContext``): the result block ``rp_plan`` left in device memory -- header + winner state
+    rows -- is the send buffer AS IT IS: ``all_gather_into_tensor`` straight from it (no host packing, no H2D / D2H
+    copies), then ``rp_combine_results`` enqueues a one-workgroup kernel behind the collective on the same stream, which
+    picks the global winner, sums the counters and writes the combined block to pinned host memory with a completion
+    ticket the host spins on.  Host path (CPU groups, oracle-backed test contexts, or a plan whose winner rows exist on
+    the host only): messages packed on the host, ``all_gather`` of host tensors (through the device for a GPU group)."""
 
     def __init__(self, dist, device, n: int):
         import torch
+        self.torch = torch
         self.dist, self.device, self.n = dist, device, n
         self.world = dist.get_world_size()
         size = HEAD + N_ARRAYS * n
@@ -239,17 +255,37 @@ class CollectiveExchange:
         self.d_cnt = torch.zeros(1, dtype=torch.int64, device=device)
         self._np_send = self.h_send.numpy()
         self._np_recv = self.h_recv.numpy()
+        self._blk = None        # (ptr, bytes, send view, gather buffer) of the context's device result block
+        self.device_path_steps = 0
+
+    def _device_buffers(self, ptr: int, nbytes: int):
+        if self._blk is None or self._blk[0] != ptr or self._blk[1] != nbytes:
+            send = self.torch.as_tensor(_DeviceBlock(ptr, nbytes), device=self.device)
+            recv = self.torch.empty((self.world, nbytes // 8), dtype=self.torch.float64, device=self.device)
+            self._blk = (ptr, nbytes, send, recv)
+        return self._blk[2], self._blk[3]
 
     def __call__(self, ctx, out: PlanOutput) -> PlanOutput:
         dist = self.dist
-        pack_result(out, self.n, self._np_send)
-        if self.device.type == "cpu":
-            dist.all_gather(list(self.h_recv.unbind(0)), self.h_send)
-        else:
-            self.d_send.copy_(self.h_send, non_blocking=True)
-            dist.all_gather_into_tensor(self.d_recv, self.d_send)
-            self.h_recv.copy_(self.d_recv, non_blocking=False)
-        glob, owner = combine_results(self._np_recv, self.n)
+        glob = owner = None
+        if self.device.type != "cpu" and hasattr(ctx, "result_device") and out.serial and out.serial == getattr(ctx, "_serial", None):
+            ptr, nbytes, _ = ctx.result_device()
+            send, recv = self._device_buffers(ptr, nbytes)
+            dist.all_gather_into_tensor(recv, send)
+            glob, owner, rows_ok = ctx.combine_results(recv.data_ptr(), self.world, self.torch.cuda.current_stream().cuda_stream)
+            if rows_ok:
+                self.device_path_steps += 1
+            else:   # the owner's rows were on its host only (every rank reads the same flag): host-packed messages this time
+                glob = None
+        if glob is None:
+            pack_result(out, self.n, self._np_send)
+            if self.device.type == "cpu":
+                dist.all_gather(list(self.h_recv.unbind(0)), self.h_send)
+            else:
+                self.d_send.copy_(self.h_send, non_blocking=True)
+                dist.all_gather_into_tensor(self.d_recv, self.d_send)
+                self.h_recv.copy_(self.d_recv, non_blocking=False)
+            glob, owner = combine_results(self._np_recv, self.n)
         glob.kernel_ms = out.kernel_ms
         if glob.n_collision > 0:   # second message only when some rank saw a colliding candidate
             n_before = local_collisions_before(ctx, out, glob, owner == dist.get_rank())

@@ -88,6 +88,7 @@ struct rp_ctx {
     unsigned long long t_calls = 0;
     bool t_warm = false;
     std::chrono::steady_clock::time_point t_entry;
+    bool last_rows_on_device = false;   // d_result holds the winner's state rows of the last plan (finalize copied them)
     int last_G = 0;              // lanes per candidate of the last plan
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
@@ -506,6 +507,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     const bool small = count <= RP_FINALIZE_MAX;
     const bool copy_states = mat && best_states != nullptr && count > 0;
     const bool winner_pass = !mat && best_states != nullptr && count > 0;
+    c->last_rows_on_device = copy_states || count == 0;
     const bool ticket = c->spin_wait && small;
     ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
     const unsigned long long seq = ++c->seq;
@@ -575,7 +577,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         KArgs kw = ka;
         kw.single_index = &drb->r.best_index;
         kw.count = 1;
-        kw.status = &drb->w_status;
+        kw.status = &drb->pad_;   // (not w_status: its RP_WSTATUS_ROWS_ON_HOST flag tells the device-side exchange where the rows are)
         kw.cost = &drb->w_cost;
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.coeffs = nullptr;
@@ -1027,7 +1029,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     KArgs kw = l;
     kw.single_index = c->d_single;
     kw.count = 1;
-    kw.status = &drb->w_status;
+    kw.status = &drb->pad_;
     kw.cost = &drb->w_cost;
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
     kw.coeffs = nullptr;
@@ -1050,7 +1052,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
-    if (status) *status = hrb->w_status;
+    if (status) *status = hrb->pad_;
     if (cost) *cost = hrb->w_cost;
     if (states) std::memcpy(states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
     return RP_OK;
@@ -1090,6 +1092,59 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
     }
     KArgs ka = c->last;
     return run_pipeline(c, ka, c->last_mat, c->last_coeffs, true, result, best_states);
+}
+
+int rp_result_device(rp_ctx *c, const void **ptr, size_t *bytes, int32_t *rows_valid) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last || !ptr || !bytes) return fail(c, RP_ESTATE, "rp_result_device: no plan / null output");
+    *ptr = c->d_result;
+    *bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)(c->last.N + 1);
+    if (rows_valid) *rows_valid = c->last_rows_on_device ? 1 : 0;
+    return RP_OK;
+}
+
+int rp_combine_results(rp_ctx *c, const void *d_msgs, int32_t world, void *stream, rp_result *global, double *best_states,
+                       int32_t *owner_rank, int32_t *rows_valid) {
+    if (!c) return RP_EINVAL;
+    if (!c->have_last || !d_msgs || !global) return fail(c, RP_ESTATE, "rp_combine_results: no plan / null argument");
+    if (world < 1 || world > RP_COMBINE_MAX_WORLD) return fail(c, RP_EINVAL, "rp_combine_results: world size out of range [1, 64]");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int n = c->last.N + 1;
+    int rc;
+    if ((rc = ensure_result(c, n)) != RP_OK) return rc;
+    const size_t msg_bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n;
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    const unsigned long long seq = ++c->seq;
+    hrb_host->seq = 0;
+    hipStream_t st = stream ? reinterpret_cast<hipStream_t>(stream) : c->stream;
+    hipLaunchKernelGGL(rp_combine_kernel, dim3(1), dim3(RP_COMBINE_THREADS), 0, st, reinterpret_cast<const char *>(d_msgs), (int)world,
+                       msg_bytes, n, reinterpret_cast<ResultBlock *>(c->h_result_dev), seq);
+    HIP_TRY(c, hipGetLastError());
+    bool done = false;
+    {   // the all-gather ahead of the kernel can take a while on a cold communicator: spin with a generous fall-back
+        const volatile unsigned long long *flag = &hrb_host->seq;
+        const auto t_start = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
+            if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
+            __builtin_ia32_pause();
+        }
+    }
+    if (!done) {
+        HIP_TRY(c, hipStreamSynchronize(st));
+        if (__atomic_load_n(&hrb_host->seq, __ATOMIC_ACQUIRE) != seq) return fail(c, RP_EHIP, "rp_combine_results: no completion ticket");
+    }
+    *global = hrb_host->r;
+    global->n_collision_before_best = 0;
+    global->kernel_ms = 0.0;
+    KArgs ka = c->last;
+    host_winner_coeffs(c, ka, c->last_coeffs, global);
+    if (owner_rank) *owner_rank = (int32_t)hrb_host->pad_;
+    const bool rows_ok = !(hrb_host->w_status & RP_WSTATUS_ROWS_ON_HOST);
+    if (rows_valid) *rows_valid = rows_ok ? 1 : 0;
+    if (global->best_index >= 0 && best_states && rows_ok)
+        std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
+    return RP_OK;
 }
 
 int rp_cost_range(rp_ctx *c, double *min_cost, double *max_cost, int64_t *n_out) {

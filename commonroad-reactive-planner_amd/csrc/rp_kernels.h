@@ -250,6 +250,8 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 #define RP_FINALIZE_MAX (1 << 14)   // above: the count of colliding samples before the winner runs as its own many-workgroup
                                     // kernel (one workgroup walking 60 000 status words took 139 us on cfg3)
 
+#define RP_WSTATUS_ROWS_ON_HOST 0x100u   // FinalizeOut.w_status: the winner's state rows are NOT behind this header in device memory
+                                         // (non-materialising plans re-evaluate the winner straight into the host mirror)
 struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
     rp_result r;
     unsigned long long n_before;
@@ -433,7 +435,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
             else if (k == 3 || k == 5 || (k >= 6 && k < 14)) v = (unsigned long long)sh_c32[ci];
             else if (k == 4 || k == 28) v = sh_before;
             else if (k == 27) v = 0ull;                                  // kernel_ms
-            else if (k == 29) v = have ? (unsigned long long)RP_LABEL_FEASIBLE : 0ull;   // w_status | pad
+            else if (k == 29) v = have ? (unsigned long long)(RP_LABEL_FEASIBLE | (want_rows ? 0u : RP_WSTATUS_ROWS_ON_HOST)) : 0ull;   // w_status | pad
             reinterpret_cast<unsigned long long *>(dev_out)[k] = v;
             host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
         }
@@ -1685,6 +1687,76 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         __syncthreads();
         if (tid == 0) __hip_atomic_store(al.host_seq, al.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU winner exchange on the device (replaces the multiprocessing.Queue fan-in of
+// ReactivePlanner._get_optimal_trajectory, reactive_planner.py:1084-1111): every rank's result block -- FinalizeOut header
+// + winner state rows, exactly what rp_finalize_kernel left in device memory -- has been all-gathered (RCCL) into `msgs`
+// [world][msg_bytes]; one workgroup picks the global winner (lexicographic (cost, index)), sums the counters, and writes
+// the combined block to the pinned host mirror, followed by the completion ticket.  pad_ of the output = owner rank.
+// The count of colliding candidates before the GLOBAL winner is a second, rarely needed message (distributed.py).
+// ------------------------------------------------------------------------------------------------
+#define RP_COMBINE_THREADS 256
+#define RP_COMBINE_MAX_WORLD 64
+__global__ __launch_bounds__(RP_COMBINE_THREADS) void rp_combine_kernel(const char *msgs, int world, size_t msg_bytes, int n,
+                                                                        FinalizeOut *host_out, unsigned long long seq) {
+    __shared__ double sh_cost[RP_COMBINE_MAX_WORLD];
+    __shared__ long long sh_idx[RP_COMBINE_MAX_WORLD];
+    __shared__ long long sh_cnt[RP_COMBINE_MAX_WORLD][11];   // n_candidates, n_feasible, n_collision, reasons[8]
+    __shared__ int sh_owner;
+    __shared__ long long sh_sum[11];
+    __shared__ unsigned int sh_flag[RP_COMBINE_MAX_WORLD];
+    const int tid = threadIdx.x;
+    if (tid < world) {
+        const FinalizeOut *m = reinterpret_cast<const FinalizeOut *>(msgs + (size_t)tid * msg_bytes);
+        sh_flag[tid] = m->w_status & RP_WSTATUS_ROWS_ON_HOST;
+        sh_cost[tid] = m->r.best_cost;
+        sh_idx[tid] = m->r.best_index;
+        sh_cnt[tid][0] = m->r.n_candidates; sh_cnt[tid][1] = m->r.n_feasible; sh_cnt[tid][2] = m->r.n_collision;
+        for (int k = 0; k < 8; ++k) sh_cnt[tid][3 + k] = m->r.reason_counts[k];
+    }
+    __syncthreads();
+    if (tid < 11) {
+        long long t = 0;
+        for (int r = 0; r < world; ++r) t += sh_cnt[r][tid];
+        sh_sum[tid] = t;
+    }
+    if (tid == 32) {   // (another wavefront than the sums)
+        int owner = -1;
+        for (int r = 0; r < world; ++r)
+            if (sh_idx[r] >= 0 && (owner < 0 || better(sh_cost[r], (int64_t)sh_idx[r], sh_cost[owner], (int64_t)sh_idx[owner]))) owner = r;
+        sh_owner = owner;
+    }
+    __syncthreads();
+    const int owner = sh_owner;
+    auto host_store = [](void *p, unsigned long long v) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+    if (tid < words) {
+        const int k = tid;
+        const unsigned long long nanb = 0x7ff8000000000000ull;
+        unsigned long long v = nanb;
+        if (k == 0) v = (unsigned long long)(owner >= 0 ? sh_idx[owner] : -1ll);
+        else if (k == 1 || k == 30) v = owner >= 0 ? (unsigned long long)__double_as_longlong(sh_cost[owner]) : nanb;
+        else if (k == 2) v = (unsigned long long)sh_sum[0];
+        else if (k == 3) v = (unsigned long long)sh_sum[1];
+        else if (k == 4 || k == 28) v = 0ull;                       // collisions before the global winner: second message
+        else if (k == 5) v = (unsigned long long)sh_sum[2];
+        else if (k >= 6 && k < 14) v = (unsigned long long)sh_sum[3 + k - 6];
+        else if (k == 27) v = 0ull;
+        else if (k == 29) v = (owner >= 0 ? (unsigned long long)(RP_LABEL_FEASIBLE | sh_flag[owner]) : 0ull) | ((unsigned long long)(unsigned int)owner << 32);
+        host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
+    }
+    if (owner >= 0) {
+        const double *src = reinterpret_cast<const double *>(msgs + (size_t)owner * msg_bytes + sizeof(FinalizeOut));
+        double *dst = reinterpret_cast<double *>(host_out + 1);
+        for (int k = tid; k < RP_N_ARRAYS * n; k += RP_COMBINE_THREADS) host_store(dst + k, (unsigned long long)__double_as_longlong(src[k]));
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -220,6 +220,24 @@ int rp_cost_range(rp_ctx *ctx, double *min_cost, double *max_cost, int64_t *n);
 int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const double *x, const double *y,
                    const double *theta, int32_t *first_hit, double *boxes);
 
+/* ---- multi-GPU winner exchange on the device ----------------------------------------------------
+   Candidate ranges sharded over GPUs (one process per GPU): every rank's rp_plan leaves its result block -- header +
+   winner state rows -- in device memory.  rp_result_device hands out its address and size, so that the caller can pass
+   it to a collective as it is (torch.distributed / RCCL all_gather_into_tensor: no host packing, no copies);
+   rows_valid = 0 means the winner's rows exist on the host only (large batches in non-materialising mode, where the
+   winner is re-evaluated straight into host memory); the header says so, the block is gathered all the same.
+   rp_combine_results takes the gathered blocks [world][bytes] (device memory), enqueues the combining kernel on
+   `stream` (a hipStream_t; the stream the collective was enqueued on, so that it runs after it; NULL: the context's)
+   and returns the global result: winner = lexicographic (cost, index) minimum over the ranks, counters summed, winner's
+   coefficients and state rows, owner rank (-1: no winner).  *rows_valid = 0: the OWNER's rows were on its host only --
+   best_states is not written, every rank sees the same flag and the caller exchanges host-packed messages for this step.
+   n_collision_before_best is 0: that count depends on the global winner and is a second message
+   (rp_count_collisions_before + a sum).  Replaces the fan-in of ReactivePlanner._get_optimal_trajectory's
+   multiprocessing.Queue (commonroad_rp/reactive_planner.py:1084-1111). */
+int rp_result_device(rp_ctx *ctx, const void **ptr, size_t *bytes, int32_t *rows_valid);
+int rp_combine_results(rp_ctx *ctx, const void *d_msgs, int32_t world, void *stream, rp_result *global, double *best_states,
+                       int32_t *owner_rank, int32_t *rows_valid);
+
 /* ---- intra-node winner exchange (host only; no GPU involved) -----------------------------------
    Replaces the reference's only "communication backend", the multiprocessing.Queue fan-out of
    ReactivePlanner._get_optimal_trajectory (commonroad_rp/reactive_planner.py:1084-1111), for candidate ranges
