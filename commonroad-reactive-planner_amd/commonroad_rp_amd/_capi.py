@@ -204,6 +204,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
         "rp_cost_range": (C.c_int, [ctx, dp, dp, C.POINTER(C.c_int64)]),
         "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
+        "rp_build_reference": (C.c_int, [C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, ip, dp, dp, dp, dp, dp]),
+        "rp_project": (C.c_int, [C.c_int32, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
+        "rp_initial_state": (C.c_int, [C.c_int32, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                       C.c_double, C.c_double, C.c_double, C.c_int32, dp, dp]),
         "rp_result_device": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), ip]),
         "rp_combine_results": (C.c_int, [ctx, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(RpResult), dp, ip, ip]),
         "rp_mailbox_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -227,8 +231,70 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_cost_range", "rp_check_swept", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
+                    "rp_cost_range", "rp_check_swept", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
+
+
+# ---- reference-path front end (host-only entry points: no context, no GPU) -------------------------
+E_DOMAIN, E_DIRECTION = -5, -6
+
+
+def build_reference(reference, smooth: bool = True, resample_step: float = 1.0):
+    """``rp_build_reference``: (polyline (n, 2), ref_pos, ref_theta, ref_curv, ref_curv_d) of a route centre line --
+    what ``CoordinateSystem.__init__`` computes (utils_coordinate_system.py:88-118)."""
+    lib = load_library()
+    xy = f64(reference)
+    if xy.ndim != 2 or xy.shape[1] != 2 or len(xy) < 2:
+        raise ValueError("reference path: expected an (n, 2) array with n >= 2")
+    cap = max(len(xy), 256)
+    for _ in range(2):
+        out = np.empty((cap, 2))
+        tabs = [np.empty(cap) for _ in range(4)]
+        n = C.c_int32(0)
+        rc = lib.rp_build_reference(len(xy), dptr(xy), int(bool(smooth)), float(resample_step), cap, C.byref(n), dptr(out),
+                                    *[dptr(t) for t in tabs])
+        if rc == 0:
+            k = n.value
+            return (np.ascontiguousarray(out[:k]),) + tuple(np.ascontiguousarray(t[:k]) for t in tabs)
+        if rc != -4:
+            raise ValueError(f"rp_build_reference -> {rc}: unusable reference path (fewer than "
+                             f"{4 if smooth else 2} distinct vertices, or non-finite coordinates)")
+        cap = n.value
+    raise RpError("rp_build_reference: output size changed between calls")
+
+
+def project(ref_xy, ref_pos, x: float, y: float, proj_domain_d_limit: float = 20.0):
+    """``rp_project``: (s, d) of a Cartesian point; ValueError outside the projection domain, as
+    ``CoordinateSystem.convert_to_curvilinear_coords`` raises (utils_coordinate_system.py:176-178)."""
+    lib = load_library()
+    s, d = C.c_double(), C.c_double()
+    rc = lib.rp_project(len(ref_pos), dptr(ref_xy), dptr(ref_pos), float(proj_domain_d_limit), float(x), float(y),
+                        C.byref(s), C.byref(d))
+    if rc == E_DOMAIN:
+        raise ValueError("<CoordinateSystem.convert_to_curvilinear_coords>: point outside projection domain")
+    if rc != 0:
+        raise RpError(f"rp_project -> {rc}")
+    return np.array([s.value, d.value])
+
+
+def initial_state(ref_xy, ref_pos, ref_theta, ref_curv, ref_curv_d, x, y, orientation, velocity, acceleration=0.0,
+                  steering_angle=0.0, wheelbase=1.0, low_vel_mode=False, proj_domain_d_limit=20.0):
+    """``rp_initial_state``: (x_0_lon, x_0_lat) as ``ReactivePlanner._compute_initial_states`` returns them
+    (reactive_planner.py:446-512), with the exceptions the reference raises."""
+    lib = load_library()
+    lon, lat = (C.c_double * 3)(), (C.c_double * 3)()
+    rc = lib.rp_initial_state(len(ref_pos), dptr(ref_xy), dptr(ref_pos), dptr(ref_theta), dptr(ref_curv), dptr(ref_curv_d),
+                              float(proj_domain_d_limit), float(x), float(y), float(orientation), float(velocity),
+                              float(acceleration), float(steering_angle), float(wheelbase), int(bool(low_vel_mode)),
+                              C.cast(lon, _DP), C.cast(lat, _DP))
+    if rc == E_DOMAIN:
+        raise ValueError("Initial state could not be transformed.")
+    if rc == E_DIRECTION:
+        raise Exception("Initial state or reference incorrect! The longitudinal velocity along the reference path is negative: "
+                        "the ego vehicle does not drive in the direction of the reference path")
+    if rc != 0:
+        raise RpError(f"rp_initial_state -> {rc}")
+    return list(lon), list(lat)
 
 
 class RpContext:

@@ -3,12 +3,15 @@
 Mirrors the interface of ``commonroad_rp.utility.utils_coordinate_system.CoordinateSystem``
 (reference: commonroad_rp/utility/utils_coordinate_system.py:86-178): the attributes
 ``reference, ref_pos, ref_curv, ref_theta, ref_curv_d`` and the two ``convert_to_*`` methods.
+The work behind it is native: ``rp_build_reference`` (duplicate removal, cubic-spline smoothing,
+resampling, tables) and ``rp_project`` ((x, y) -> (s, d)) of the C ABI (include/rp_amd.h,
+csrc/rp_frontend.h; host-only entry points, no GPU needed).
 
 The reference delegates the geometry to the un-vendored C++ package commonroad-drivability-checker
 2024.1 (``pycrccosy.CurvilinearCoordinateSystem`` and ``commonroad_dc.geometry.util``), whose source
-is not under /root/reference.  This module therefore *defines* the transform explicitly
+is not under /root/reference.  This build therefore *defines* the transform explicitly
 (polyline segment + linearly interpolated vertex tangent, normal = tangent rotated by +90 deg,
-normalised) -- the same definition is implemented by ``oracle/rp_oracle.c`` and by the HIP kernels
+normalised) -- the same definition is implemented by ``oracle/`` and by the HIP kernels
 (``csrc/rp_device.h``), and it is what the golden fixtures were generated with.
 Parity with the real CCosy is unpinned.
 
@@ -18,16 +21,9 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = [
-    "compute_pathlength_from_polyline",
-    "compute_orientation_from_polyline",
-    "compute_curvature_from_polyline",
-    "compute_vertex_tangents",
-    "resample_polyline",
-    "interpolate_angle",
-    "make_valid_orientation",
-    "CoordinateSystem",
-]
+from . import _capi
+
+__all__ = ["compute_vertex_tangents", "interpolate_angle", "make_valid_orientation", "CoordinateSystem"]
 
 TWO_PI = 2.0 * np.pi
 
@@ -49,35 +45,6 @@ def interpolate_angle(x: float, x1: float, x2: float, y1: float, y2: float) -> f
     return make_valid_orientation(delta * (x - x1) / (x2 - x1) + y1)
 
 
-def compute_pathlength_from_polyline(polyline: np.ndarray) -> np.ndarray:
-    """Cumulative arc length, first entry 0 (commonroad_dc.geometry.util, used at
-    utils_coordinate_system.py:114)."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    seg = np.sqrt(np.sum(np.diff(polyline, axis=0) ** 2, axis=1))
-    return np.concatenate(([0.0], np.cumsum(seg)))
-
-
-def compute_orientation_from_polyline(polyline: np.ndarray) -> np.ndarray:
-    """Segment headings; the last vertex repeats the last segment's heading
-    (commonroad_dc.geometry.util, used at utils_coordinate_system.py:116)."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    d = np.diff(polyline, axis=0)
-    theta = np.arctan2(d[:, 1], d[:, 0])
-    return np.concatenate((theta, theta[-1:]))
-
-
-def compute_curvature_from_polyline(polyline: np.ndarray) -> np.ndarray:
-    """Signed curvature from second-order finite differences over arc length
-    (commonroad_dc.geometry.util, used at utils_coordinate_system.py:115)."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    s = compute_pathlength_from_polyline(polyline)
-    x_d = np.gradient(polyline[:, 0], s)
-    x_dd = np.gradient(x_d, s)
-    y_d = np.gradient(polyline[:, 1], s)
-    y_dd = np.gradient(y_d, s)
-    return (x_d * y_dd - x_dd * y_d) / ((x_d ** 2 + y_d ** 2) ** 1.5)
-
-
 def compute_vertex_tangents(polyline: np.ndarray) -> np.ndarray:
     """Unit tangent per vertex: normalised sum of the two adjacent unit segment directions
     (end vertices: the single adjacent segment).  The operation order here is the contract that
@@ -97,17 +64,6 @@ def compute_vertex_tangents(polyline: np.ndarray) -> np.ndarray:
     return t
 
 
-def resample_polyline(polyline: np.ndarray, step: float = 1.0) -> np.ndarray:
-    """Equidistant resampling by linear interpolation over arc length (set-up helper)."""
-    polyline = np.asarray(polyline, dtype=np.float64)
-    s = compute_pathlength_from_polyline(polyline)
-    n = max(int(np.floor(s[-1] / step)) + 1, 2)
-    s_new = np.arange(n) * step
-    if s[-1] - s_new[-1] > 1e-9:
-        s_new = np.append(s_new, s[-1])
-    return np.stack((np.interp(s_new, s, polyline[:, 0]), np.interp(s_new, s, polyline[:, 1])), axis=1)
-
-
 class CoordinateSystem:
     """Drop-in for the reference ``CoordinateSystem`` on the hot path's side of the boundary.
 
@@ -116,18 +72,15 @@ class CoordinateSystem:
         (CCosy's ``default_projection_domain_limit``; 20 m there).
     """
 
-    def __init__(self, reference: np.ndarray, proj_domain_d_limit: float = 20.0):
+    def __init__(self, reference: np.ndarray, proj_domain_d_limit: float = 20.0, smooth_reference: bool = False,
+                 resample_step: float = 1.0):
         reference = np.asarray(reference, dtype=np.float64)
         assert reference.ndim == 2 and reference.shape[1] == 2 and reference.shape[0] >= 2
-        keep = np.ones(len(reference), dtype=bool)
-        keep[1:] = np.any(np.diff(reference, axis=0) != 0.0, axis=1)
-        self._reference = np.ascontiguousarray(reference[keep])
         self.proj_domain_d_limit = float(proj_domain_d_limit)
-        # utils_coordinate_system.py:114-117
-        self._ref_pos = compute_pathlength_from_polyline(self._reference)
-        self._ref_curv = compute_curvature_from_polyline(self._reference)
-        self._ref_theta = np.unwrap(compute_orientation_from_polyline(self._reference))
-        self._ref_curv_d = np.gradient(self._ref_curv, self._ref_pos)
+        # utils_coordinate_system.py:88-118 in one native call: duplicates removed, smoothed and resampled when asked
+        # (the reference smooths by default; here the caller says so: the fixtures and workloads hand in final polylines)
+        (self._reference, self._ref_pos, self._ref_theta, self._ref_curv, self._ref_curv_d) = _capi.build_reference(
+            reference, smooth=smooth_reference, resample_step=resample_step)
         self._tangent = compute_vertex_tangents(self._reference)
 
     # --- reference-compatible read-only views ------------------------------------------------
@@ -182,38 +135,14 @@ class CoordinateSystem:
     def convert_to_curvilinear_coords(self, x: float, y: float):
         """(x, y) -> (s, d); raises ValueError outside the projection domain
         (reference: utils_coordinate_system.py:176-178; used once per replan for the initial
-        state at reactive_planner.py:458).  Per segment the foot point solves
+        state at reactive_planner.py:458).  ``rp_project``: per segment the foot point solves
         ((P - p0) - lam*e) . ((1-lam) t0 + lam t1) = 0, a quadratic in lam."""
-        P = np.array([x, y], dtype=np.float64)
-        ref = self._reference
-        tan = self._tangent
-        e = ref[1:] - ref[:-1]
-        q = P[None, :] - ref[:-1]
-        t0 = tan[:-1]
-        dt = tan[1:] - tan[:-1]
-        # (q - lam e).(t0 + lam dt) = q.t0 + lam (q.dt - e.t0) - lam^2 e.dt
-        a = -np.sum(e * dt, axis=1)
-        b = np.sum(q * dt, axis=1) - np.sum(e * t0, axis=1)
-        c = np.sum(q * t0, axis=1)
-        best = None
-        for k in range(len(e)):
-            if abs(a[k]) < 1e-14:
-                roots = [-c[k] / b[k]] if b[k] != 0.0 else []
-            else:
-                disc = b[k] * b[k] - 4.0 * a[k] * c[k]
-                if disc < 0.0:
-                    continue
-                sq = np.sqrt(disc)
-                roots = [(-b[k] + sq) / (2.0 * a[k]), (-b[k] - sq) / (2.0 * a[k])]
-            for lam in roots:
-                if -1e-12 <= lam <= 1.0 + 1e-12:
-                    lam = min(max(lam, 0.0), 1.0)
-                    tx, ty = t0[k] + lam * dt[k]
-                    tn = np.sqrt(tx * tx + ty * ty)
-                    foot = ref[k] + lam * e[k]
-                    dd = (-(P[0] - foot[0]) * ty + (P[1] - foot[1]) * tx) / tn
-                    if abs(dd) <= self.proj_domain_d_limit and (best is None or abs(dd) < abs(best[1])):
-                        best = (self._ref_pos[k] + lam * (self._ref_pos[k + 1] - self._ref_pos[k]), dd)
-        if best is None:
-            raise ValueError("<CoordinateSystem.convert_to_curvilinear_coords>: point outside projection domain")
-        return np.array(best)
+        return _capi.project(self._reference, self._ref_pos, x, y, self.proj_domain_d_limit)
+
+    def initial_state(self, x: float, y: float, orientation: float, velocity: float, acceleration: float = 0.0,
+                      steering_angle: float = 0.0, wheelbase: float = 1.0, low_vel_mode: bool = False):
+        """Frenet state (x_0_lon, x_0_lat) of a Cartesian rear-axle state: ``rp_initial_state``, i.e.
+        ``ReactivePlanner._compute_initial_states`` (reactive_planner.py:446-512)."""
+        return _capi.initial_state(self._reference, self._ref_pos, self._ref_theta, self._ref_curv, self._ref_curv_d, x, y,
+                                   orientation, velocity, acceleration, steering_angle, wheelbase, low_vel_mode,
+                                   self.proj_domain_d_limit)

@@ -495,8 +495,7 @@ class ReactivePlanner(GpuBackendMixin):
     def set_reference_path(self, reference_path: np.ndarray = None, coordinate_system: CoordinateSystem = None):
         if coordinate_system is None:
             assert reference_path is not None, "<set reference path>: Please provide a reference path OR a CoordinateSystem object to the planner."
-            from .workloads import smooth_ref_path
-            self._co = CoordinateSystem(smooth_ref_path(reference_path))
+            self._co = CoordinateSystem(reference_path, smooth_reference=True)   # (utils_coordinate_system.py:88: smoothed by default)
         else:
             assert reference_path is None, "<set reference path>: Please provide a reference path OR a CoordinateSystem object to the planner."
             self._co = coordinate_system
@@ -575,11 +574,10 @@ class ReactivePlanner(GpuBackendMixin):
     def _compute_initial_states(self, x_0: ReactivePlannerState):
         if not self._co or x_0 is None:
             return None
-        from .workloads import initial_curvilinear_state
         try:
-            return initial_curvilinear_state(self._co, x_0.position[0], x_0.position[1], x_0.orientation, x_0.velocity,
-                                             acceleration=x_0.acceleration or 0.0, steering_angle=x_0.steering_angle or 0.0,
-                                             low_vel_mode=self._low_vel_mode, wheelbase=self.vehicle_params.wheelbase)
+            return self._co.initial_state(x_0.position[0], x_0.position[1], x_0.orientation, x_0.velocity,
+                                          acceleration=x_0.acceleration or 0.0, steering_angle=x_0.steering_angle or 0.0,
+                                          wheelbase=self.vehicle_params.wheelbase, low_vel_mode=self._low_vel_mode)
         except ValueError:
             logger.critical("Initial state could not be transformed.")
             raise ValueError("Initial state could not be transformed.")

@@ -16,7 +16,7 @@ import numpy as np
 
 from ._capi import PlanInputs, make_cost, make_params
 from .collision import ObstacleTables
-from .coordinate_system import CoordinateSystem, interpolate_angle, resample_polyline
+from .coordinate_system import CoordinateSystem
 
 _REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SCENARIO_DIR = os.path.join(_REPO, "tests", "golden")
@@ -44,56 +44,9 @@ class Workload:
         ctx.set_obstacles(self.obstacles)
 
 
-def smooth_ref_path(ref_path: np.ndarray, resample_step: float = 1.0) -> np.ndarray:
-    """Cubic-spline smoothing + equidistant resampling of a route centre line, as
-    ``smooth_ref_path`` does (utils_coordinate_system.py:74-83: splprep k=3 s=0, 200 samples)."""
-    from scipy.interpolate import splprep, splev
-    ref_path = np.asarray(ref_path, dtype=np.float64)
-    keep = np.ones(len(ref_path), dtype=bool)
-    keep[1:] = np.any(np.diff(ref_path, axis=0) != 0.0, axis=1)
-    ref_path = ref_path[keep]
-    tck, u = splprep(ref_path.T, u=None, k=3, s=0.0)
-    u_new = np.linspace(u.min(), u.max(), 200)
-    x_new, y_new = splev(u_new, tck, der=0)
-    return resample_polyline(np.array([x_new, y_new]).transpose(), resample_step)
-
-
 def traj_len_of(T, dt: float) -> np.ndarray:
     """``len(np.arange(0, np.round(T + dt, 5), dt))`` (reactive_planner.py:733,748)."""
     return np.array([len(np.arange(0, np.round(t + dt, 5), dt)) for t in np.atleast_1d(T)], dtype=np.int32)
-
-
-def initial_curvilinear_state(co: CoordinateSystem, x: float, y: float, orientation: float, velocity: float,
-                              acceleration: float = 0.0, steering_angle: float = 0.0, low_vel_mode: bool = False,
-                              wheelbase: float = VEHICLE2["wheelbase"]):
-    """``ReactivePlanner._compute_initial_states`` (reactive_planner.py:446-512), once per replan."""
-    s, d = co.convert_to_curvilinear_coords(x, y)
-    ref_pos = co.ref_pos
-    s_idx = int(np.argmax(ref_pos > s)) - 1
-    s_lambda = (s - ref_pos[s_idx]) / (ref_pos[s_idx + 1] - ref_pos[s_idx])
-    ref_theta = np.unwrap(co.ref_theta)
-    theta_cl = orientation - interpolate_angle(s, ref_pos[s_idx], ref_pos[s_idx + 1], ref_theta[s_idx],
-                                               ref_theta[s_idx + 1])
-    kr = (co.ref_curv[s_idx + 1] - co.ref_curv[s_idx]) * s_lambda + co.ref_curv[s_idx]
-    kr_d = (co.ref_curv_d[s_idx + 1] - co.ref_curv_d[s_idx]) * s_lambda + co.ref_curv_d[s_idx]
-    kappa_0 = np.tan(steering_angle) / wheelbase
-    d_p = (1 - kr * d) * np.tan(theta_cl)
-    d_pp = -(kr_d * d + kr * d_p) * np.tan(theta_cl) + ((1 - kr * d) / (math.cos(theta_cl) ** 2)) * (
-        kappa_0 * (1 - kr * d) / math.cos(theta_cl) - kr)
-    s_velocity = velocity * math.cos(theta_cl) / (1 - kr * d)
-    if s_velocity < 0:
-        raise Exception("Initial state or reference incorrect! Curvilinear velocity is negative which indicates"
-                        "that the ego vehicle is not driving in the same direction as specified by the reference")
-    s_acceleration = acceleration
-    s_acceleration -= (s_velocity ** 2 / math.cos(theta_cl)) * (
-        (1 - kr * d) * np.tan(theta_cl) * (kappa_0 * (1 - kr * d) / (math.cos(theta_cl)) - kr) - (kr_d * d + kr * d_p))
-    s_acceleration /= ((1 - kr * d) / (math.cos(theta_cl)))
-    if low_vel_mode:
-        d_velocity, d_acceleration = d_p, d_pp
-    else:
-        d_velocity = velocity * math.sin(theta_cl)
-        d_acceleration = s_acceleration * d_p + s_velocity ** 2 * d_pp
-    return [float(s), float(s_velocity), float(s_acceleration)], [float(d), float(d_velocity), float(d_acceleration)]
 
 
 def velocity_range(v0: float, horizon: float, a_max: float = VEHICLE2["a_max"]):
@@ -116,12 +69,12 @@ def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired
                        flags=0, description="", extra_jitter=1.5, extra_lane=4.0, road_boundary=False) -> Workload:
     sc = _load_scenario(scen_name)
     dt = float(sc["dt"])
-    co = CoordinateSystem(smooth_ref_path(sc["centre"]))
+    co = CoordinateSystem(sc["centre"], smooth_reference=True)   # (the reference smooths a route by default, utils_coordinate_system.py:88,98-100)
     x, y, th, v0 = (float(v) for v in sc["init"])
     # the planner state sits on the rear axle (state.py:52-55)
     xr, yr = x - VEHICLE2["wb_rear_axle"] * math.cos(th), y - VEHICLE2["wb_rear_axle"] * math.sin(th)
     low = v0 < low_vel_threshold
-    x0_lon, x0_lat = initial_curvilinear_state(co, xr, yr, th, v0, low_vel_mode=low)
+    x0_lon, x0_lat = co.initial_state(xr, yr, th, v0, wheelbase=VEHICLE2["wheelbase"], low_vel_mode=low)
     vmin, vmax = velocity_range(v0, N * dt)
     L = np.linspace(vmin, vmax, nL)
     D = _with_d0(np.linspace(-3.0, 3.0, nD), x0_lat[0])

@@ -1,0 +1,337 @@
+// rp_frontend.h -- reference-path front end of the planner: host-side C++ behind the C ABI entries rp_build_reference,
+// rp_project and rp_initial_state (include/rp_amd.h).  Set-up work, once per route (a few hundred vertices) or once per
+// replanning cycle (one point): it stays on the host -- there is nothing to batch.
+//
+// What it replaces (paths relative to /root/reference):
+//   CoordinateSystem.__init__                 commonroad_rp/utility/utils_coordinate_system.py:88-118
+//   smooth_ref_path                           commonroad_rp/utility/utils_coordinate_system.py:74-83
+//   ReactivePlanner._compute_initial_states   commonroad_rp/reactive_planner.py:446-512
+// Third-party pieces behind those lines, restated from their published algorithms:
+//   scipy.interpolate.splprep(k=3, s=0) / splev (FITPACK parcur / splev, SciPy 1.10.1 in the reference's lock file): the
+//     interpolating cubic B-spline through the points, chord-length parameter normalised to [0, 1], interior knots at
+//     u[2] .. u[m-3] (fpcurf.f: "find the position of the interior knots in case of interpolation"), evaluated by de Boor.
+//   numpy.unique(axis=0, return_index) + sort, numpy.unwrap, numpy.gradient (second-order, non-uniform spacing).
+//   commonroad_dc.geometry.util (resample_polyline, compute_pathlength / orientation / curvature_from_polyline) and
+//     pycrccosy (projection (x, y) -> (s, d)): source not under /root/reference; the definitions of this build
+//     (commonroad_rp_amd/coordinate_system.py) -- unpinned against the real packages.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace rpfe {
+
+struct Pt { double x, y; };
+
+// reference[np.sort(np.unique(reference, axis=0, return_index=True)[1])]: first occurrence of every distinct vertex, in
+// the original order (utils_coordinate_system.py:95-96, 103-104)
+inline std::vector<Pt> unique_vertices(const std::vector<Pt> &p) {
+    std::vector<int> order(p.size());
+    for (size_t i = 0; i < p.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p[a].x < p[b].x || (p[a].x == p[b].x && p[a].y < p[b].y); });
+    std::vector<char> keep(p.size(), 0);
+    for (size_t k = 0; k < order.size(); ++k)
+        if (k == 0 || p[order[k]].x != p[order[k - 1]].x || p[order[k]].y != p[order[k - 1]].y) keep[order[k]] = 1;   // stable: smallest index of the run
+    std::vector<Pt> out;
+    for (size_t i = 0; i < p.size(); ++i)
+        if (keep[i]) out.push_back(p[i]);
+    return out;
+}
+
+// ---- cubic B-splines (FITPACK conventions: knots t[0..n-1], coefficients c[0..n-5], degree 3) ---------------------------
+// non-zero basis functions B_{l-3..l}(u) for t[l] <= u < t[l+1] (de Boor / Cox recursion, fpbspl.f)
+inline void bspline_basis(const std::vector<double> &t, int l, double u, double h[4]) {
+    double hh[3];
+    h[0] = 1.0;
+    for (int j = 1; j <= 3; ++j) {
+        for (int i = 0; i < j; ++i) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 0; i < j; ++i) {
+            const int li = l + i + 1, lj = li - j;
+            const double f = hh[i] / (t[li] - t[lj]);
+            h[i] += f * (t[li] - u);
+            h[i + 1] = f * (u - t[lj]);
+        }
+    }
+}
+
+// interpolating cubic spline through (u_i, f_i), i < m, m >= 4: solves the (m x m, bandwidth 4) collocation system by
+// Gaussian elimination with row pivoting inside the band.  Returns false for a singular system.
+inline bool interpolating_spline(const std::vector<double> &u, const std::vector<double> &fx, const std::vector<double> &fy,
+                                 std::vector<double> &t, std::vector<double> &cx, std::vector<double> &cy) {
+    const int m = (int)u.size();
+    if (m < 4) return false;
+    const int n = m + 4;
+    t.assign(n, 0.0);
+    for (int i = 0; i < 4; ++i) { t[i] = u[0]; t[n - 1 - i] = u[m - 1]; }
+    for (int i = 0; i < m - 4; ++i) t[4 + i] = u[2 + i];   // interior knots u[2] .. u[m-3]
+    std::vector<double> A((size_t)m * m, 0.0);               // (m is a few hundred at most: a dense matrix is fine)
+    int l = 3;
+    for (int i = 0; i < m; ++i) {
+        while (l < n - 5 && u[i] >= t[l + 1]) ++l;           // t[l] <= u_i < t[l+1]; the last point sits in the last interval
+        double h[4];
+        bspline_basis(t, l, u[i], h);
+        for (int j = 0; j < 4; ++j) A[(size_t)i * m + (l - 3 + j)] = h[j];
+    }
+    cx = fx;
+    cy = fy;
+    for (int k = 0; k < m; ++k) {
+        int p = k;
+        double best = std::fabs(A[(size_t)k * m + k]);
+        const int r1 = std::min(m, k + 4);
+        for (int i = k + 1; i < r1; ++i)
+            if (std::fabs(A[(size_t)i * m + k]) > best) { best = std::fabs(A[(size_t)i * m + k]); p = i; }
+        if (best == 0.0) return false;
+        if (p != k) {
+            for (int j = 0; j < m; ++j) std::swap(A[(size_t)k * m + j], A[(size_t)p * m + j]);
+            std::swap(cx[k], cx[p]);
+            std::swap(cy[k], cy[p]);
+        }
+        const int c1 = std::min(m, k + 8);
+        for (int i = k + 1; i < r1; ++i) {
+            const double f = A[(size_t)i * m + k] / A[(size_t)k * m + k];
+            if (f == 0.0) continue;
+            for (int j = k; j < c1; ++j) A[(size_t)i * m + j] -= f * A[(size_t)k * m + j];
+            cx[i] -= f * cx[k];
+            cy[i] -= f * cy[k];
+        }
+    }
+    for (int k = m - 1; k >= 0; --k) {
+        const int c1 = std::min(m, k + 8);
+        double sx = cx[k], sy = cy[k];
+        for (int j = k + 1; j < c1; ++j) { sx -= A[(size_t)k * m + j] * cx[j]; sy -= A[(size_t)k * m + j] * cy[j]; }
+        cx[k] = sx / A[(size_t)k * m + k];
+        cy[k] = sy / A[(size_t)k * m + k];
+    }
+    return true;
+}
+
+inline Pt spline_eval(const std::vector<double> &t, const std::vector<double> &cx, const std::vector<double> &cy, double u) {
+    const int n = (int)t.size();
+    int l = 3;
+    while (l < n - 5 && u >= t[l + 1]) ++l;
+    double h[4];
+    bspline_basis(t, l, u, h);
+    Pt r = {0.0, 0.0};
+    for (int j = 0; j < 4; ++j) { r.x += cx[l - 3 + j] * h[j]; r.y += cy[l - 3 + j] * h[j]; }
+    return r;
+}
+
+// ---- polyline utilities (this build's definitions of commonroad_dc.geometry.util) ---------------------------------------
+inline std::vector<double> pathlength(const std::vector<Pt> &p) {
+    std::vector<double> s(p.size(), 0.0);
+    for (size_t i = 1; i < p.size(); ++i) {
+        const double dx = p[i].x - p[i - 1].x, dy = p[i].y - p[i - 1].y;
+        s[i] = s[i - 1] + std::sqrt(dx * dx + dy * dy);
+    }
+    return s;
+}
+
+// equidistant resampling by linear interpolation over arc length; the end point is kept when it lies more than 1e-9 m
+// beyond the last multiple of `step`
+inline std::vector<Pt> resample(const std::vector<Pt> &p, double step) {
+    const std::vector<double> s = pathlength(p);
+    const double total = s.back();
+    int n = std::max((int)std::floor(total / step) + 1, 2);
+    std::vector<double> at(n);
+    for (int i = 0; i < n; ++i) at[i] = i * step;
+    if (total - at.back() > 1e-9) at.push_back(total);
+    std::vector<Pt> out;
+    size_t k = 0;
+    for (double q : at) {   // np.interp: clamps beyond the ends
+        if (q <= s.front()) { out.push_back(p.front()); continue; }
+        if (q >= s.back()) { out.push_back(p.back()); continue; }
+        while (k + 2 < s.size() && s[k + 1] <= q) ++k;
+        const double slope_x = (p[k + 1].x - p[k].x) / (s[k + 1] - s[k]), slope_y = (p[k + 1].y - p[k].y) / (s[k + 1] - s[k]);
+        out.push_back({slope_x * (q - s[k]) + p[k].x, slope_y * (q - s[k]) + p[k].y});
+    }
+    return out;
+}
+
+// np.gradient(f, x): second-order central differences for non-uniform spacing, one-sided first differences at the ends
+inline std::vector<double> gradient(const std::vector<double> &f, const std::vector<double> &x) {
+    const int n = (int)f.size();
+    std::vector<double> g(n, 0.0);
+    if (n < 2) return g;
+    for (int i = 1; i + 1 < n; ++i) {
+        const double hd = x[i + 1] - x[i], hs = x[i] - x[i - 1];
+        const double a = -hd / (hs * (hd + hs)), b = (hd - hs) / (hd * hs), c = hs / (hd * (hd + hs));
+        g[i] = a * f[i - 1] + b * f[i] + c * f[i + 1];
+    }
+    g[0] = (f[1] - f[0]) / (x[1] - x[0]);
+    g[n - 1] = (f[n - 1] - f[n - 2]) / (x[n - 1] - x[n - 2]);
+    return g;
+}
+
+// np.unwrap (period 2 pi)
+inline void unwrap(std::vector<double> &p) {
+    const double pi = 3.14159265358979323846, two_pi = 2.0 * pi;
+    double corr = 0.0, prev = p.empty() ? 0.0 : p[0];
+    for (size_t i = 1; i < p.size(); ++i) {
+        const double dd = p[i] - prev;
+        double ddmod = std::fmod(dd + pi, two_pi);
+        if (ddmod < 0.0) ddmod += two_pi;   // numpy's mod: result has the sign of the divisor
+        ddmod -= pi;
+        if (ddmod == -pi && dd > 0.0) ddmod = pi;
+        double ph = ddmod - dd;
+        if (std::fabs(dd) < pi) ph = 0.0;
+        corr += ph;
+        prev = p[i];
+        p[i] += corr;
+    }
+}
+
+struct Tables {
+    std::vector<Pt> ref;
+    std::vector<double> pos, theta, curv, curv_d;
+};
+
+// utils_coordinate_system.py:114-117 over the final polyline
+inline void tables_of(Tables &tb) {
+    const std::vector<Pt> &p = tb.ref;
+    const int n = (int)p.size();
+    tb.pos = pathlength(p);
+    std::vector<double> x(n), y(n);
+    for (int i = 0; i < n; ++i) { x[i] = p[i].x; y[i] = p[i].y; }
+    const std::vector<double> xd = gradient(x, tb.pos), yd = gradient(y, tb.pos);
+    const std::vector<double> xdd = gradient(xd, tb.pos), ydd = gradient(yd, tb.pos);
+    tb.curv.resize(n);
+    for (int i = 0; i < n; ++i) tb.curv[i] = (xd[i] * ydd[i] - xdd[i] * yd[i]) / std::pow(xd[i] * xd[i] + yd[i] * yd[i], 1.5);
+    tb.theta.resize(n);
+    for (int i = 0; i + 1 < n; ++i) tb.theta[i] = std::atan2(p[i + 1].y - p[i].y, p[i + 1].x - p[i].x);
+    tb.theta[n - 1] = tb.theta[n - 2];
+    unwrap(tb.theta);
+    tb.curv_d = gradient(tb.curv, tb.pos);
+}
+
+// CoordinateSystem.__init__ (utils_coordinate_system.py:88-118).  Returns 0, or -1 for unusable input.
+inline int build_reference(const std::vector<Pt> &in, bool smooth, double resample_step, Tables &tb) {
+    std::vector<Pt> ref = unique_vertices(in);
+    if (ref.size() < 2) return -1;
+    if (smooth) {   // smooth_ref_path, :74-83
+        const int m = (int)ref.size();
+        if (m < 4) return -1;   // (splprep: m > k must hold)
+        std::vector<double> u(m, 0.0), fx(m), fy(m), t, cx, cy;
+        for (int i = 0; i < m; ++i) { fx[i] = ref[i].x; fy[i] = ref[i].y; }
+        for (int i = 1; i < m; ++i) {
+            const double dx = ref[i].x - ref[i - 1].x, dy = ref[i].y - ref[i - 1].y;
+            u[i] = u[i - 1] + std::sqrt(dx * dx + dy * dy);
+        }
+        if (!(u[m - 1] > 0.0)) return -1;
+        for (int i = 1; i < m; ++i) u[i] /= u[m - 1];
+        if (!interpolating_spline(u, fx, fy, t, cx, cy)) return -1;
+        std::vector<Pt> fine(200);
+        for (int k = 0; k < 200; ++k) {   // np.linspace(0, 1, 200)
+            const double uk = k == 199 ? 1.0 : k * (1.0 / 199.0);
+            fine[k] = spline_eval(t, cx, cy, uk);
+        }
+        ref = unique_vertices(resample(fine, resample_step));
+        if (ref.size() < 2) return -1;
+    }
+    tb.ref = ref;
+    tables_of(tb);
+    return 0;
+}
+
+// unit tangent per vertex: normalised sum of the two adjacent unit segment directions (same as rp_set_reference)
+inline std::vector<Pt> vertex_tangents(const std::vector<Pt> &p) {
+    const int n = (int)p.size();
+    std::vector<Pt> u(n - 1), t(n);
+    for (int i = 0; i + 1 < n; ++i) {
+        const double ex = p[i + 1].x - p[i].x, ey = p[i + 1].y - p[i].y, ln = std::sqrt(ex * ex + ey * ey);
+        u[i] = {ex / ln, ey / ln};
+    }
+    t[0] = u[0];
+    t[n - 1] = u[n - 2];
+    for (int i = 1; i + 1 < n; ++i) {
+        const double sx = u[i - 1].x + u[i].x, sy = u[i - 1].y + u[i].y, tn = std::sqrt(sx * sx + sy * sy);
+        t[i] = {sx / tn, sy / tn};
+    }
+    return t;
+}
+
+// (x, y) -> (s, d): the inverse of the kernels' (s, d) -> (x, y) = foot point + d * unit normal, normal = interpolated vertex
+// tangent rotated by +90 degrees.  Per segment the foot point solves ((P - p0) - lam e) . ((1 - lam) t0 + lam t1) = 0, a
+// quadratic in lam; of all admissible roots the one with the smallest |d| wins.  false: outside the projection domain.
+inline bool project(const std::vector<Pt> &ref, const std::vector<double> &pos, double d_limit, double x, double y, double &s_out, double &d_out) {
+    const std::vector<Pt> tan = vertex_tangents(ref);
+    bool have = false;
+    for (size_t k = 0; k + 1 < ref.size(); ++k) {
+        const double ex = ref[k + 1].x - ref[k].x, ey = ref[k + 1].y - ref[k].y;
+        const double qx = x - ref[k].x, qy = y - ref[k].y;
+        const double t0x = tan[k].x, t0y = tan[k].y, dtx = tan[k + 1].x - t0x, dty = tan[k + 1].y - t0y;
+        const double a = -(ex * dtx + ey * dty), b = (qx * dtx + qy * dty) - (ex * t0x + ey * t0y), c = qx * t0x + qy * t0y;
+        double roots[2];
+        int nr = 0;
+        if (std::fabs(a) < 1e-14) {
+            if (b != 0.0) roots[nr++] = -c / b;
+        } else {
+            const double disc = b * b - 4.0 * a * c;
+            if (disc < 0.0) continue;
+            const double sq = std::sqrt(disc);
+            roots[nr++] = (-b + sq) / (2.0 * a);
+            roots[nr++] = (-b - sq) / (2.0 * a);
+        }
+        for (int r = 0; r < nr; ++r) {
+            double lam = roots[r];
+            if (!(lam >= -1e-12 && lam <= 1.0 + 1e-12)) continue;
+            lam = std::min(std::max(lam, 0.0), 1.0);
+            const double tx = t0x + lam * dtx, ty = t0y + lam * dty, tn = std::sqrt(tx * tx + ty * ty);
+            const double fx = ref[k].x + lam * ex, fy = ref[k].y + lam * ey;
+            const double dd = (-(x - fx) * ty + (y - fy) * tx) / tn;
+            if (std::fabs(dd) <= d_limit && (!have || std::fabs(dd) < std::fabs(d_out))) {
+                have = true;
+                s_out = pos[k] + lam * (pos[k + 1] - pos[k]);
+                d_out = dd;
+            }
+        }
+    }
+    return have;
+}
+
+// make_valid_orientation (commonroad-io): into [-pi, pi)
+inline double valid_orientation(double a) {
+    const double pi = 3.14159265358979323846, two_pi = 2.0 * pi;
+    double m = std::fmod(a, two_pi);
+    if (m < 0.0) m += two_pi;
+    if (pi <= m && m <= two_pi) m -= two_pi;
+    return m;
+}
+
+// ReactivePlanner._compute_initial_states (reactive_planner.py:446-512) after the projection: Frenet state of a Cartesian
+// state (position = rear axle).  Returns 0; -2 when the longitudinal velocity comes out negative (the reference raises:
+// the vehicle does not drive along the reference path).
+inline int initial_state(const Tables &tb, double s, double d, double orientation, double velocity, double acceleration,
+                         double steering_angle, double wheelbase, bool low_vel_mode, double lon[3], double lat[3]) {
+    const int n = (int)tb.pos.size();
+    // np.argmax(ref_pos > s) - 1; -1 (no vertex beyond s, or s before the first one) indexes from the end, :467-469
+    int ub = 0;
+    while (ub < n && !(tb.pos[ub] > s)) ++ub;
+    const int idx = (ub == n ? 0 : ub) - 1;
+    const int k0 = idx < 0 ? n + idx : idx, k1 = idx + 1;
+    const double seg = tb.pos[k1] - tb.pos[k0];
+    const double w = (s - tb.pos[k0]) / seg;
+    std::vector<double> th = tb.theta;
+    unwrap(th);                                                                                   // :472
+    const double th_ref = valid_orientation((th[k1] - th[k0]) * (s - tb.pos[k0]) / seg + th[k0]);  // interpolate_angle
+    const double th_cl = orientation - th_ref;                                                    // :473-474
+    const double k_r = (tb.curv[k1] - tb.curv[k0]) * w + tb.curv[k0];                             // :477-478
+    const double k_r_d = (tb.curv_d[k1] - tb.curv_d[k0]) * w + tb.curv_d[k0];                     // :480
+    const double kappa0 = std::tan(steering_angle) / wheelbase;                                   // :483
+    const double q = 1.0 - k_r * d, tn = std::tan(th_cl), cs = std::cos(th_cl);
+    const double d_p = q * tn;                                                                    // :486
+    const double d_pp = -(k_r_d * d + k_r * d_p) * tn + (q / (cs * cs)) * (kappa0 * q / cs - k_r);   // :487-488
+    const double s_vel = velocity * cs / q;                                                       // :491
+    if (s_vel < 0.0) return -2;                                                                   // :492-494
+    double s_acc = acceleration;
+    s_acc -= (s_vel * s_vel / cs) * (q * tn * (kappa0 * q / cs - k_r) - (k_r_d * d + k_r * d_p));    // :497-499
+    s_acc /= (q / cs);                                                                            // :500
+    lon[0] = s; lon[1] = s_vel; lon[2] = s_acc;
+    lat[0] = d;
+    if (low_vel_mode) { lat[1] = d_p; lat[2] = d_pp; }                                            // :503-506
+    else { lat[1] = velocity * std::sin(th_cl); lat[2] = s_acc * d_p + s_vel * s_vel * d_pp; }    // :507-510
+    return 0;
+}
+
+}  // namespace rpfe

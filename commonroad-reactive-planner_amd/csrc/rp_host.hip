@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "rp_kernels.h"
+#include "rp_frontend.h"
 
 namespace {
 
@@ -1221,6 +1222,56 @@ int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double 
 
 }  // extern "C"
 
+
+// ------------------------------------------------------------------------------------------------
+// Reference-path front end (host only; rp_frontend.h)
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int rp_build_reference(int32_t n_in, const double *xy_in, int32_t smooth, double resample_step, int32_t cap, int32_t *n_out,
+                       double *xy_out, double *ref_pos, double *ref_theta, double *ref_curv, double *ref_curv_d) {
+    if (n_in < 2 || !xy_in || !n_out || !(resample_step > 0.0)) return RP_EINVAL;
+    std::vector<rpfe::Pt> in((size_t)n_in);
+    for (int i = 0; i < n_in; ++i) {
+        in[i] = {xy_in[2 * i], xy_in[2 * i + 1]};
+        if (!(std::isfinite(in[i].x) && std::isfinite(in[i].y))) return RP_EINVAL;
+    }
+    rpfe::Tables tb;
+    if (rpfe::build_reference(in, smooth != 0, resample_step, tb) != 0) return RP_EINVAL;
+    const int n = (int)tb.ref.size();
+    *n_out = n;
+    if (n > cap || !xy_out || !ref_pos || !ref_theta || !ref_curv || !ref_curv_d) return RP_ENOMEM;   // *n_out tells how much room is needed
+    for (int i = 0; i < n; ++i) {
+        xy_out[2 * i] = tb.ref[i].x; xy_out[2 * i + 1] = tb.ref[i].y;
+        ref_pos[i] = tb.pos[i]; ref_theta[i] = tb.theta[i]; ref_curv[i] = tb.curv[i]; ref_curv_d[i] = tb.curv_d[i];
+    }
+    return RP_OK;
+}
+
+int rp_project(int32_t n, const double *ref_xy, const double *ref_pos, double proj_domain_d_limit, double x, double y, double *s, double *d) {
+    if (n < 2 || !ref_xy || !ref_pos || !s || !d) return RP_EINVAL;
+    std::vector<rpfe::Pt> ref((size_t)n);
+    for (int i = 0; i < n; ++i) ref[i] = {ref_xy[2 * i], ref_xy[2 * i + 1]};
+    const std::vector<double> pos(ref_pos, ref_pos + n);
+    return rpfe::project(ref, pos, proj_domain_d_limit, x, y, *s, *d) ? RP_OK : RP_EDOMAIN;
+}
+
+int rp_initial_state(int32_t n, const double *ref_xy, const double *ref_pos, const double *ref_theta, const double *ref_curv,
+                     const double *ref_curv_d, double proj_domain_d_limit, double x, double y, double orientation, double velocity,
+                     double acceleration, double steering_angle, double wheelbase, int32_t low_vel_mode, double *x0_lon, double *x0_lat) {
+    if (n < 2 || !ref_xy || !ref_pos || !ref_theta || !ref_curv || !ref_curv_d || !x0_lon || !x0_lat || !(wheelbase > 0.0)) return RP_EINVAL;
+    rpfe::Tables tb;
+    tb.ref.resize((size_t)n);
+    for (int i = 0; i < n; ++i) tb.ref[i] = {ref_xy[2 * i], ref_xy[2 * i + 1]};
+    tb.pos.assign(ref_pos, ref_pos + n); tb.theta.assign(ref_theta, ref_theta + n);
+    tb.curv.assign(ref_curv, ref_curv + n); tb.curv_d.assign(ref_curv_d, ref_curv_d + n);
+    double s = 0.0, d = 0.0;
+    if (!rpfe::project(tb.ref, tb.pos, proj_domain_d_limit, x, y, s, d)) return RP_EDOMAIN;
+    return rpfe::initial_state(tb, s, d, orientation, velocity, acceleration, steering_angle, wheelbase, low_vel_mode != 0, x0_lon, x0_lat) == 0
+               ? RP_OK : RP_EDIRECTION;
+}
+
+}  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
 // Intra-node winner exchange through a shared-memory mailbox (include/rp_amd.h).  Slot layout per

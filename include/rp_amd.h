@@ -48,6 +48,8 @@ extern "C" {
 #define RP_EHIP (-2)    /* HIP runtime error (message has the hipError string) */
 #define RP_ESTATE (-3)  /* call sequence error (e.g. rp_plan before rp_set_reference) */
 #define RP_ENOMEM (-4)
+#define RP_EDOMAIN (-5)    /* point outside the projection domain of the reference path */
+#define RP_EDIRECTION (-6) /* the vehicle does not drive along the reference path (negative longitudinal velocity) */
 
 /* per-candidate status word:  label | reason << 4 | first_bad_step << 8 */
 #define RP_LABEL_NONE 0u                 /* reference label None: pre-filtered or left the projection domain */
@@ -219,6 +221,30 @@ int rp_cost_range(rp_ctx *ctx, double *min_cost, double *max_cost, int64_t *n);
  * half width of every segment's rectangle.  Uses the obstacle tables of rp_set_obstacles. */
 int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const double *x, const double *y,
                    const double *theta, int32_t *first_hit, double *boxes);
+
+/* ---- reference-path front end (host only; no GPU involved) ---------------------------------------
+   rp_build_reference: what CoordinateSystem.__init__ makes of a route centre line
+   (commonroad_rp/utility/utils_coordinate_system.py:88-118): duplicate vertices removed (:95-96), with `smooth`
+   the cubic-spline smoothing of smooth_ref_path (:74-83: interpolating cubic B-spline over the chord-length
+   parameter, 200 samples, equidistant resampling at `resample_step` metres) and duplicates removed again (:103-104),
+   then the tables path length, unwrapped orientation, curvature and curvature rate (:114-117) -- the inputs of
+   rp_set_reference.  Output arrays hold `cap` vertices; *n_out is the number written, or, with RP_ENOMEM, the room
+   needed.  rp_project: (x, y) -> (s, d), what CoordinateSystem.convert_to_curvilinear_coords returns (:176-178;
+   RP_EDOMAIN where the reference raises ValueError).  rp_initial_state: ReactivePlanner._compute_initial_states
+   (commonroad_rp/reactive_planner.py:446-512): Frenet state x0_lon = (s, s', s''), x0_lat = (d, d', d'') of a
+   Cartesian rear-axle state; derivatives of d w.r.t. arc length in low-velocity mode (:503-506), w.r.t. time
+   otherwise; RP_EDIRECTION where the reference raises for a negative longitudinal velocity (:492-494).
+   The polyline / projection geometry behind these (commonroad_dc.geometry.util, pycrccosy) is this build's own
+   definition; SciPy's splprep / splev and NumPy's unique / unwrap / gradient are restated. */
+int rp_build_reference(int32_t n_in, const double *xy_in /* [n_in][2] */, int32_t smooth, double resample_step, int32_t cap,
+                       int32_t *n_out, double *xy_out /* [cap][2] */, double *ref_pos, double *ref_theta, double *ref_curv,
+                       double *ref_curv_d);
+int rp_project(int32_t n, const double *ref_xy /* [n][2] */, const double *ref_pos, double proj_domain_d_limit, double x, double y,
+               double *s, double *d);
+int rp_initial_state(int32_t n, const double *ref_xy, const double *ref_pos, const double *ref_theta, const double *ref_curv,
+                     const double *ref_curv_d, double proj_domain_d_limit, double x, double y, double orientation, double velocity,
+                     double acceleration, double steering_angle, double wheelbase, int32_t low_vel_mode, double *x0_lon /* [3] */,
+                     double *x0_lat /* [3] */);
 
 /* ---- multi-GPU winner exchange on the device ----------------------------------------------------
    Candidate ranges sharded over GPUs (one process per GPU): every rank's rp_plan leaves its result block -- header +

@@ -384,6 +384,38 @@ class CollisionChecker:
         return False
 
 
+class CurvilinearCoordinateSystem:
+    """Stand-in for ``commonroad_dc.pycrccosy.CurvilinearCoordinateSystem`` as the reference's ``CoordinateSystem`` uses it
+    (utils_coordinate_system.py:128-129, 139-140, 170, 178): keeps the polyline it is given (the real CCosy extends and
+    may resample it -- not reproducible here), (s, d) <-> (x, y) by this build's definition (oracle/frontend.py)."""
+
+    def __init__(self, reference, default_projection_domain_limit: float = 20.0, eps: float = 0.1):
+        self._ref = np.ascontiguousarray(reference, dtype=float)
+        self._limit = float(default_projection_domain_limit)
+        from oracle import frontend
+        self._fe = frontend
+        self._pos = frontend.compute_pathlength_from_polyline(self._ref)
+
+    def reference_path(self):
+        return [p for p in self._ref]
+
+    def convert_to_curvilinear_coords(self, x, y):
+        sd = self._fe.project(self._ref, self._pos, x, y, self._limit)
+        if sd is None:
+            raise ValueError("<CurvilinearCoordinateSystem/convertToCurvilinearCoords> Coordinate outside of projection domain.")
+        return np.array(sd)
+
+    def convert_to_cartesian_coords(self, s, d):
+        from commonroad_rp_amd.coordinate_system import CoordinateSystem as _Co
+        co = getattr(self, "_co", None)
+        if co is None:
+            co = self._co = _Co(self._ref, self._limit)
+        p = co.convert_to_cartesian_coords(s, d)
+        if p is None:
+            raise ValueError("<CurvilinearCoordinateSystem/convertToCartesianCoords> Coordinate outside of projection domain.")
+        return p
+
+
 # ----------------------------------------------------------------------------------------------
 def install():
     """Inject the stand-ins into ``sys.modules`` and put the reference on ``sys.path``."""
@@ -414,7 +446,7 @@ def install():
     _mod("commonroad_dc")
     _mod("commonroad_dc.pycrcc", CollisionChecker=CollisionChecker, RectOBB=RectOBB,
          TimeVariantCollisionObject=TimeVariantCollisionObject)
-    _mod("commonroad_dc.pycrccosy", CurvilinearCoordinateSystem=_Anything)
+    _mod("commonroad_dc.pycrccosy", CurvilinearCoordinateSystem=CurvilinearCoordinateSystem)
     _mod("commonroad_dc.boundary")
     _mod("commonroad_dc.boundary.boundary", create_road_boundary_obstacle=create_road_boundary_obstacle)
     _mod("commonroad_dc.collision")
@@ -425,9 +457,15 @@ def install():
     _mod("commonroad_dc.feasibility")
     _mod("commonroad_dc.feasibility.vehicle_dynamics", VehicleParameterMapping=VehicleParameterMapping)
     _mod("commonroad_dc.geometry")
-    _mod("commonroad_dc.geometry.util", compute_pathlength_from_polyline=None,
-         compute_curvature_from_polyline=None, compute_orientation_from_polyline=None,
-         resample_polyline=None, chaikins_corner_cutting=None)
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if repo not in sys.path:
+        sys.path.insert(0, repo)
+    from oracle import frontend as _fe   # this build's definitions of the commonroad_dc.geometry.util functions
+    _mod("commonroad_dc.geometry.util", compute_pathlength_from_polyline=_fe.compute_pathlength_from_polyline,
+         compute_curvature_from_polyline=_fe.compute_curvature_from_polyline,
+         compute_orientation_from_polyline=_fe.compute_orientation_from_polyline,
+         resample_polyline=_fe.resample_polyline, chaikins_corner_cutting=None)
     # route planner / vehicle models
     _mod("commonroad_route_planner")
     _mod("commonroad_route_planner.route", Route=_Anything)
