@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import dataclasses
 import os
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -177,6 +178,17 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if _lib is not None and path is None:
         return _lib
     path = path or os.environ.get("RP_AMD_LIBRARY", LIB_PATH)
+    # One HIP runtime per process, and the same one whatever the import order: PyTorch-ROCm brings its own libamdhip64
+    # (same SONAME as the system's), so whichever of the two libraries is loaded first decides which runtime both use.
+    # With this library first, a process that created and destroyed a context and imported torch afterwards found
+    # "No HIP GPUs are available" (observed on the GPU box, ROCm 7.2 system runtime under a torch built for 7.0); with
+    # torch first -- the order bench.py has always had -- everything runs on torch's runtime.  So: torch first, when it
+    # is installed and the process may use it (the multi-GPU exchange does).  RP_AMD_NO_TORCH_PRELOAD=1 skips this.
+    if "torch" not in sys.modules and not os.environ.get("RP_AMD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(path):
         raise RpLibraryMissing(
             f"{path} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()' "
