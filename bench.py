@@ -291,6 +291,7 @@ def run_single(args, torch, device):
         if not args.no_configs:
             result["configs"] = side_configs(args, torch, device, skip=base.name)
         result["plan_latency_ms"] = plan_latency(base, device)
+        result["corridor_sampling"] = corridor_sampling_cost(base, device)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(base, with_mode(seq, args.mode)[0], args.cpu_seconds)
     if ctx is not None:
@@ -353,6 +354,65 @@ def plan_latency(base, device, n_replans=220, warm=20):
     return {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "p99": float(np.percentile(lat, 99)),
             "n": int(len(lat)), "loops": loops, "what": "ReactivePlanner.plan() wall time per closed-loop replan (every time step a new "
             "state, velocity grid and time index), one sampling level of the workload's grid, production mode, Python included"}
+
+
+def corridor_sampling_cost(base, device, reps=15):
+    """A data-dependent sampling space (CorridorSampling, reference sampling.py:273-397: no (T, L, D) product form) on the
+    explicit-polynomial entry rp_plan_coeffs: what one sampling level costs through the reference's object interface (one
+    TrajectorySample per candidate, coefficients extracted) and through the batch view (coefficient arrays), and the device
+    call itself.  Synthetic corridor around the workload's initial state, same time samples as the workload."""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    from commonroad_rp_amd.corridor import ReachBox
+    from commonroad_rp_amd.sampling import CorridorSampling
+    if base.n_candidates > 100000 or base.name == "cfg5":
+        return None
+    rp = W.make_planner(base, device=device)
+    p = base.inputs.params
+    sp = CorridorSampling(rp.config)
+    sp.samples_t._dict_level_to_sample_set[1] = set(float(t) for t in base.inputs.T)
+    sp.set_dict_number_of_samples(dict_level_to_num_samples={k: 21 for k in range(rp.config.sampling.num_sampling_levels)})
+    s0, v0 = p.x0_lon[0], max(p.x0_lon[1], 1.0)
+    cor = {}
+    for q in range(p.N + 2):
+        k = p.time_step0 + q
+        t = q * p.dt
+        cor[k] = [ReachBox(s0 - 1.0, s0 + 1.6 * v0 * t + 4.0, -2.8, -0.3, 0.5 * v0, 1.3 * v0 + 1.0),
+                  ReachBox(s0 + 0.3 * v0 * t, s0 + 1.8 * v0 * t + 6.0, -0.5, 1.4, 0.6 * v0, 1.4 * v0 + 1.0),
+                  ReachBox(s0 + 0.8 * v0 * t + 2.0, s0 + 2.0 * v0 * t + 8.0, 2.0, 3.0, 0.9 * v0, 1.5 * v0 + 1.0)]
+    sp.driving_corridor = cor
+    rp.set_sampling_space(sp)
+    x0_lon, x0_lat = rp.x_0_cl
+    mode = rp.config.sampling.longitudinal_mode
+    t_obj, t_batch, t_dev, t_level, C = [], [], [], [], 0
+    ctx = rp._gpu_ctx()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        trajs = sp.generate_trajectories_at_level(1, x0_lon, x0_lat, mode, False)
+        lon = np.array([t.trajectory_long.coeffs for t in trajs])
+        lat = np.array([t.trajectory_lat.coeffs for t in trajs])
+        lon_T = np.array([t.trajectory_long.delta_tau for t in trajs], dtype=float)
+        tl = np.array([len(np.arange(0, np.round(tt + p.dt, 5), p.dt)) for tt in lon_T], dtype=np.int32)
+        t_obj.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        blon, blat, bT, btl, _, _ = sp.coeffs_at_level(1, x0_lon, x0_lat, mode, False)
+        t_batch.append(time.perf_counter() - t0)
+        C = len(bT)
+        params = rp._gpu_params(x0_lon, x0_lat, 0)
+        cost = rp._gpu_cost()
+        t0 = time.perf_counter()
+        out = ctx.plan_coeffs(params, cost, blon, blat, bT, btl)
+        t_dev.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        rp._get_optimal_trajectory(rp._create_trajectory_bundle(x0_lon, x0_lat, samp_level=1))
+        t_level.append(time.perf_counter() - t0)
+    rp.close()
+    ms = lambda v: float(np.median(v) * 1e3)   # noqa: E731
+    return {"candidates": C, "objects_ms": ms(t_obj), "batch_view_ms": ms(t_batch), "rp_plan_coeffs_ms": ms(t_dev),
+            "one_sampling_level_ms": ms(t_level), "winner": int(out.best_index), "candidates_per_s_device": C / (ms(t_dev) * 1e-3),
+            "what": "CorridorSampling on a synthetic 3-lane corridor, 21 samples per interval: candidate generation through the "
+                    "reference's object interface vs the batch view (coefficient arrays), rp_plan_coeffs on the device, and the "
+                    "planner's whole per-level hot path (batch view + device + winner sample)"}
 
 
 # --------------------------------------------------------------------------------------------------------------------

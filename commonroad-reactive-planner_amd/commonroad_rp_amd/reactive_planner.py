@@ -56,12 +56,15 @@ class GpuTrajectoryBundle:
     sample grids (or, for foreign sampling spaces, explicit polynomials) instead of one Python object
     per candidate.  ``trajectories`` materialises the objects on demand for code that wants them."""
 
-    def __init__(self, planner, level: int, x_0_lon, x_0_lat, grids=None, samples: Optional[List[TrajectorySample]] = None):
+    def __init__(self, planner, level: int, x_0_lon, x_0_lat, grids=None, samples: Optional[List[TrajectorySample]] = None,
+                 coeffs=None):
         self._planner = planner
         self.level = level
         self.x_0_lon, self.x_0_lat = list(x_0_lon), list(x_0_lat)
         self.grids = grids            # (T, traj_len, L, D) or None
         self._samples = samples       # foreign sampling space: list of TrajectorySample
+        self.coeffs = coeffs          # sampling space with a batch view but no product grid (CorridorSampling):
+                                      # (lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])
         self._is_sorted = False
         self.costs: Optional[np.ndarray] = None   # per-candidate costs after _get_optimal_trajectory (when they were fetched)
         self._range_fn = None         # () -> (min, max, n) of the costs on the device: min_costs() / max_costs() without a fetch
@@ -72,10 +75,14 @@ class GpuTrajectoryBundle:
         if self.grids is not None:
             T, _, L, D = self.grids
             return len(T) * len(L) * len(D)
+        if self.coeffs is not None:
+            return len(self.coeffs[2])
         return len(self._samples)
 
     @property
     def trajectories(self) -> List[TrajectorySample]:
+        if self._samples is None and self.coeffs is not None:
+            self._samples = [self._planner._gpu_candidate_sample(self, i) for i in range(len(self.coeffs[2]))]
         if self._samples is None:
             p = self._planner
             self._samples = p.sampling_space.generate_trajectories_at_level(
@@ -277,6 +284,9 @@ class GpuBackendMixin:
         if hasattr(sp, "grids_at_level"):
             grids = sp.grids_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, grids=grids)
+        elif hasattr(sp, "coeffs_at_level"):   # data-dependent candidates (CorridorSampling), batch view: coefficient arrays
+            coeffs = sp.coeffs_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode, self._low_vel_mode)
+            bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, coeffs=coeffs)
         else:   # foreign sampling space: its own objects, polynomials handed to the device explicitly
             samples = sp.generate_trajectories_at_level(samp_level, x_0_lon, x_0_lat,
                                                         self.config.sampling.longitudinal_mode, self._low_vel_mode)
@@ -307,6 +317,12 @@ class GpuBackendMixin:
                 self._infeasible_count_kinematics = 0
                 return None
             out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D))
+        elif bundle.coeffs is not None:
+            lon, lat, lon_T, tl = bundle.coeffs[:4]
+            if len(lon_T) == 0:
+                self._infeasible_count_kinematics = 0
+                return None
+            out = ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl)
         else:
             samples = bundle.trajectories
             if not samples:
@@ -328,7 +344,7 @@ class GpuBackendMixin:
         for i, name in enumerate(_capi.REASON_NAMES[1:6], start=1):
             if name in self._infeasible_reason_dict:
                 self._infeasible_reason_dict[name] = int(out.reason_counts[i])
-        status, costs = ctx.fetch_status() if (self._draw_traj_set or bundle.grids is None) else (None, None)
+        status, costs = ctx.fetch_status() if (self._draw_traj_set or (bundle.grids is None and bundle.coeffs is None)) else (None, None)
         bundle.costs = costs
         # plan()'s standstill branch reads bundle.min_costs() / max_costs() (reactive_planner.py:650-651): two numbers, worked out
         # on the device when somebody asks (the reference's bundle then holds the kinematically feasible samples, :1128)
@@ -350,6 +366,15 @@ class GpuBackendMixin:
     # ---- helpers ----------------------------------------------------------------------------------
     def _gpu_candidate_sample(self, bundle: GpuTrajectoryBundle, index: int, lon_coeffs=None, lat_coeffs=None,
                               lat_T=None) -> TrajectorySample:
+        if bundle.coeffs is not None:   # polynomials straight from the coefficient arrays of the batch view
+            lon_c, lat_c, lon_T, _, lon_end, lat_end = bundle.coeffs
+            x0_lon, x0_lat = np.asarray(bundle.x_0_lon, dtype=float), np.asarray(bundle.x_0_lat, dtype=float)
+            if self.config.sampling.longitudinal_mode == "stopping":
+                lon = QuinticTrajectory(tau_0=0, delta_tau=lon_T[index], x_0=x0_lon, x_d=np.array([lon_end[index], 0.0, 0.0]), coeffs=lon_c[index])
+            else:
+                lon = QuarticTrajectory(tau_0=0, delta_tau=lon_T[index], x_0=x0_lon, x_d=np.array([lon_end[index], 0.0]), coeffs=lon_c[index])
+            lat = QuinticTrajectory(tau_0=0, delta_tau=lon_T[index], x_0=x0_lat, x_d=np.array([lat_end[index], 0.0, 0.0]), coeffs=lat_c[index])
+            return TrajectorySample(self.horizon, self.dt, lon, lat)
         if bundle.grids is None:
             return bundle.trajectories[index]
         T, _, L, D = bundle.grids
@@ -371,7 +396,9 @@ class GpuBackendMixin:
         return TrajectorySample(self.horizon, self.dt, lon, lat)
 
     def _gpu_winner_sample(self, bundle, out: PlanOutput) -> TrajectorySample:
-        if bundle.grids is None:
+        if bundle.coeffs is not None:
+            s = self._gpu_candidate_sample(bundle, out.best_index)
+        elif bundle.grids is None:
             s = bundle.trajectories[out.best_index]      # foreign sampling space: its own object
         else:
             def polys(b=bundle, o=out):

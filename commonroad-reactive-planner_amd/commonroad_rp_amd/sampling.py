@@ -181,14 +181,120 @@ class FixedIntervalSampling(SamplingSpace):
 
 
 class CorridorSampling(SamplingSpace):
-    """Adaptive corridor sampling needs the optional CommonRoad-Reach package (sampling.py:273-397);
-    out of scope here (SURVEY.md section 2 #2) -- same failure mode as the reference without it."""
+    """Adaptive sampling inside a collision-free driving corridor (reference: commonroad_rp/sampling.py:273-397).
 
-    def __init__(self, config):
-        raise ImportError("<CorridorSampling>: Please install CommonRoad-Reach to use adaptive corridor sampling!")
+    Per time sample T the longitudinal end velocities are spread over the velocity interval the corridor allows at that time
+    step, and for every (T, v) the lateral end positions over the lateral extent of each connected part of the corridor that
+    the longitudinal end position falls into -- so the grid is DATA DEPENDENT: a different number of lateral samples per
+    (T, v), none at all where the corridor is not reached.  Such a space has no (T, L, D) product form; the GPU path takes
+    explicit polynomials (``rp_plan_coeffs``).  Two views of the same candidate list:
 
-    def generate_trajectories_at_level(self, *a, **k):
-        raise NotImplementedError
+    * ``generate_trajectories_at_level``: the reference's interface, one ``TrajectorySample`` per candidate;
+    * ``coeffs_at_level``: the batch view -- coefficient arrays in the same order, without one Python object per candidate.
+
+    The corridor comes as ``{time step: [reach nodes]}`` with the operations of ``commonroad_rp_amd.corridor`` (the
+    reference uses CommonRoad-Reach objects for both; see that module)."""
+
+    def __init__(self, config, reach_operation=None):
+        super().__init__(config.sampling.num_sampling_levels)
+        from . import corridor as _corridor
+        self._ops = reach_operation or _corridor
+        self.dt = config.planning.dt
+        self.horizon = config.planning.dt * config.planning.time_steps_computation
+        self.samples_t = TimeSampling(config.sampling.t_min, self.horizon, config.sampling.num_sampling_levels, self.dt)   # :289
+        self._corridor = None
+        self._velocity_constraints: Dict[int, list] = dict()
+        self._dict_level_to_num_samples: Dict[int, int] = dict()
+        self.set_dict_number_of_samples()
+
+    @property
+    def driving_corridor(self):
+        return self._corridor
+
+    @driving_corridor.setter
+    def driving_corridor(self, corridor):
+        self._corridor = corridor
+        self._velocity_constraints = {k: list(self._ops.lon_velocity_interval_connected_set(nodes)) for k, nodes in corridor.items()}   # :311-315
+
+    # (the planner assigns samples_d / samples_v in set_*_sampling_parameters; this space only keeps the bounds, :317-325)
+    samples_d = property(lambda self: None, lambda self, ps: self.__dict__.update(_d_min=getattr(ps, "low", None), _d_max=getattr(ps, "up", None)))
+    samples_v = property(lambda self: None, lambda self, vs: self.__dict__.update(_v_min=getattr(vs, "low", None), _v_max=getattr(vs, "up", None)))
+
+    def set_dict_number_of_samples(self, n_min: int = 3, dict_level_to_num_samples: dict = None):
+        """3, 5, 9, ... samples per level, or an explicit table (:327-343)."""
+        if dict_level_to_num_samples is not None:
+            for level in range(self.num_sampling_levels):
+                assert level in dict_level_to_num_samples, f"<SamplingSpace.set_dict_number_of_samples()>: input dictionary does not contain sampling level: {level}"
+            self._dict_level_to_num_samples = dict(dict_level_to_num_samples)
+            return
+        n = n_min
+        for i in range(self.num_sampling_levels):
+            self._dict_level_to_num_samples[i] = n
+            n = (n * 2) - 1
+
+    def _end_states(self, level_sampling: int, x_0_lon):
+        """(T, lon polynomial, [lateral end positions]) per longitudinal sample, in the reference's iteration order
+        (:357-389: sets of floats for T, v and d; connected parts in the order the reach operations return them)."""
+        if self._corridor is None:
+            raise AttributeError("<CorridorSampling>: Please set a driving corridor.")
+        n = self._dict_level_to_num_samples[level_sampling]
+        first_step = min(self._corridor.keys())
+        x_0_lon = np.array(x_0_lon, dtype=float)
+        for t in self.samples_t.samples_at_level(level_sampling):
+            step = round(t / self.dt) + first_step                                            # :359
+            low, up = self._velocity_constraints[step]                                        # :363-364
+            for v in set(np.linspace(low, up, n)):                                            # :367
+                lon = QuarticTrajectory(tau_0=0, delta_tau=t, x_0=x_0_lon, x_d=np.array([v, 0]))
+                end_pos = lon.calc_position(t, t ** 2, t ** 3, t ** 4, t ** 5)               # :369
+                nodes = list(self._ops.determine_overlapping_nodes_with_lon_pos(self._corridor[step], end_pos))   # :374-375
+                if not nodes:
+                    continue
+                lateral: List[float] = []
+                for part in self._ops.determine_connected_components(nodes):                  # :378
+                    lo, hi = self._ops.lat_interval_connected_set(part)                       # :382
+                    ds = set(np.linspace(lo, hi, n))
+                    if lo < 0 < hi:
+                        ds = ds.union({0})                                                    # :384-386
+                    lateral.extend(ds)
+                yield t, v, lon, lateral
+
+    def generate_trajectories_at_level(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str,
+                                       low_vel_mode: bool) -> List[TrajectorySample]:
+        out = []
+        x_0_lat = np.array(x_0_lat, dtype=float)
+        for t, _, lon, lateral in self._end_states(level_sampling, x_0_lon):
+            for d in lateral:   # (lateral motion over time whatever the velocity, :390-393)
+                out.append(TrajectorySample(self.horizon, self.dt, lon,
+                                            QuinticTrajectory(tau_0=0, delta_tau=t, x_0=x_0_lat, x_d=np.array([d, 0.0, 0.0]))))
+        return out
+
+    def coeffs_at_level(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str, low_vel_mode: bool):
+        """Batch view: ``(lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])`` of the
+        candidates ``generate_trajectories_at_level`` would return, in the same order.  The lateral quintics of all candidates
+        are solved at once (closed form of polynomial_trajectory.py:292-320)."""
+        rows_T, rows_v, rows_lon, rows_d = [], [], [], []
+        for t, v, lon, lateral in self._end_states(level_sampling, x_0_lon):
+            k = len(lateral)
+            rows_T.append(np.full(k, t)); rows_v.append(np.full(k, v)); rows_lon.append(np.tile(lon.coeffs, (k, 1)))
+            rows_d.append(np.asarray(lateral, dtype=float))
+        if not rows_T:
+            z = np.zeros(0)
+            return np.zeros((0, 6)), np.zeros((0, 6)), z, np.zeros(0, dtype=np.int32), z, z
+        T, v_end, lon_c, d_end = np.concatenate(rows_T), np.concatenate(rows_v), np.concatenate(rows_lon), np.concatenate(rows_d)
+        p0, v0, a0 = (float(c) for c in x_0_lat)
+        T2 = T * T
+        bp = d_end - (p0 + v0 * T + 0.5 * a0 * T2)
+        bv = -(v0 + a0 * T)
+        ba = -a0
+        T3 = T2 * T
+        lat_c = np.empty((len(T), 6))
+        lat_c[:, 0], lat_c[:, 1], lat_c[:, 2] = p0, v0, 0.5 * a0
+        lat_c[:, 3] = (20.0 * bp - 8.0 * T * bv + T2 * ba) / (2.0 * T3)
+        lat_c[:, 4] = (-30.0 * bp + 14.0 * T * bv - 2.0 * T2 * ba) / (2.0 * T3 * T)
+        lat_c[:, 5] = (12.0 * bp - 6.0 * T * bv + T2 * ba) / (2.0 * T3 * T2)
+        uniq = {float(t): len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in set(T.tolist())}   # reactive_planner.py:733,748
+        traj_len = np.array([uniq[float(t)] for t in T], dtype=np.int32)
+        return lon_c, lat_c, T, traj_len, v_end, d_end
 
 
 def sampling_space_factory(config):

@@ -466,6 +466,19 @@ def install():
          compute_curvature_from_polyline=_fe.compute_curvature_from_polyline,
          compute_orientation_from_polyline=_fe.compute_orientation_from_polyline,
          resample_polyline=_fe.resample_polyline, chaikins_corner_cutting=None)
+    # CommonRoad-Reach (optional package behind CorridorSampling, commonroad_rp/sampling.py:17-25): this build's duck-typed
+    # corridor (commonroad_rp_amd/corridor.py) under the names the reference imports
+    from commonroad_rp_amd import corridor as _corridor
+    _mod("commonroad_reach")
+    _mod("commonroad_reach.data_structure")
+    _mod("commonroad_reach.data_structure.reach")
+    _mod("commonroad_reach.data_structure.reach.driving_corridor", DrivingCorridor=dict)
+    _mod("commonroad_reach.utility")
+    _mod("commonroad_reach.utility.reach_operation",
+         lon_velocity_interval_connected_set=_corridor.lon_velocity_interval_connected_set,
+         determine_overlapping_nodes_with_lon_pos=_corridor.determine_overlapping_nodes_with_lon_pos,
+         determine_connected_components=_corridor.determine_connected_components,
+         lat_interval_connected_set=_corridor.lat_interval_connected_set)
     # route planner / vehicle models
     _mod("commonroad_route_planner")
     _mod("commonroad_route_planner.route", Route=_Anything)

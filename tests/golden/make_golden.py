@@ -596,11 +596,75 @@ def case_inputs(rp, case):
                 dyn_t0=tb.dyn_t0)
 
 
+# ----------------------------------------------------------------------------------------------
+# CorridorSampling (sampling.py:273-397): the reference's own class on a duck-typed corridor (commonroad_rp_amd/corridor.py
+# under the module names of CommonRoad-Reach).  The candidate list has no (T, L, D) product form: the fixture stores the
+# polynomials of every candidate in list order and what _get_optimal_trajectory makes of them.
+# ----------------------------------------------------------------------------------------------
+def arc_corridor(time_step0=3, n_steps=21):
+    from commonroad_rp_amd.corridor import ReachBox
+    cor = {}
+    for k in range(time_step0, time_step0 + n_steps):
+        q = k - time_step0
+        s0 = 12.0 + 0.9 * q
+        cor[k] = [ReachBox(s0 - 3.0 - 0.2 * q, s0 + 2.0 + 0.25 * q, -2.5, -0.4, 6.0, 11.0),
+                  ReachBox(s0 - 1.0, s0 + 4.0 + 0.3 * q, -0.6, 1.0 + 0.05 * q, 7.0, 12.0),
+                  ReachBox(s0 + 1.0, s0 + 5.0 + 0.3 * q, 2.0, 3.0, 9.0, 12.5)]
+    return cor
+
+
+def corridor_cases():
+    arc = path_arc()
+    base = dict(dt=0.1, N=20, t_min=0.4, ref_path=arc, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1], x0_orientation=0.14,
+                x0_velocity=9.0, desired_speed=10.0, time_step0=3)
+    return [dict(base, name="corridor_arc_l1", level=1, corridor=arc_corridor()),
+            dict(base, name="corridor_arc_l2_obs", level=2, corridor=arc_corridor(), obstacles=obstacles_arc()),
+            dict(base, name="corridor_arc_l1_draw", level=1, corridor=arc_corridor(), obstacles=obstacles_arc(), draw=True)]
+
+
+def run_corridor_case(case):
+    from commonroad_rp.sampling import CorridorSampling
+    rp = make_planner(case)
+    sp = CorridorSampling(rp.config)
+    sp.driving_corridor = dict(case["corridor"])
+    rp.sampling_space = sp
+    bundle = rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], samp_level=case["level"])
+    trajs = list(bundle.trajectories)
+    opt = rp._get_optimal_trajectory(bundle)
+    label = np.array([LABEL[t.feasibility_label] for t in trajs], dtype=np.int32)
+    cost = np.array([t.cost if t.feasibility_label in (FeasibilityStatus.FEASIBLE, FeasibilityStatus.INFEASIBLE_COLLISION) else np.nan
+                     for t in trajs])
+    boxes = np.array([[k, b.p_lon_min, b.p_lon_max, b.p_lat_min, b.p_lat_max, b.v_lon_min, b.v_lon_max]
+                      for k, nodes in sorted(case["corridor"].items()) for b in nodes])
+    out = dict(case_inputs(rp, case), level=case["level"], draw=int(rp._draw_traj_set), corridor=boxes,
+               lon_coeffs=np.array([t.trajectory_long.coeffs for t in trajs]), lat_coeffs=np.array([t.trajectory_lat.coeffs for t in trajs]),
+               lon_T=np.array([t.trajectory_long.delta_tau for t in trajs]), lon_end=np.array([t.trajectory_long.x_d[0] for t in trajs]),
+               lat_end=np.array([t.trajectory_lat.x_d[0] for t in trajs]), label=label, cost=cost,
+               winner=trajs.index(opt) if opt is not None else -1, winner_cost=(opt.cost if opt is not None else np.nan),
+               n_infeasible_kinematics=rp._infeasible_count_kinematics, n_infeasible_collision=rp._infeasible_count_collision,
+               reason_counts=np.array([rp._infeasible_reason_dict.get(k, 0) for k in REASONS], dtype=np.int64),
+               ref_pos=rp._co.ref_pos, ref_theta=rp._co.ref_theta, ref_curv=rp._co.ref_curv, ref_curv_d=rp._co.ref_curv_d,
+               vehicle=np.array([VEH[k] for k in ("wheelbase", "wb_rear_axle", "length", "width", "a_max", "v_switch", "delta_max", "v_delta_max")]),
+               w_a=float(rp.cost_function.w_a), desired_d=float(rp.cost_function.desired_d))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", action="store_true")
     ap.add_argument("--only", default=None)
     args = ap.parse_args()
+    for case in corridor_cases():
+        if args.list:
+            print(case["name"])
+            continue
+        if args.only and case["name"] != args.only:
+            continue
+        out = run_corridor_case(case)
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out)
+        lab = out["label"]
+        print(f"{case['name']:34s} C={len(lab):5d} feasible={int((lab == 1).sum()):5d} kin={int((lab == 2).sum()):4d} coll={int((lab == 3).sum()):4d} "
+              f"none={int((lab == 0).sum()):4d} winner={out['winner']} ncol={out['n_infeasible_collision']}")
     for case in plan_cases():
         if args.list:
             print(case["name"])

@@ -1,0 +1,167 @@
+"""Data-dependent sampling space on the explicit-polynomial entry (rp_plan_coeffs): ``CorridorSampling``
+(reference: commonroad_rp/sampling.py:273-397) -- a different number of lateral samples per (T, v), none where the
+corridor is not reached -- against fixtures produced by the reference's OWN CorridorSampling and _get_optimal_trajectory
+running on this build's duck-typed corridor (tests/golden/make_golden.py::run_corridor_case; CommonRoad-Reach itself is
+not available).  CPU: candidate list, oracle labels / costs / winner.  GPU: every launch path against oracle and fixture."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from _golden import GOLDEN_DIR, build_planner_from_plan_golden
+from commonroad_rp_amd._capi import FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, make_cost, make_params
+from commonroad_rp_amd.collision import ObstacleTables
+from commonroad_rp_amd.config import ReactivePlannerConfiguration
+from commonroad_rp_amd.corridor import ReachBox
+from commonroad_rp_amd.sampling import CorridorSampling
+
+CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "corridor_*.npz")))
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def _space(z):
+    cfg = ReactivePlannerConfiguration.from_dict(dict(planning=dict(dt=float(z["dt"]), time_steps_computation=int(z["N"])),
+                                                      sampling=dict(t_min=float(z["t_min"]), sampling_method=2)))
+    sp = CorridorSampling(cfg)
+    cor = {}
+    for row in z["corridor"]:
+        cor.setdefault(int(row[0]), []).append(ReachBox(*row[1:]))
+    sp.driving_corridor = cor
+    return sp
+
+
+def _params(z, flags=0):
+    veh = z["vehicle"]
+    p = make_params(dt=float(z["dt"]), N=int(z["N"]), factor=int(z["factor"]), time_step0=int(z["time_step0"]), low_vel_mode=False,
+                    lon_mode=0, constraint_mask=31, flags=flags | (FLAG_DRAW_ALL if int(z["draw"]) else 0), x0_lon=z["x0_lon"],
+                    x0_lat=z["x0_lat"], x0_orientation=float(z["x0_orientation"]), wheelbase=veh[0], wb_rear_axle=veh[1], length=veh[2],
+                    width=veh[3], a_max=veh[4], v_switch=veh[5], delta_max=veh[6], v_delta_max=veh[7])
+    cost = make_cost(w_a=float(z["w_a"]), desired_speed=float(z["desired_speed"]), desired_d=float(z["desired_d"]))
+    return p, cost
+
+
+def _tables(z):
+    return ObstacleTables(static_obb=z["static_obb"], static_tri=z["static_tri"], static_circ=z["static_circ"], dyn_obb=z["dyn_obb"],
+                          dyn_t0=int(z["dyn_t0"]))
+
+
+def test_fixture_inventory():
+    assert len(CASES) >= 3
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_candidate_list_follows_the_reference(name):
+    """same candidates, same order (sets of floats for T, v, d; parts of the corridor in the order of the reach operations),
+    in the object view and in the batch view"""
+    z = _load(name)
+    sp = _space(z)
+    lvl = int(z["level"])
+    trajs = sp.generate_trajectories_at_level(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    lon, lat, T, tl, v_end, d_end = sp.coeffs_at_level(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    assert len(trajs) == len(T) == len(z["lon_T"])
+    np.testing.assert_array_equal(T, z["lon_T"])
+    np.testing.assert_array_equal(v_end, z["lon_end"])
+    np.testing.assert_array_equal(d_end, z["lat_end"])
+    np.testing.assert_array_equal(np.array([t.trajectory_long.delta_tau for t in trajs]), z["lon_T"])
+    np.testing.assert_allclose(np.array([t.trajectory_long.coeffs for t in trajs]), z["lon_coeffs"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(np.array([t.trajectory_lat.coeffs for t in trajs]), z["lat_coeffs"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lon, z["lon_coeffs"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(lat, z["lat_coeffs"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_array_equal(tl, np.round(T / float(z["dt"])).astype(int) + 1)
+    # irregular: the number of lateral samples differs between longitudinal samples
+    counts = {}
+    for t, v in zip(T.tolist(), v_end.tolist()):
+        counts[(t, v)] = counts.get((t, v), 0) + 1
+    assert len(set(counts.values())) >= 2
+
+
+def _check_against_fixture(status, cost, out, z):
+    mine, ref = status & 3, z["label"]
+    # the reference checks collisions lazily, in cost order, up to the winner: a colliding sample that sorts after the winner
+    # keeps the label FEASIBLE there and carries INFEASIBLE_COLLISION here (eager check); everything else is label for label
+    # (draw mode stores out-of-domain samples as kinematically infeasible here, without a label there)
+    np.testing.assert_array_equal(mine == 2, (ref == 2) | ((ref == 0) & (mine == 2) & bool(int(z["draw"]))))
+    np.testing.assert_array_equal((mine == 1) | (mine == 3), (ref == 1) | (ref == 3))
+    assert np.all(mine[ref == 3] == 3)
+    has = ~np.isnan(z["cost"])
+    np.testing.assert_allclose(cost[has], z["cost"][has], rtol=1e-9)
+    assert out.best_index == int(z["winner"])
+    assert out.n_collision_before_best == int(z["n_infeasible_collision"])
+    assert out.n_candidates - out.n_feasible == int(z["n_infeasible_kinematics"])
+    np.testing.assert_array_equal(out.reason_counts[1:6], z["reason_counts"])
+    if out.best_index >= 0:
+        np.testing.assert_allclose(out.best_cost, float(z["winner_cost"]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_on_the_reference_candidates(name):
+    from oracle import oracle
+    z = _load(name)
+    p, cost = _params(z)
+    tb = oracle.OracleTables(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]), _tables(z))
+    tl = np.round(z["lon_T"] / float(z["dt"])).astype(np.int32) + 1
+    run = oracle.plan_coeffs(p, cost, tb, z["lon_coeffs"], z["lat_coeffs"], tl)
+    _check_against_fixture(run.status, run.cost, run.out, z)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_planner_with_corridor_sampling_cpu_glue(name):
+    """the planner's per-level hot path with this sampling space (batch view -> rp_plan_coeffs), oracle-backed context"""
+    from _oracle_ctx import OracleContext
+    z = _load(name)
+    z.setdefault("low_vel_mode_threshold", np.float64(4.0))
+    np.savez(os.path.join(GOLDEN_DIR, "_tmp_corridor_plan.npz"), **dict(z, continuous=0, lon_mode=0, v_range=np.array([np.nan, np.nan])))
+    try:
+        rp, _ = build_planner_from_plan_golden("_tmp_corridor_plan", OracleContext)
+    finally:
+        os.remove(os.path.join(GOLDEN_DIR, "_tmp_corridor_plan.npz"))
+    rp._draw_traj_set = bool(int(z["draw"]))
+    rp.set_sampling_space(_space(z))
+    bundle = rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], samp_level=int(z["level"]))
+    assert bundle.coeffs is not None and bundle.n_candidates == len(z["lon_T"])
+    opt = rp._get_optimal_trajectory(bundle)
+    assert (opt is not None) == (int(z["winner"]) >= 0)
+    assert rp.infeasible_count_collision == int(z["n_infeasible_collision"])
+    assert rp.infeasible_count_kinematics == int(z["n_infeasible_kinematics"])
+    if opt is not None:
+        w = int(z["winner"])
+        np.testing.assert_allclose(opt.cost, float(z["winner_cost"]), rtol=1e-9)
+        np.testing.assert_allclose(opt.trajectory_lat.coeffs, z["lat_coeffs"][w], rtol=1e-9, atol=1e-10)
+        assert opt.trajectory_long.delta_tau == z["lon_T"][w] and opt.trajectory_lat.x_d[0] == z["lat_end"][w]
+    if rp._draw_traj_set:
+        assert len(rp.stored_trajectories) == len(z["lon_T"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_corridor_candidates_on_every_launch_path(name):
+    from _paths import LAUNCH_PATHS, launch_path_env
+    from commonroad_rp_amd._capi import RpContext
+    from oracle import oracle
+    z = _load(name)
+    sp = _space(z)
+    lon, lat, T, tl, _, _ = sp.coeffs_at_level(int(z["level"]), z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    tabs = _tables(z)
+    tb = oracle.OracleTables(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]), tabs)
+    for path in LAUNCH_PATHS:
+        with launch_path_env(path):
+            ctx = RpContext(0)
+            ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
+            ctx.set_obstacles(tabs)
+            for extra in (0, FLAG_MATERIALIZE_ALL):
+                p, cost = _params(z, extra)
+                orun = oracle.plan_coeffs(p, cost, tb, lon, lat, tl)
+                out = ctx.plan_coeffs(p, cost, lon, lat, T, tl)
+                status, c = ctx.fetch_status()
+                np.testing.assert_array_equal(status & 0x7F, orun.status & 0x7F)
+                _check_against_fixture(status, c, out, z)
+                if out.best_index >= 0:
+                    np.testing.assert_allclose(out.best_states, orun.out.best_states, rtol=0, atol=1e-6)
+                if extra:
+                    have = ((orun.status & 3) == 1) | ((orun.status & 3) == 3) | bool(int(z["draw"]))
+                    np.testing.assert_allclose(ctx.fetch_states()[have], orun.states[have], rtol=0, atol=1e-6)
+            ctx.close()
