@@ -270,13 +270,50 @@ class CorridorSampling(SamplingSpace):
 
     def coeffs_at_level(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str, low_vel_mode: bool):
         """Batch view: ``(lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])`` of the
-        candidates ``generate_trajectories_at_level`` would return, in the same order.  The lateral quintics of all candidates
-        are solved at once (closed form of polynomial_trajectory.py:292-320)."""
+        candidates ``generate_trajectories_at_level`` would return, in the same order, without one Python object per
+        candidate or per longitudinal sample: per time sample the quartics of all velocity samples are solved in one
+        ``np.linalg.solve`` call (the same LAPACK routine per system as polynomial_trajectory.py:341-360, so the end positions
+        that decide which part of the corridor a sample falls into come out bit for bit), the lateral samples of a set of
+        corridor nodes are worked out once per set, and the lateral quintics of all candidates are solved at once (closed
+        form of polynomial_trajectory.py:292-320)."""
+        if self._corridor is None:
+            raise AttributeError("<CorridorSampling>: Please set a driving corridor.")
+        n = self._dict_level_to_num_samples[level_sampling]
+        first_step = min(self._corridor.keys())
+        s0, sv0, sa0 = (float(c) for c in x_0_lon)
         rows_T, rows_v, rows_lon, rows_d = [], [], [], []
-        for t, v, lon, lateral in self._end_states(level_sampling, x_0_lon):
-            k = len(lateral)
-            rows_T.append(np.full(k, t)); rows_v.append(np.full(k, v)); rows_lon.append(np.tile(lon.coeffs, (k, 1)))
-            rows_d.append(np.asarray(lateral, dtype=float))
+        lateral_of: Dict[tuple, np.ndarray] = {}
+        for t in self.samples_t.samples_at_level(level_sampling):
+            step = round(t / self.dt) + first_step
+            low, up = self._velocity_constraints[step]
+            vs = set(np.linspace(low, up, n))
+            v = np.fromiter(vs, dtype=np.float64, count=len(vs))
+            # QuarticTrajectory._calc_coeffs_static_: [[3 T^2, 4 T^3], [6 T, 12 T^2]] x = [v_d - v_0 - a_0 T, -a_0]
+            t2, t3 = t ** 2, t ** 3
+            A = np.array([[3 * t2, 4 * t3], [6 * t, 12 * t2]])
+            rhs = np.stack((v - sv0 - sa0 * t, np.full(len(v), -sa0)), axis=1)[:, :, None]
+            x = np.linalg.solve(np.broadcast_to(A, (len(v), 2, 2)), rhs)[:, :, 0]
+            lon = np.zeros((len(v), 6))
+            lon[:, 0], lon[:, 1], lon[:, 2], lon[:, 3], lon[:, 4] = s0, sv0, sa0 / 2.0, x[:, 0], x[:, 1]
+            end = lon[:, 0] + lon[:, 1] * t + lon[:, 2] * t ** 2 + lon[:, 3] * t ** 3 + lon[:, 4] * t ** 4 + lon[:, 5] * t ** 5   # :369
+            nodes = self._corridor[step]
+            for k in range(len(v)):
+                ids = tuple(i for i, nd in enumerate(nodes) if nd in self._ops.determine_overlapping_nodes_with_lon_pos([nd], end[k]))
+                if not ids:
+                    continue
+                lat = lateral_of.get((step, ids))
+                if lat is None:
+                    ds: List[float] = []
+                    for part in self._ops.determine_connected_components([nodes[i] for i in ids]):
+                        lo, hi = self._ops.lat_interval_connected_set(part)
+                        one = set(np.linspace(lo, hi, n))
+                        if lo < 0 < hi:
+                            one = one.union({0})
+                        ds.extend(one)
+                    lat = lateral_of[(step, ids)] = np.asarray(ds, dtype=np.float64)
+                m = len(lat)
+                rows_T.append(np.full(m, t)); rows_v.append(np.full(m, v[k])); rows_lon.append(np.broadcast_to(lon[k], (m, 6)))
+                rows_d.append(lat)
         if not rows_T:
             z = np.zeros(0)
             return np.zeros((0, 6)), np.zeros((0, 6)), z, np.zeros(0, dtype=np.int32), z, z
