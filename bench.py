@@ -567,6 +567,20 @@ def cpu_baseline(w, inp, budget_s: float):
             oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads)
             n += 1
         out["all_cores"] = {"value": big * n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": threads}
+    # the reference's own execution model -- one Python iteration per candidate, NumPy per trajectory, a
+    # scalar Python loop over the steps, sort + lazy collision walk (oracle/numpy_loop.py) -- on one core, a few seconds
+    from oracle import numpy_loop
+    n_py = min(C, 1500)
+    numpy_loop.plan(inp, tb, 0, min(C, 50))
+    t0 = time.perf_counter()
+    reps_py = 0
+    while reps_py == 0 or time.perf_counter() - t0 < min(5.0, budget_s / 3):
+        numpy_loop.plan(inp, tb, 0, n_py)
+        reps_py += 1
+    el_py = time.perf_counter() - t0
+    out["numpy_loop"] = {"value": n_py * reps_py / el_py, "unit": "candidates/s", "cores": 1, "kind": "port",
+                         "sample": f"first {n_py} candidates, {reps_py} repetitions, {el_py:.1f} s: loop-faithful NumPy "
+                                   f"restatement of the reference's per-candidate Python loop (lazy collision walk)"}
     return out
 
 
