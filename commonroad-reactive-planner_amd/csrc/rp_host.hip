@@ -66,6 +66,8 @@ struct rp_ctx {
     double *d_cost = nullptr, *d_user = nullptr;
     size_t cap_status = 0, cap_cost = 0, cap_user = 0;
     double *d_states = nullptr;
+    double *d_compact = nullptr;   // rp_fetch_states: compact copy of padded state rows
+    size_t cap_compact = 0;
     size_t cap_states = 0;
     double *d_profile = nullptr, *d_profile_one = nullptr;   // longitudinal profiles (batch / rp_eval_one scratch)
     size_t cap_profile = 0, cap_profile_one = 0;
@@ -253,10 +255,23 @@ void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin,
     else     { if (cin) launch_eval_fused_t<false, true>(c, ka, grid, lds, kFusedLonG); else launch_eval_fused_t<false, false>(c, ka, grid, lds, kFusedLonG); }
 }
 
+// State rows leave through LDS as one linear stream (STAGE_OUT) for whole-wavefront candidates of the two-kernel path.
+inline bool stage_out_applies(const KArgs &ka, int G, bool mat) {
+    const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
+    return mat && !ka.single_index && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
+}
+
+// Doubles between two rows of a state block in device memory.  Rows stored directly (every variant but STAGE_OUT) start on
+// 64-byte lines: N + 1 rounded up to a multiple of 8 (rp_fetch_states hands out compact [14][N + 1] blocks either way).
+inline int state_row_stride(int n, bool staged) {
+    if (staged || std::getenv("RP_AMD_NO_ROW_PADDING")) return n;
+    return (n + 7) & ~7;
+}
+
 template <int G, bool MAT, bool CIN, int COLL>
 void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
-    const bool stage = MAT && !ka.single_index && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
+    const bool stage = stage_out_applies(ka, G, MAT);
     if (MAT && stage) launch_eval_tcs<G, MAT, CIN, COLL, true>(c, ka, grid, tile);
     else launch_eval_tcs<G, MAT, CIN, COLL, false>(c, ka, grid, 0);
 }
@@ -492,7 +507,10 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
     }
     ka.lds_pairs = fused_pairs;
-    if (!skip_eval) { c->last_fused_lds = fused_lds; c->last_G = G; }
+    if (!skip_eval) {
+        c->last_fused_lds = fused_lds; c->last_G = G;
+        ka.row_stride = state_row_stride(n, !fused_lds && stage_out_applies(ka, G, mat));   // (rp_select keeps the plan's)
+    }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
     if (grid > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
@@ -564,6 +582,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         fa.count = ka.count; fa.cand_begin = ka.cand_begin; fa.seq = fin_seq;
         fa.debug = c->d_debug;
         fa.N = ka.N; fa.n_partials = n_partials; fa.count_inline = small ? 1 : 0; fa.copy_states = copy_states ? 1 : 0;
+        fa.row_stride = ka.row_stride; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
         launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
         if (c->timing) c->t_sum[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count();
     }
@@ -581,6 +600,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.status = &drb->pad_;   // (not w_status: its RP_WSTATUS_ROWS_ON_HOST flag tells the device-side exchange where the rows are)
         kw.cost = &drb->w_cost;
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
+        kw.row_stride = n;   // the block behind the result header is compact
         kw.coeffs = nullptr;
         kw.partials = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
@@ -709,7 +729,7 @@ void rp_destroy(rp_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
-                   c->d_states, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
+                   c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
                    c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
         if (p) (void)hipFree(p);
@@ -925,7 +945,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
 
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)count)) != RP_OK) return rc;
-    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)n)) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
 
     KArgs ka;
     fill_common(c, p, cost, ka);
@@ -976,7 +996,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)C)) != RP_OK) return rc;
-    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)n)) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
     KArgs ka;
     fill_common(c, p, cost, ka);
     const double *ds = reinterpret_cast<const double *>(c->d_stage);
@@ -1009,8 +1029,24 @@ int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
     if (first < 0 || count < 0 || first + count > c->last.count || (count && !states))
         return fail(c, RP_EINVAL, "rp_fetch_states: range");
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t blk = (size_t)RP_N_ARRAYS * (size_t)(c->last.N + 1);
-    if (count) HIP_TRY(c, hipMemcpy(states, c->d_states + blk * first, sizeof(double) * blk * count, hipMemcpyDeviceToHost));
+    const int n = c->last.N + 1, ns = c->last.row_stride;
+    const size_t blk = (size_t)RP_N_ARRAYS * (size_t)n;
+    if (!count) return RP_OK;
+    if (ns == n) {
+        HIP_TRY(c, hipMemcpy(states, c->d_states + blk * first, sizeof(double) * blk * count, hipMemcpyDeviceToHost));
+        return RP_OK;
+    }
+    // padded rows: compact on the device (a copy at memory speed), then one linear transfer
+    int rc;
+    if ((rc = grow(c, c->d_compact, c->cap_compact, blk * (size_t)count)) != RP_OK) return rc;
+    const size_t total = blk * (size_t)count;
+    const int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)c->num_cus * 16);
+    hipLaunchKernelGGL(rp_compact_rows_kernel, dim3(grid), dim3(256), 0, c->stream,
+                       c->d_states + (size_t)RP_N_ARRAYS * (size_t)ns * (size_t)first, c->d_compact, n, ns,
+                       (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u, (unsigned long long)total);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(states, c->d_compact, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RP_OK;
 }
 
@@ -1033,6 +1069,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.status = &drb->pad_;
     kw.cost = &drb->w_cost;
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
+    kw.row_stride = n;
     kw.coeffs = nullptr;
     kw.partials = nullptr;
     // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own

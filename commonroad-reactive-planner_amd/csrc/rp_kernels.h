@@ -74,7 +74,7 @@ struct KArgs {
     double pos_first, pos_last;   // ref_pos[0], ref_pos[n_ref - 1]
     ObsTables obs;         // obstacle table descriptor, by value: a pointer to a device copy costs a dependent
                            // memory round trip before the first obstacle row can be requested
-    int32_t has_obstacles, pad2_;
+    int32_t has_obstacles, row_stride;   // row_stride: doubles between the rows of `states` (>= N + 1; rp_host.hip: state_row_stride)
     // longitudinal profiles (rp_lon_kernel -> rp_eval_kernel): pairs [pair_begin, pair_begin + pair_count)
     double *profile;            // [pair_count][PF_FIELDS][N+1]
     struct PairHdr *pair_hdr;   // [pair_count]
@@ -85,7 +85,7 @@ struct KArgs {
     // outputs
     uint32_t *status;  // [count]
     double *cost;      // [count]
-    double *states;    // [count][14][N+1] (MAT) or nullptr
+    double *states;    // [count][14][row_stride] (MAT) or nullptr
     double *coeffs;    // [count][13] or nullptr (lon 6, lat 6, lat_T)
     struct BlockPartial *partials;  // [gridDim.x] or nullptr
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
@@ -301,6 +301,8 @@ struct FinArgs {
     int64_t count, cand_begin;
     unsigned long long seq;      // completion ticket for the host (0: none)
     int32_t N, n_partials, count_inline, copy_states;
+    int32_t row_stride;          // doubles between the rows of `states`
+    uint32_t inv_n;              // floor(2^32 / (N + 1)) + 1: k / (N + 1) == umulhi(k, inv_n) for k < 14 (N + 1)
     unsigned long long *debug;   // diagnostic build (-DRP_STAMPS): s_memtime stamps of the phases, slots 26..31
 };
 #ifdef RP_STAMPS
@@ -369,11 +371,16 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     constexpr int kRowsPerThread = 4;   // covers 14 (N+1) <= 1024 doubles in registers; longer blocks loop at the end
     double wrow[kRowsPerThread];
     const bool want_rows = a.copy_states && widx >= 0;
-    const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)n : nullptr;
+    const int ns = a.row_stride;
+    const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)ns : nullptr;
+    auto padded = [&](int k) -> int {   // element k of the compact [14][N + 1] block inside the [14][row_stride] one
+        const int row = (int)__umulhi((uint32_t)k, a.inv_n);
+        return k + row * (ns - n);
+    };
 #pragma unroll
     for (int q = 0; q < kRowsPerThread; ++q) {
         const int k = tid + q * RP_FIN_THREADS;
-        wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[k] : 0.0;
+        wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[padded(k)] : 0.0;
     }
     // counters: wavefront sums through 32-bit DPP adds, one LDS add per wavefront and counter
 #pragma unroll
@@ -449,7 +456,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
             if (k < RP_N_ARRAYS * n) { d1[k] = wrow[q]; host_store(d2 + k, (unsigned long long)__double_as_longlong(wrow[q])); }
         }
         for (int k = tid + kRowsPerThread * RP_FIN_THREADS; k < RP_N_ARRAYS * n; k += RP_FIN_THREADS) {
-            const double v = wsrc[k];
+            const double v = wsrc[padded(k)];
             d1[k] = v;
             host_store(d2 + k, (unsigned long long)__double_as_longlong(v));
         }
@@ -1360,16 +1367,21 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             // Row addresses: a wave-uniform base (the first candidate of this wavefront) plus a 32-bit byte offset per
             // lane; each row then costs one 32-bit add with a scalar operand (row * n * 8) instead of a 64-bit
             // address per (lane, row) formed from 14 hoisted -- and spilled -- row pointers.
+            // Rows stored directly lie row_stride doubles apart (N + 1 rounded up to whole 64-byte lines): a lane group's run of
+            // G consecutive steps then starts on a line boundary and covers whole lines, which is what a write-through store
+            // needs to reach memory as one full-line write (248-byte rows cost 1.28 x the bytes: profiles/r02_pmc_traffic.json).
+            const int ns = (MAT && !STAGE_OUT) ? al.row_stride : n;
             char *const obase = !MAT ? nullptr
                                 : (STAGE_OUT ? reinterpret_cast<char *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n)
-                                             : reinterpret_cast<char *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)n));
-            const uint32_t n8 = (uint32_t)n * 8u;
+                                             : reinterpret_cast<char *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)ns));
+            const uint32_t n8 = (uint32_t)ns * 8u;
             const uint32_t lane_off8 = (uint32_t)group_in_wave * RP_N_ARRAYS * n8;   // this group's candidate inside the wavefront
             // row * n8 is formed where it is used, from a per-lane copy of n8 the compiler cannot see through (one
             // v_mad_u32_u24 per row): as a loop invariant it would be hoisted into 14 scalar registers that live across
             // the whole step loop -- the kernel runs out of those first (spilled ones cost a v_readlane per use)
             // (only where scalar registers are short: the single-launch variants; elsewhere the extra multiply costs ~4 %)
             constexpr bool ROW_MULV = LON_FUSED;
+            constexpr bool LATE_STORE = MAT && !STAGE_OUT;
             uint32_t n8v = n8;
             auto row_at = [&](uint32_t off8, int row) -> double * {
                 return reinterpret_cast<double *>(obase + (size_t)(ROW_MULV ? __umul24((uint32_t)row, n8v) + off8 : off8 + (uint32_t)row * n8));
@@ -1399,7 +1411,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 const double tau = low ? s - s0 : t;
                 double d = poly_pos(gs_poly, tau), dd = poly_vel(gs_poly, tau), ddd = poly_acc(gs_poly, tau);
                 if (fabs(dd) < RP_EPS) dd = 0.0;
-                if (store_ok && act) {   // curvilinear rows of valid steps are final here
+                // Rows stored straight to memory leave once per step block, behind the horizon extension (LATE_STORE): valid and
+                // extended steps of a row then share ONE store instruction, i.e. whole 64-byte lines -- stored separately, the
+                // 32-byte sector that holds the last valid step was written twice (+ 24 B per row on cfg2, PMC WRITE_SIZE).
+                if (!LATE_STORE && store_ok && act) {   // curvilinear rows of valid steps are final here
                     const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
                     st_row<RP_WT>(row_at(off8, RP_S), s);
                     st_row<RP_WT>(row_at(off8, RP_S_DOT), sd);
@@ -1505,7 +1520,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     if (ood_step >= 0 && i >= ood_step) { x = 0.0; y = 0.0; }   // x, y stay np.zeros past the break
                 }
                 if (act) {   // Cartesian rows of valid steps are final here
-                    if (store_ok) {
+                    if (!LATE_STORE && store_ok) {
                         const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
                         st_row<RP_WT>(row_at(off8, RP_X), x);
                         st_row<RP_WT>(row_at(off8, RP_Y), y);
@@ -1559,8 +1574,13 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         const double e_dd = o[12] + tk * 0.0;          // :319
                         const double e_s = o[7] + tk * o[10];          // :330
                         const double e_d = o[8] + tk * o[12];          // :331
-                        if (live) {
-                            if (store_ok) {
+                        if (live) cost_acc += cost_terms(i, o[4], vt, e_s, e_d, o[9]);
+                        if (LATE_STORE) {   // what the step block's store below writes for this lane
+                            v = vt; acc = o[4]; kappa = o[5]; kdot = o[6];
+                            s = e_s; d = e_d; th_cl = o[9];
+                            sd = e_sd; sdd = o[11]; dd = e_dd; ddd = o[13];
+                        } else if (store_ok && live) {
+                            {
                                 const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
                                 st_row<RP_WT>(row_at(off8, RP_X), x);
                                 st_row<RP_WT>(row_at(off8, RP_Y), y);
@@ -1577,7 +1597,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                                 st_row<RP_WT>(row_at(off8, RP_D_DOT), e_dd);
                                 st_row<RP_WT>(row_at(off8, RP_D_DDOT), o[13]);      // :324
                             }
-                            cost_acc += cost_terms(i, o[4], vt, e_s, e_d, o[9]);
                         }
                     }
                     if (!ONE_CHUNK && c + 1 < nchunks) {
@@ -1585,7 +1604,26 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         cumy = group_bcast<G>(scy, G - 1);
                     }
                 }
-                RP_STAMP(9);   // extension + scans + stores of extended steps
+                // (lanes in the padding behind step N store too: their values are never read, and the run of the lane group
+                //  then ends on a line boundary)
+                if (LATE_STORE && store_ok && i < ns) {
+                    const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                    st_row<RP_WT>(row_at(off8, RP_X), x);
+                    st_row<RP_WT>(row_at(off8, RP_Y), y);
+                    st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
+                    st_row<RP_WT>(row_at(off8, RP_V), v);
+                    st_row<RP_WT>(row_at(off8, RP_A), acc);
+                    st_row<RP_WT>(row_at(off8, RP_KAPPA), kappa);
+                    st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), kdot);
+                    st_row<RP_WT>(row_at(off8, RP_S), s);
+                    st_row<RP_WT>(row_at(off8, RP_D), d);
+                    st_row<RP_WT>(row_at(off8, RP_THETA_CL), th_cl);
+                    st_row<RP_WT>(row_at(off8, RP_S_DOT), sd);
+                    st_row<RP_WT>(row_at(off8, RP_S_DDOT), sdd);
+                    st_row<RP_WT>(row_at(off8, RP_D_DOT), dd);
+                    st_row<RP_WT>(row_at(off8, RP_D_DDOT), ddd);
+                }
+                RP_STAMP(9);   // extension + scans + stores of the step block
 
                 // -- eager collision query for every pose, reactive_planner.py:1033-1046
                 if (COLL) {
@@ -1757,6 +1795,22 @@ __global__ __launch_bounds__(RP_COMBINE_THREADS) void rp_combine_kernel(const ch
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (tid == 0) __hip_atomic_store(&host_out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rp_fetch_states of padded state rows: [rows][ns] -> compact [rows][n] in device memory (grid-stride, one element per
+// thread and turn; the transfer to the host that follows is the slow part).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rp_compact_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int ns,
+                                                             uint32_t inv_n, unsigned long long total) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        // one state block (14 n elements) at a time keeps the row index inside the exact range of the reciprocal
+        const unsigned long long blk = k / (unsigned long long)(RP_N_ARRAYS * n);
+        const uint32_t r = (uint32_t)(k - blk * (unsigned long long)(RP_N_ARRAYS * n));
+        const uint32_t row = __umulhi(r, inv_n);
+        dst[k] = src[blk * (unsigned long long)(RP_N_ARRAYS * ns) + (unsigned long long)(r + row * (uint32_t)(ns - n))];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
