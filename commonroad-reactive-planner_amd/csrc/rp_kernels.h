@@ -24,6 +24,9 @@
                                 reinterpret_cast<__attribute__((ext_vector_type(2))) double *>(p))
 #endif
 #ifndef RP_WRITE_THROUGH
+#ifndef RP_BRANCHFREE_CONSTRAINTS
+#define RP_BRANCHFREE_CONSTRAINTS 1
+#endif
 #define RP_WRITE_THROUGH 1   // single-launch variant: agent-scope write-through stores of the state rows (see st_row)
 #endif
 #ifndef RP_LATE_KERNARGS
@@ -1486,6 +1489,31 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 RP_STAMP(6);   // kappa, v, a + prev-step shifts
 
                 // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
+#if RP_BRANCHFREE_CONSTRAINTS
+                // (straight-line code: every lane evaluates the five tests and the first failing one in the reference's order is
+                //  picked by selects -- as an if / else-if chain the compiler emitted five nested exec-mask regions, each with its
+                //  own scalar loads of the limits and a wait on them)
+                uint32_t reason = RP_REASON_NONE;
+                {
+                    const double a_max = al.a_max, v_switch = al.v_switch, kappa_max = al.kappa_max;
+                    const double wk = al.wheelbase * kappa;
+                    // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
+                    const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > kappa_max * v * 1e5;
+                    // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
+                    const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
+                    // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
+                    const bool fast = v > v_switch;
+                    const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
+                    const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
+                    const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
+                    reason = ((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc ? RP_REASON_ACCELERATION : reason;
+                    reason = ((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd ? RP_REASON_KAPPA_DOT : reason;
+                    reason = ((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw ? RP_REASON_YAW_RATE : reason;
+                    reason = ((cm & RP_CHECK_KAPPA) != 0) & bad_k ? RP_REASON_KAPPA : reason;
+                    reason = ((cm & RP_CHECK_VELOCITY) != 0) & bad_v ? RP_REASON_VELOCITY : reason;
+                    reason = act ? reason : RP_REASON_NONE;
+                }
+#else
                 uint32_t reason = RP_REASON_NONE;
                 if (act) {
                     const double wk = al.wheelbase * kappa;
@@ -1501,6 +1529,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     else if ((cm & RP_CHECK_KAPPA_DOT) && bad_kd) reason = RP_REASON_KAPPA_DOT;
                     else if ((cm & RP_CHECK_ACCELERATION) && !ok_acc) reason = RP_REASON_ACCELERATION;
                 }
+#endif
                 if (__any(reason != RP_REASON_NONE)) {   // wave-uniform
                     const uint64_t fm = group_ballot<G>(reason != RP_REASON_NONE, gbase);
                     const int fl = fm ? __ffsll((unsigned long long)fm) - 1 : 0;

@@ -11,6 +11,33 @@
 
 #include <hip/hip_runtime.h>
 
+// a * b + c as a three-address v_fma_f64.  For Horner steps whose addend is a loop-invariant coefficient held in a register:
+// the compiler selects the two-address v_fmac_f64 there and puts a v_mov_b64 copy of the coefficient in front of every step
+// (a wavefront of a small batch pays ~10 cycles per instruction whatever its kind: profiles/r01_instruction_costs.txt).
+#ifndef RP_FMA3_ASM
+#define RP_FMA3_ASM 1
+#endif
+__device__ __forceinline__ double rp_fma3(double a, double b, double c) {
+#if RP_FMA3_ASM
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+// first Horner step: both coefficients are constants; the multiplier may sit in scalar registers (one scalar source per
+// VOP3 instruction), which keeps it out of the vector registers the other coefficients occupy across the step loop
+__device__ __forceinline__ double rp_fma3_first(double x, double c1, double c0) {
+#if RP_FMA3_ASM
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(c1), "v"(x), "v"(c0));
+    return r;
+#else
+    return __builtin_fma(x, c1, c0);
+#endif
+}
+
 // 1/x: v_rcp_f64 estimate + two Newton-Raphson steps
 __device__ __forceinline__ double rp_rcp(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -29,36 +56,43 @@ __device__ __forceinline__ double rp_rsqrt(double x) {
     return __builtin_fma(y * e, t, y);
 }
 
-// atan(x), all x.  fdlibm s_atan.c scheme, branch-free except for the (wave-uniform) division skip.
+// atan(x), all x.  fdlibm s_atan.c scheme.  Wavefronts whose lanes all lie in the first interval (|x| < 7/16: the slope d' of
+// a lateral offset over the arc length almost always does) skip the interval selection and the division altogether; the
+// general path gives the same bits for such lanes (hi = lo = 0: 0 - ((p - 0) - t) == t - p).
+__device__ __forceinline__ double rp_atan_poly(double t) {   // t * (odd minimax polynomial part), fdlibm aT[]
+    const double z = t * t, w = z * z;
+    double s1 = rp_fma3_first(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+    s1 = rp_fma3(w, s1, 6.66107313738753120669e-02);
+    s1 = rp_fma3(w, s1, 9.09088713343650656196e-02);
+    s1 = rp_fma3(w, s1, 1.42857142725034663711e-01);
+    s1 = rp_fma3(w, s1, 3.33333333333329318027e-01);
+    s1 = z * s1;
+    double s2 = rp_fma3_first(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+    s2 = rp_fma3(w, s2, -7.69187620504482999495e-02);
+    s2 = rp_fma3(w, s2, -1.11111104054623557880e-01);
+    s2 = rp_fma3(w, s2, -1.99999999998764832476e-01);
+    s2 = w * s2;
+    return t * (s1 + s2);
+}
+
 __device__ __forceinline__ double rp_atan(double x) {
     const double ax = fabs(x);
-    // interval selection
-    const bool r0 = ax < 0.4375, r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
-    // reduced argument t = num / den
-    double num = r0 ? ax : (r1 ? __builtin_fma(2.0, ax, -1.0) : (r2 ? ax - 1.0 : (r3 ? ax - 1.5 : -1.0)));
-    double den = r0 ? 1.0 : (r1 ? 2.0 + ax : (r2 ? ax + 1.0 : (r3 ? __builtin_fma(1.5, ax, 1.0) : ax)));
-    double t = num;
-    if (__any(!r0)) t = num * rp_rcp(den);     // most waves never divide: |d'| < 0.4375 everywhere
-    const double hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01
-                         : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
-    const double lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17
-                         : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
-    const double z = t * t, w = z * z;
-    double s1 = __builtin_fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
-    s1 = __builtin_fma(w, s1, 6.66107313738753120669e-02);
-    s1 = __builtin_fma(w, s1, 9.09088713343650656196e-02);
-    s1 = __builtin_fma(w, s1, 1.42857142725034663711e-01);
-    s1 = __builtin_fma(w, s1, 3.33333333333329318027e-01);
-    s1 = z * s1;
-    double s2 = __builtin_fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
-    s2 = __builtin_fma(w, s2, -7.69187620504482999495e-02);
-    s2 = __builtin_fma(w, s2, -1.11111104054623557880e-01);
-    s2 = __builtin_fma(w, s2, -1.99999999998764832476e-01);
-    s2 = w * s2;
-    const double p = t * (s1 + s2);
-    double res = hi - ((p - lo) - t);     // r0: 0 - ((p - 0) - t) = t - p
-    if (ax != ax) res = ax;               // NaN
-    if (ax > 7.3786976294838206464e19) res = 1.57079632679489655800e+00 + 6.12323399573676603587e-17;  // |x| >= 2^66
+    const bool r0 = ax < 0.4375;
+    double t = ax, hi = 0.0, lo = 0.0;
+    if (!__all(r0)) {   // wave-uniform
+        // interval selection, reduced argument t = num / den
+        const bool r1 = ax < 0.6875, r2 = ax < 1.1875, r3 = ax < 2.4375;
+        const double num = r0 ? ax : (r1 ? __builtin_fma(2.0, ax, -1.0) : (r2 ? ax - 1.0 : (r3 ? ax - 1.5 : -1.0)));
+        const double den = r0 ? 1.0 : (r1 ? 2.0 + ax : (r2 ? ax + 1.0 : (r3 ? __builtin_fma(1.5, ax, 1.0) : ax)));
+        t = r0 ? num : num * rp_rcp(den);
+        hi = r0 ? 0.0 : (r1 ? 4.63647609000806093515e-01 : (r2 ? 7.85398163397448278999e-01
+                : (r3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00)));
+        lo = r0 ? 0.0 : (r1 ? 2.26987774529616870924e-17 : (r2 ? 3.06161699786838301793e-17
+                : (r3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17)));
+        if (ax > 7.3786976294838206464e19) t = 0.0;   // |x| >= 2^66 (and inf, whose reciprocal iteration is NaN): pi/2
+    }
+    const double p = rp_atan_poly(t);
+    const double res = hi - ((p - lo) - t);     // first interval: 0 - ((p - 0) - t) = t - p;  NaN stays NaN
     return copysign(res, x);
 }
 
@@ -69,18 +103,18 @@ __device__ __forceinline__ void rp_sincos(double x, double *s, double *c) {
     const double y = __builtin_fma(-n, 6.07710050650619224932e-11, r);   // pio2_1t (remaining error ~ n * 7e-27)
     const double z = y * y;
     // __kernel_sin
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = rp_fma3_first(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = rp_fma3(z, ps, 2.75573137070700676789e-06);
+    ps = rp_fma3(z, ps, -1.98412698298579493134e-04);
+    ps = rp_fma3(z, ps, 8.33333333332248946124e-03);
+    ps = rp_fma3(z, ps, -1.66666666666666324348e-01);
     const double sn = __builtin_fma(y * z, ps, y);
     // __kernel_cos
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = rp_fma3_first(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = rp_fma3(z, pc, -2.75573143513906633035e-07);
+    pc = rp_fma3(z, pc, 2.48015872894767294178e-05);
+    pc = rp_fma3(z, pc, -1.38888888888741095749e-03);
+    pc = rp_fma3(z, pc, 4.16666666666666019037e-02);
     const double hz = 0.5 * z;
     const double w1 = 1.0 - hz;
     const double cs = w1 + (((1.0 - w1) - hz) + z * z * pc);
