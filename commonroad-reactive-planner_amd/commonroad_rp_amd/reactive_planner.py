@@ -156,6 +156,9 @@ class _WinnerSample(TrajectorySample):
     trajectory_lat = property(lambda self: self._get(1), lambda self, v: None)
 
 
+_LON_ROWS, _LAT_ROWS = [7, 10, 11], [8, 12, 13]   # rows of a state block (include/rp_amd.h: RP_S, RP_S_DOT, RP_S_DDOT | RP_D, ...)
+
+
 class GpuBackendMixin:
     """Routes the per-level hot path of ``plan()`` through the HIP library."""
 
@@ -687,10 +690,19 @@ class ReactivePlanner(GpuBackendMixin):
                 while o > hi:
                     o -= 2 * np.pi
                 th_c[i] = o
-        pos = np.empty((n, 2))
-        pos[:, 0], pos[:, 1] = ca.x, ca.y
-        sd = np.empty((n, 2))
-        sd[:, 0], sd[:, 1] = cu.s, cu.d
+        # the winner's arrays are rows of one [14, N + 1] block (bind_states): positions and the lon / lat lists then come from
+        # slices of it instead of column-by-column copies
+        blk = ca.x.base
+        whole = (blk is not None and blk.shape == (14, n) and ca.y.base is blk and cu.s.base is blk and cu.d.base is blk
+                 and cu.s_dot.base is blk and cu.s_ddot.base is blk and cu.d_dot.base is blk and cu.d_ddot.base is blk
+                 and getattr(trajectory, "_state_block", None) is blk)
+        if whole:
+            pos, sd = blk[0:2].T.copy(), blk[7:9].T.copy()          # rows x, y | s, d
+        else:
+            pos = np.empty((n, 2))
+            pos[:, 0], pos[:, 1] = ca.x, ca.y
+            sd = np.empty((n, 2))
+            sd[:, 0], sd[:, 1] = cu.s, cu.d
         # (states are filled through __dict__: a dataclass __init__ call costs three times as much)
         new_state, RS, CS = object.__new__, ReactivePlannerState, CustomState
 
@@ -705,8 +717,12 @@ class ReactivePlanner(GpuBackendMixin):
             sc.__dict__ = {"time_step": t0 + factor * i, "position": sd[i], "orientation": float(theta[i]), "velocity": float(v[i]),
                            "acceleration": float(acc[i]), "yaw_rate": float(kappa[i])}
             return sc
-        lon = np.empty((n, 3))
-        lon[:, 0], lon[:, 1], lon[:, 2] = cu.s, cu.s_dot, cu.s_ddot
-        lat = np.empty((n, 3))
-        lat[:, 0], lat[:, 1], lat[:, 2] = cu.d, cu.d_dot, cu.d_ddot
-        return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)), lon.tolist(), lat.tolist())
+        if whole:
+            lon, lat = blk[_LON_ROWS].T.tolist(), blk[_LAT_ROWS].T.tolist()   # rows s, s_dot, s_ddot | d, d_dot, d_ddot
+        else:
+            lo3 = np.empty((n, 3))
+            lo3[:, 0], lo3[:, 1], lo3[:, 2] = cu.s, cu.s_dot, cu.s_ddot
+            la3 = np.empty((n, 3))
+            la3[:, 0], la3[:, 1], la3[:, 2] = cu.d, cu.d_dot, cu.d_ddot
+            lon, lat = lo3.tolist(), la3.tolist()
+        return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)), lon, lat)

@@ -54,6 +54,10 @@ def bind_states(sample, block: np.ndarray, label_code: int, cost=None):
         sample.feasibility_label = None if lab is None else status_cls[lab.name]
     if cost is not None:
         sample._cost = cost
+    try:
+        sample._state_block = block if block.base is None else None   # (a row's .base is the block only if the block owns its data)
+    except AttributeError:   # foreign sample classes with __slots__
+        pass
     return sample
 
 

@@ -51,3 +51,28 @@ def test_sampling_grids_follow_reference_set_order():
         np.testing.assert_array_equal(tl, g["traj_len"])
         np.testing.assert_array_equal(L, g["L"])
         np.testing.assert_array_equal(D, g["D"])
+
+
+def test_output_packing_paths_agree():
+    """_compute_trajectory_pair takes positions and the lon / lat lists from slices of the winner's [14, N + 1] block when the
+    sample's arrays are rows of one block, and column by column otherwise (reactive_planner.py:514-568): same values."""
+    from commonroad_rp_amd import workloads
+    from _oracle_ctx import OracleContext
+    rp = workloads.make_planner(workloads.cfg2(), backend_factory=OracleContext)
+    seen = {}
+    orig = rp._compute_trajectory_pair
+
+    def spy(trajectory):
+        seen["t"] = trajectory
+        return orig(trajectory)
+    rp._compute_trajectory_pair = spy
+    fast = rp.plan()
+    t = seen["t"]
+    assert t._state_block is not None and t.cartesian.x.base is t._state_block   # the fast path was taken
+    t._state_block = None                                                        # force the column-by-column path
+    slow = orig(t)
+    assert fast[2] == slow[2] and fast[3] == slow[3]
+    for a, b in zip(fast[0].state_list, slow[0].state_list):
+        assert np.array_equal(a.position, b.position) and a.orientation == b.orientation and a.velocity == b.velocity
+    for a, b in zip(fast[1].state_list, slow[1].state_list):
+        assert np.array_equal(a.position, b.position) and a.yaw_rate == b.yaw_rate
