@@ -209,6 +209,12 @@ __device__ __forceinline__ bool obb_slab_far(const Obb &b, double ex, double ey,
     return fabs(tx * b.ux + ty * b.uy) > (b.hl + ego_r) * 1.000001 || fabs(ty * b.ux - tx * b.uy) > (b.hw + ego_r) * 1.000001;
 }
 
+// the slab along b's normal alone (the one that says something for a long thin strip)
+__device__ __forceinline__ bool obb_normal_far(const Obb &b, double ex, double ey, double ego_r) {
+    const double tx = ex - b.cx, ty = ey - b.cy;
+    return fabs(ty * b.ux - tx * b.uy) > (b.hw + ego_r) * 1.000001;
+}
+
 __device__ __forceinline__ bool obb_tri(const Obb &a, const double *t) {
     double vx = -a.uy, vy = a.ux;
     double lx[3], ly[3];
@@ -280,6 +286,7 @@ __device__ __forceinline__ Obb merge_swept(const Obb &a, const Obb &b) {
 // reads the same row (broadcast).  Dynamic OBBs: struct-of-arrays [7][n_dyn][n_steps] so that the
 // lanes of a group (consecutive time steps) read consecutive addresses.
 enum { OB_CX = 0, OB_CY, OB_UX, OB_UY, OB_HL, OB_HW, OB_R, OB_PAD, OB_ROW };  // static obb row
+#define RP_SLOT_ROW 8
 struct ObsTables {
     const double *sobb;     // [n_sobb][8]  cx, cy, ux, uy, hl, hw, r_bound, -
     const double *tri;      // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
@@ -289,6 +296,11 @@ struct ObsTables {
     // rectangles come as polylines, so consecutive shapes are neighbours): bounding circle + member range
     const double *clus;        // [n_clus][4]  cx, cy, r, -
     const int32_t *clus_info;  // [n_clus][4]  kind (0 obb, 1 triangle, 2 circle), first, count, -
+    // one row per member slot of the clusters, in cluster order (slot = cluster * clus_per + member): what the broad phase of
+    // the single-launch prologue tests, as one flat table it can stage in LDS instead of chasing cluster descriptor -> shape row
+    // through dependent loads.  Rectangles as they are; triangles and circles as the square around their bounding circle;
+    // slots without a member: half extents -inf (never near).
+    const double *slot;        // [n_clus * clus_per][RP_SLOT_ROW]  cx, cy, ux, uy, hl, hw, bit of the cluster (as a double), -
     int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0, n_clus, clus_per;   // clus_per: members per cluster (upper bound)
 };
 typedef const int32_t __attribute__((address_space(4))) *gcint;
@@ -363,12 +375,53 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 // after a wave-level bounding-circle rejection).
 // Per lane, a bounding-circle rejection comes before the exact test (conservative: a small relative margin keeps
 // it from ever rejecting a pair the exact test would accept).
-template <bool MASKED, bool STATIC>
+// LDS_SLOTS (single-launch variants): `lds_slot` is the workgroup's LDS copy of ObsTables::slot; the walk over the static
+// clusters reads member rows from there (broadcast reads, tens of cycles) instead of through chained scalar loads from device
+// memory (cluster descriptor -> member rows: a few hundred cycles per cluster with nothing to overlap them with when a SIMD
+// holds one or two wavefronts -- that chain, not the tests, was the cost of a road boundary on a small batch).
+template <bool MASKED, bool STATIC, bool LDS_SLOTS = false>
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
-                                              uint64_t near_static) {
+                                              uint64_t near_static, const double *lds_slot = nullptr) {
     bool hit = false;
     const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
-    if (MASKED && STATIC) {
+    if (MASKED && STATIC && LDS_SLOTS) {
+        uint64_t mu = wave_or_u64(want ? near_static : 0);
+        mu &= ob.n_clus >= 64 ? ~0ull : (1ull << ob.n_clus) - 1ull;
+        const int per = ob.clus_per;
+        auto exact = [&](const Obb &b, int tag, bool close) -> bool {   // tag: kind + 4 * index in the table of that kind (wave-uniform)
+            const int kind = tag & 3, j = tag >> 2;
+            if (kind == 0) return close && !obb_sep_on_b_axes(ego, b) && !obb_sep_on_a_axes(ego, b);   // strip's own axes first
+            if (kind == 1) {
+                const gcdouble o = tri + (size_t)j * 10;
+                const double dx = o[6] - ego.cx, dy = o[7] - ego.cy, rr = ego_r + o[8];
+                if (!(close && dx * dx + dy * dy <= rr * rr * 1.000001)) return false;
+                const double tv[6] = {o[0], o[1], o[2], o[3], o[4], o[5]};
+                return obb_tri(ego, tv);
+            }
+            const gcdouble o = circ + (size_t)j * 4;
+            return close && obb_circ(ego, o[0], o[1], o[2]);
+        };
+        while (mu != 0) {   // wave-uniform
+            const int c = __ffsll((unsigned long long)mu) - 1;
+            mu &= mu - 1;
+            const double *row = lds_slot + (size_t)(c * per) * RP_SLOT_ROW;
+            for (int m = 0; m < per; m += 2) {
+                const bool two = m + 1 < per;
+                const double *o0 = row + (size_t)m * RP_SLOT_ROW, *o1 = row + (size_t)(two ? m + 1 : m) * RP_SLOT_ROW;
+                const Obb b0 = {o0[0], o0[1], o0[2], o0[3], o0[4], o0[5]};
+                const Obb b1 = {o1[0], o1[1], o1[2], o1[3], o1[4], o1[5]};
+                const double g0 = o0[7], g1 = o1[7];
+                // one slab (the shape's normal; slots without a member have half extents -inf: always far) with the ego's
+                // bounding circle first; the exact test only when some lane of the wavefront comes that close
+                const bool c0 = want && !obb_normal_far(b0, ego.cx, ego.cy, ego_r);
+                const bool c1 = want && two && !obb_normal_far(b1, ego.cx, ego.cy, ego_r);
+                if (__any(c0 || c1)) {
+                    hit |= exact(b0, __builtin_amdgcn_readfirstlane((int)g0), c0);
+                    hit |= exact(b1, __builtin_amdgcn_readfirstlane((int)g1), c1);
+                }
+            }
+        }
+    } else if (MASKED && STATIC) {
         // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
         // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
         // per-lane gathers, no dependent vector-memory round trips), every lane runs the cheap rejection test
@@ -395,8 +448,15 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
                     const gcdouble o1 = sobb + (size_t)(first + (q + 1 < count ? q + 1 : q)) * OB_ROW;
                     const Obb b0 = {o0[OB_CX], o0[OB_CY], o0[OB_UX], o0[OB_UY], o0[OB_HL], o0[OB_HW]};
                     const Obb b1 = {o1[OB_CX], o1[OB_CY], o1[OB_UX], o1[OB_UY], o1[OB_HL], o1[OB_HW]};
-                    if (want && !obb_sep_on_b_axes(ego, b0)) hit |= !obb_sep_on_a_axes(ego, b0);   // strip's own axes first
-                    if (want && q + 1 < count && !obb_sep_on_b_axes(ego, b1)) hit |= !obb_sep_on_a_axes(ego, b1);
+                    // Most members are strips of a road boundary a few metres to the side: one slab (the strip's normal) with the
+                    // ego's bounding circle rejects them in ~7 instructions; the exact test runs only when some lane of the
+                    // wavefront comes that close (wave-uniform), the strip's own axes first.
+                    const bool c0 = want && !obb_normal_far(b0, ego.cx, ego.cy, ego_r);
+                    const bool c1 = want && q + 1 < count && !obb_normal_far(b1, ego.cx, ego.cy, ego_r);
+                    if (__any(c0 || c1)) {
+                        if (c0 && !obb_sep_on_b_axes(ego, b0)) hit |= !obb_sep_on_a_axes(ego, b0);
+                        if (c1 && !obb_sep_on_b_axes(ego, b1)) hit |= !obb_sep_on_a_axes(ego, b1);
+                    }
                 }
             } else if (kind == 1) {
                 for (int q = 0; q < count; ++q) {

@@ -52,7 +52,7 @@ struct rp_ctx {
     double proj_d_limit = 20.0;
     std::vector<double> h_pos;    // host copy of ref_pos (table window of the single-launch variant)
     // obstacles
-    double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr;
+    double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr, *d_slot = nullptr;
     int32_t *d_clus_info = nullptr;
     ObsTables obs{};
 
@@ -220,8 +220,10 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     // consecutive candidates of one workgroup touch at most this many (T, longitudinal sample) pairs
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
     // reference tables + profile rows + pair headers + pre-filter votes + time sample per pair
-    const size_t bytes = (size_t)ka.table_words * sizeof(double) +
-                         (size_t)P * ((size_t)PF_STRIDE * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 8;
+    // (+ the member slots of the static clusters, which the broad phase of the prologue reads from LDS)
+    const size_t slot_bytes = (!cin && ka.use_near_mask && ka.has_obstacles) ? (size_t)ka.obs.n_clus * ka.obs.clus_per * RP_SLOT_ROW * sizeof(double) : 0;
+    const size_t bytes = (size_t)ka.table_words * sizeof(double) + slot_bytes +
+                         (size_t)P * ((size_t)PF_STRIDE * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 16;
     if (bytes > kFusedLonLdsLimit) return 0;
     *pairs = P;
     return (bytes + 15) & ~(size_t)15;
@@ -728,7 +730,7 @@ void rp_destroy(rp_ctx *c) {
                      c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
+    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
                    c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
@@ -881,7 +883,30 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     const int n_clus = (int)(ci.size() / 4);
     const int clus_per = std::max(1, (n_sobb + n_tri + n_circ + 59) / 60);
     if (n_clus > 63) return fail(c, RP_EINVAL, "rp_set_obstacles: internal error, more than 63 static clusters");
+    // member slots of the clusters as one flat table (rp_device.h: ObsTables::slot)
+    std::vector<double> sl((size_t)n_clus * clus_per * RP_SLOT_ROW, 0.0);
+    for (int cidx = 0; cidx < n_clus; ++cidx) {
+        const int kind = ci[4 * cidx], first = ci[4 * cidx + 1], cnt = ci[4 * cidx + 2];
+        unsigned long long bit = 1ull << cidx;
+        double bit_d;
+        std::memcpy(&bit_d, &bit, sizeof(bit_d));
+        for (int m = 0; m < clus_per; ++m) {
+            double *r = &sl[((size_t)cidx * clus_per + m) * RP_SLOT_ROW];
+            r[6] = bit_d;
+            if (m >= cnt) { r[2] = 1.0; r[4] = r[5] = -HUGE_VAL; continue; }
+            const int j = first + m;
+            r[7] = (double)(kind + 4 * j);   // what the narrow phase needs to find the shape itself
+            if (kind == 0) {
+                for (int q = 0; q < 6; ++q) r[q] = a[(size_t)j * OB_ROW + q];
+            } else {
+                const double bx = kind == 1 ? b[(size_t)j * 10 + 6] : d[(size_t)j * 4], by = kind == 1 ? b[(size_t)j * 10 + 7] : d[(size_t)j * 4 + 1];
+                const double rr = kind == 1 ? b[(size_t)j * 10 + 8] : d[(size_t)j * 4 + 2];
+                r[0] = bx; r[1] = by; r[2] = 1.0; r[3] = 0.0; r[4] = r[5] = rr;
+            }
+        }
+    }
     int rc;
+    if ((rc = upload(c, c->d_slot, sl)) != RP_OK) return rc;
     if ((rc = upload(c, c->d_clus, cl)) != RP_OK) return rc;
     if (c->d_clus_info) { HIP_TRY(c, hipFree(c->d_clus_info)); c->d_clus_info = nullptr; }
     if (n_clus) {
@@ -896,6 +921,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
     c->obs.clus = c->d_clus; c->obs.clus_info = c->d_clus_info; c->obs.n_clus = n_clus; c->obs.clus_per = clus_per;
+    c->obs.slot = c->d_slot;
     c->have_last = false;
     return RP_OK;
 }

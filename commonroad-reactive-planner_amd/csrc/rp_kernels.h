@@ -152,13 +152,16 @@ struct DevResult {
 #ifndef RP_STAMP_BLOCK
 #define RP_STAMP_BLOCK 0
 #endif
+#ifndef RP_STAMP_THREAD
+#define RP_STAMP_THREAD 0
+#endif
 #define RP_STAMP(k)                                                                              \
     do {                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         unsigned long long t_;                                                                   \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == 0) a.debug[(k)] = t_;                   \
+        if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) a.debug[(k)] = t_;                   \
     } while (0)
 #else
 #define RP_STAMP(k) do { } while (0)
@@ -1024,6 +1027,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     int64_t pair0 = a.pair_begin;
     CandIn cin;
     ProfStep pf0;        // first step block of this lane group's candidate
+    const double *slot_lds = nullptr;   // single-launch variants with static shapes: the workgroup's copy of ObsTables::slot
     if (LON_FUSED) {
         // dynamic LDS: reference tables | profile rows [lds_pairs][PF_FIELDS][n] | pair headers | pre-filter votes |
         //              time sample of each pair [lds_pairs]
@@ -1033,6 +1037,10 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         PairHdr *const lds_hdr = reinterpret_cast<PairHdr *>(lds_prof + (size_t)a.lds_pairs * PF_STRIDE * (size_t)n0);   // (PF_STRIDE * 8 * pairs * n0: a multiple of 8)
         int *const lds_flags = reinterpret_cast<int *>(lds_hdr + a.lds_pairs);
         double *const lds_T = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs] time sample of the pair
+        // member slots of the static clusters (ObsTables::slot), 16-byte aligned behind the time samples
+        double *const lds_slot = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_T + a.lds_pairs) + 15) & ~(uintptr_t)15);
+        const int n_slots = (COLL == 2 && !COEFFS_IN && a.use_near_mask && a.has_obstacles) ? a.obs.n_clus * a.obs.clus_per : 0;
+        slot_lds = lds_slot;
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
         const int64_t s_first = (int64_t)blockIdx.x * GPB;
         const int64_t s_last = (s_first + GPB <= count ? s_first + GPB : count) - 1;
@@ -1137,6 +1145,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 }
             }
             const bool whole = !windowed || pass == 1;
+            if (COLL == 2 && pass == 0 && wave_in_block == RP_BLOCK / 64 - 1) {
+                // the wavefront that only clears mask words below brings the slot table of the static clusters into LDS
+                // while the others work out the profile rows (one round trip, requests back to back)
+                const double2 *src = reinterpret_cast<const double2 *>(a.obs.slot);
+                double2 *dst = reinterpret_cast<double2 *>(lds_slot);
+                const int n2 = n_slots * (RP_SLOT_ROW / 2);
+#pragma unroll 4
+                for (int k = lane; k < n2; k += 64) dst[k] = src[k];
+            }
             while (j < items) {
                 const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
                 RP_STAMP(18);
@@ -1212,9 +1229,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             };
             const gcdouble dyn = (gcdouble)ob.dyn;
             const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
-            const gcint info = (gcint)ob.clus_info;
-            const int per = ob.clus_per > 0 ? ob.clus_per : 1;   // members per cluster (the last cluster of a kind may hold fewer)
-            const int slots = ob.n_clus * per;
             // lanes_per_item lanes share an item: each works the bound out once and takes every lanes_per_item-th shape
             const int lanes_per_item = items >= RP_BLOCK ? 1 : RP_BLOCK / items;
             const int sub = tid % lanes_per_item;
@@ -1236,7 +1250,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 RP_STAMP(23);
                 if (!bounded) {   // no bound: every bit
                     if (sub == 0 && dyn_here) atomicOr(mask_word(it, PF_NEAR), ~0ull);
-                    if (sub == 0 && slots > 0) atomicOr(mask_word(it, PF_NEAR_S), ~0ull);
+                    if (sub == 0 && n_slots > 0) atomicOr(mask_word(it, PF_NEAR_S), ~0ull);
                     continue;
                 }
                 if (dyn_here) {
@@ -1252,11 +1266,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     }
                     if (m) atomicOr(mask_word(it, PF_NEAR), m);
                 }
+                // static shapes: the slot rows in LDS, two slabs each (tight for the long thin strips of a road boundary, where a
+                // bounding circle says nothing).  Was: cluster descriptor -> shape row through dependent loads from device memory,
+                // ~20 slots per lane one after the other -- 13 k cycles of the prologue with 85 boundary rectangles.
                 uint64_t ms = 0;
                 if (COLL == 2)
-                for (int r = sub; r < slots; r += lanes_per_item) {
-                    const int c = (int)((uint32_t)r / (uint32_t)per), mem = r - c * per;
-                    if (mem < info[4 * c + 2] && static_shape_near(ob, info[4 * c], info[4 * c + 1] + mem, bx, by, bR)) ms |= 1ull << c;
+                for (int r = sub; r < n_slots; r += lanes_per_item) {
+                    const double *o = lds_slot + (size_t)r * RP_SLOT_ROW;
+                    const Obb b = {o[0], o[1], o[2], o[3], o[4], o[5]};
+                    if (!obb_slab_far(b, bx, by, bR)) ms |= double_as_mask(o[6]);
                 }
                 if (ms) atomicOr(mask_word(it, PF_NEAR_S), ms);
             }
@@ -1672,7 +1690,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         ob.n_sobb = al.obs.n_sobb; ob.n_tri = al.obs.n_tri; ob.n_circ = al.obs.n_circ; ob.n_dyn = al.obs.n_dyn;
                         ob.n_steps = al.obs.n_steps; ob.dyn_t0 = al.obs.dyn_t0; ob.n_clus = al.obs.n_clus; ob.clus_per = al.obs.clus_per;
                         const Obb ego = {x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl, cos_gl, sin_gl, al.half_length, al.half_width};
-                        hit = pose_collides<masked, COLL == 2>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask, near_dyn, near_sta) && ask;
+                        hit = pose_collides<masked, COLL == 2, LON_FUSED && masked && COLL == 2>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
+                                                                                                 near_dyn, near_sta, slot_lds) && ask;
                     }
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }
