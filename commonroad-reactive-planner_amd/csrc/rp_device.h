@@ -209,6 +209,17 @@ __device__ __forceinline__ bool obb_slab_far(const Obb &b, double ex, double ey,
     return fabs(tx * b.ux + ty * b.uy) > (b.hl + ego_r) * 1.000001 || fabs(ty * b.ux - tx * b.uy) > (b.hw + ego_r) * 1.000001;
 }
 
+// bits of the static clusters within reach of an ego rectangle centred at (ex, ey)
+__device__ __forceinline__ uint64_t static_grid_mask(const unsigned long long *grid, double gx0, double gy0, double ginv, int gnx, int gny,
+                                                     double ex, double ey) {
+    const double fx = (ex - gx0) * ginv, fy = (ey - gy0) * ginv;
+    if (gnx < 0 || !(fx == fx && fy == fy)) return ~0ull;   // no grid (a shape without finite extent) / NaN pose: nothing can be
+                                                             // ruled out, the exact tests decide
+    // outside the grid nothing is within reach: it covers every shape inflated by the reach
+    if (!(fx >= 0.0 && fy >= 0.0 && fx < (double)gnx && fy < (double)gny)) return 0ull;
+    return grid[(size_t)(int)fy * (size_t)gnx + (size_t)(int)fx];
+}
+
 // the slab along b's normal alone (the one that says something for a long thin strip)
 __device__ __forceinline__ bool obb_normal_far(const Obb &b, double ex, double ey, double ego_r) {
     const double tx = ex - b.cx, ty = ey - b.cy;
@@ -300,7 +311,13 @@ struct ObsTables {
     // the single-launch prologue tests, as one flat table it can stage in LDS instead of chasing cluster descriptor -> shape row
     // through dependent loads.  Rectangles as they are; triangles and circles as the square around their bounding circle;
     // slots without a member: half extents -inf (never near).
-    const double *slot;        // [n_clus * clus_per][RP_SLOT_ROW]  cx, cy, ux, uy, hl, hw, bit of the cluster (as a double), -
+    const double *slot;        // [n_clus * clus_per][RP_SLOT_ROW]  cx, cy, ux, uy, hl, hw, bit of the cluster (as a double), kind + 4 index
+    // uniform grid over the static shapes (rp_host.hip: ensure_static_grid): cell -> bits of the clusters with a member within
+    // reach of an ego rectangle whose centre lies in the cell.  Every pose looks its own mask up (static_grid_mask), so the walk
+    // of the narrow phase visits the few clusters next to the pose instead of every cluster near any candidate of the pair.
+    const unsigned long long *grid;   // [gny][gnx]
+    double gx0, gy0, ginv;            // origin and 1 / cell size
+    int32_t gnx, gny;
     int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0, n_clus, clus_per;   // clus_per: members per cluster (upper bound)
 };
 typedef const int32_t __attribute__((address_space(4))) *gcint;
@@ -379,6 +396,13 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 // clusters reads member rows from there (broadcast reads, tens of cycles) instead of through chained scalar loads from device
 // memory (cluster descriptor -> member rows: a few hundred cycles per cluster with nothing to overlap them with when a SIMD
 // holds one or two wavefronts -- that chain, not the tests, was the cost of a road boundary on a small batch).
+#ifdef RP_WALK_COUNT
+static __device__ unsigned long long *rp_walk_dbg = nullptr;   // diagnostic: clusters walked / queries / exact tests of one wavefront
+#define RP_WSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0); if (rp_walk_dbg && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) rp_walk_dbg[(k)] = t_; } while (0)
+#else
+#define RP_WSTAMP(k) do { } while (0)
+#endif
 template <bool MASKED, bool STATIC, bool LDS_SLOTS = false>
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
                                               uint64_t near_static, const double *lds_slot = nullptr) {
@@ -388,6 +412,10 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         uint64_t mu = wave_or_u64(want ? near_static : 0);
         mu &= ob.n_clus >= 64 ? ~0ull : (1ull << ob.n_clus) - 1ull;
         const int per = ob.clus_per;
+#ifdef RP_WALK_COUNT
+        if (rp_walk_dbg && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) { rp_walk_dbg[0] += (unsigned long long)__popcll(mu); rp_walk_dbg[1] += 1; }
+#endif
+        RP_WSTAMP(8);
         auto exact = [&](const Obb &b, int tag, bool close) -> bool {   // tag: kind + 4 * index in the table of that kind (wave-uniform)
             const int kind = tag & 3, j = tag >> 2;
             if (kind == 0) return close && !obb_sep_on_b_axes(ego, b) && !obb_sep_on_a_axes(ego, b);   // strip's own axes first
@@ -404,23 +432,30 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         while (mu != 0) {   // wave-uniform
             const int c = __ffsll((unsigned long long)mu) - 1;
             mu &= mu - 1;
-            const double *row = lds_slot + (size_t)(c * per) * RP_SLOT_ROW;
+            // (explicitly an LDS pointer: through a generic one the rows come by flat loads, which count on the vector-memory
+            //  counter as well -- and waiting for them then means waiting for the write-through row stores issued before)
+            typedef const double __attribute__((address_space(3))) *lds_cdouble;
+            const lds_cdouble row = (lds_cdouble)lds_slot + (size_t)(c * per) * RP_SLOT_ROW;
             for (int m = 0; m < per; m += 2) {
                 const bool two = m + 1 < per;
-                const double *o0 = row + (size_t)m * RP_SLOT_ROW, *o1 = row + (size_t)(two ? m + 1 : m) * RP_SLOT_ROW;
+                const lds_cdouble o0 = row + (size_t)m * RP_SLOT_ROW, o1 = row + (size_t)(two ? m + 1 : m) * RP_SLOT_ROW;
                 const Obb b0 = {o0[0], o0[1], o0[2], o0[3], o0[4], o0[5]};
                 const Obb b1 = {o1[0], o1[1], o1[2], o1[3], o1[4], o1[5]};
                 const double g0 = o0[7], g1 = o1[7];
-                // one slab (the shape's normal; slots without a member have half extents -inf: always far) with the ego's
-                // bounding circle first; the exact test only when some lane of the wavefront comes that close
-                const bool c0 = want && !obb_normal_far(b0, ego.cx, ego.cy, ego_r);
-                const bool c1 = want && two && !obb_normal_far(b1, ego.cx, ego.cy, ego_r);
+                // the shape's two slabs (slots without a member have half extents -inf: always far) with the ego's bounding circle
+                // first; the exact test only when some lane of the wavefront comes that close
+                const bool c0 = want && !obb_slab_far(b0, ego.cx, ego.cy, ego_r);
+                const bool c1 = want && two && !obb_slab_far(b1, ego.cx, ego.cy, ego_r);
                 if (__any(c0 || c1)) {
+#ifdef RP_WALK_COUNT
+                    { const int ne_ = (__any(c0) ? 1 : 0) + (__any(c1) ? 1 : 0); if (rp_walk_dbg && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) rp_walk_dbg[2] += ne_; }
+#endif
                     hit |= exact(b0, __builtin_amdgcn_readfirstlane((int)g0), c0);
                     hit |= exact(b1, __builtin_amdgcn_readfirstlane((int)g1), c1);
                 }
             }
         }
+        RP_WSTAMP(9);
     } else if (MASKED && STATIC) {
         // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
         // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
@@ -524,6 +559,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         return hit;
     }
     uint64_t m = k_ok ? near : 0;
+    RP_WSTAMP(10);
     const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
     m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
     while (__any(m != 0)) {   // wave-uniform trip count = largest number of near obstacles among the lanes

@@ -53,6 +53,12 @@ struct rp_ctx {
     std::vector<double> h_pos;    // host copy of ref_pos (table window of the single-launch variant)
     // obstacles
     double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr, *d_slot = nullptr;
+    // uniform grid over the static shapes, built for the ego radius of the plans (ensure_static_grid)
+    unsigned long long *d_grid = nullptr;
+    std::vector<double> h_sobb, h_tri, h_circ;   // host copies of the static rows (device layout) and the cluster descriptors
+    std::vector<int32_t> h_clus_info;
+    bool grid_valid = false;
+    double grid_ego_r = 0.0;
     int32_t *d_clus_info = nullptr;
     ObsTables obs{};
 
@@ -638,6 +644,20 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
         for (int k = 1; k < 24; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[0]));
+#ifdef RP_WALK_COUNT
+        {
+            unsigned long long wc[4];
+            HIP_TRY(c, hipMemcpy(wc, c->d_debug + 40, sizeof(wc), hipMemcpyDeviceToHost));
+            unsigned long long xs[4], s0;
+            HIP_TRY(c, hipMemcpy(xs, c->d_debug + 44, sizeof(xs), hipMemcpyDeviceToHost));
+            HIP_TRY(c, hipMemcpy(&s0, c->d_debug, sizeof(s0), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "\ncollision block: [44]%lld [45]%lld [46]%lld", (long long)(xs[0] - s0), (long long)(xs[1] - s0), (long long)(xs[2] - s0));
+            unsigned long long ws[3];
+            HIP_TRY(c, hipMemcpy(ws, c->d_debug + 48, sizeof(ws), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, " | in pose_collides: masks or-ed %lld, static walk done %lld, dynamic part reached %lld", (long long)(ws[0] - s0), (long long)(ws[1] - s0), (long long)(ws[2] - s0));
+            std::fprintf(stderr, "\nstatic walk of that wavefront (accumulated over the launches so far): clusters %llu, queries %llu, exact member tests %llu", wc[0], wc[1], wc[2]);
+        }
+#endif
         std::fprintf(stderr, "\nfinalize stamps (cycles since its start):");
         for (int k = 25; k < 31; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[24]));
         std::fprintf(stderr, "\n");
@@ -730,7 +750,7 @@ void rp_destroy(rp_ctx *c) {
                      c->t_sum[2] / c->t_calls, c->t_sum[3] / c->t_calls);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
+    void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_grid, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
                    c->d_pair_hdr, c->d_pair_hdr_one};
     for (void *p : dev)
@@ -816,6 +836,89 @@ int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *
     while ((1 << it) < n + 1) ++it;
     c->search_iters = it + 1;
     c->have_last = false;
+    return RP_OK;
+}
+
+// Uniform grid over the static shapes for an ego rectangle of bounding radius ego_r: bit k of a cell is set when a member of
+// cluster k lies within ego_r (+ half a cell diagonal + a margin) of the cell's centre, i.e. can be touched by an ego
+// rectangle whose centre lies anywhere in the cell.  Distances: exact for rectangles, through the bounding circle for
+// triangles (an under-estimate: more bits, never fewer).  At most ~2^20 cells (8 MB); the cell grows with the map.
+// Built on first use and again when a plan comes with a larger ego rectangle (a smaller one keeps the grid: still conservative).
+int ensure_static_grid(rp_ctx *c, double ego_r) {
+    if (c->grid_valid && ego_r <= c->grid_ego_r) return RP_OK;
+    const int n_clus = (int)(c->h_clus_info.size() / 4);
+    c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0;
+    c->grid_valid = true; c->grid_ego_r = ego_r;
+    if (n_clus == 0 || !(ego_r == ego_r) || !(ego_r < 1e300)) return RP_OK;   // (no static shapes: every lookup says "nothing")
+    struct Shape { int clus, kind; double cx, cy, ux, uy, hl, hw; };   // triangles / circles: the circle (cx, cy), radius hl
+    std::vector<Shape> shapes;
+    double x0 = HUGE_VAL, y0 = HUGE_VAL, x1 = -HUGE_VAL, y1 = -HUGE_VAL;
+    for (int k = 0; k < n_clus; ++k) {
+        const int kind = c->h_clus_info[4 * k], first = c->h_clus_info[4 * k + 1], cnt = c->h_clus_info[4 * k + 2];
+        for (int m = 0; m < cnt; ++m) {
+            Shape sh{k, kind, 0, 0, 1, 0, 0, 0};
+            double ex, ey;   // half extents of the axis-aligned box of the shape
+            if (kind == 0) {
+                const double *o = &c->h_sobb[(size_t)(first + m) * OB_ROW];
+                sh.cx = o[OB_CX]; sh.cy = o[OB_CY]; sh.ux = o[OB_UX]; sh.uy = o[OB_UY]; sh.hl = o[OB_HL]; sh.hw = o[OB_HW];
+                ex = std::fabs(sh.ux) * sh.hl + std::fabs(sh.uy) * sh.hw; ey = std::fabs(sh.uy) * sh.hl + std::fabs(sh.ux) * sh.hw;
+            } else if (kind == 1) {
+                const double *o = &c->h_tri[(size_t)(first + m) * 10];
+                sh.cx = o[6]; sh.cy = o[7]; sh.hl = o[8]; ex = ey = o[8];
+            } else {
+                const double *o = &c->h_circ[(size_t)(first + m) * 4];
+                sh.cx = o[0]; sh.cy = o[1]; sh.hl = o[2]; ex = ey = o[2];
+            }
+            if (!(sh.cx == sh.cx && sh.cy == sh.cy && ex == ex && ey == ey) || !(std::fabs(sh.cx) < 1e300 && std::fabs(sh.cy) < 1e300 && ex < 1e300 && ey < 1e300)) {
+                c->obs.gnx = c->obs.gny = -1;   // a shape without finite extent: no grid, every pose walks every cluster
+                return RP_OK;
+            }
+            sh.hw = kind == 0 ? sh.hw : 0.0;
+            shapes.push_back(sh);
+            x0 = std::min(x0, sh.cx - ex); x1 = std::max(x1, sh.cx + ex);
+            y0 = std::min(y0, sh.cy - ey); y1 = std::max(y1, sh.cy + ey);
+        }
+    }
+    if (shapes.empty()) return RP_OK;
+    // cell size: 0.5 m unless that takes more than ~2^20 cells
+    double cell = 0.5;
+    for (int it = 0; it < 64; ++it) {
+        const double R = ego_r + cell * 0.70710678118654757 + 1e-6;
+        const double w = (x1 - x0) + 2.0 * (R + cell), h = (y1 - y0) + 2.0 * (R + cell);
+        if ((w / cell) * (h / cell) <= 1048576.0) break;
+        cell *= 1.25;
+    }
+    const double R = (ego_r + cell * 0.70710678118654757) * (1.0 + 1e-9) + 1e-6;
+    const double gx0 = x0 - (R + cell), gy0 = y0 - (R + cell);
+    const int nx = (int)std::ceil(((x1 + R + cell) - gx0) / cell) + 1, ny = (int)std::ceil(((y1 + R + cell) - gy0) / cell) + 1;
+    std::vector<unsigned long long> cells((size_t)nx * (size_t)ny, 0ull);
+    for (const Shape &sh : shapes) {
+        const double ex = sh.kind == 0 ? std::fabs(sh.ux) * sh.hl + std::fabs(sh.uy) * sh.hw : sh.hl;
+        const double ey = sh.kind == 0 ? std::fabs(sh.uy) * sh.hl + std::fabs(sh.ux) * sh.hw : sh.hl;
+        const int ix0 = std::max(0, (int)std::floor((sh.cx - ex - R - gx0) / cell) - 1), ix1 = std::min(nx - 1, (int)std::floor((sh.cx + ex + R - gx0) / cell) + 1);
+        const int iy0 = std::max(0, (int)std::floor((sh.cy - ey - R - gy0) / cell) - 1), iy1 = std::min(ny - 1, (int)std::floor((sh.cy + ey + R - gy0) / cell) + 1);
+        const unsigned long long bit = 1ull << sh.clus;
+        for (int iy = iy0; iy <= iy1; ++iy) {
+            const double py = gy0 + ((double)iy + 0.5) * cell - sh.cy;
+            for (int ix = ix0; ix <= ix1; ++ix) {
+                const double px = gx0 + ((double)ix + 0.5) * cell - sh.cx;
+                double dist;
+                if (sh.kind == 0) {
+                    const double lx = std::fabs(px * sh.ux + py * sh.uy) - sh.hl, ly = std::fabs(py * sh.ux - px * sh.uy) - sh.hw;
+                    dist = std::hypot(std::max(lx, 0.0), std::max(ly, 0.0));
+                } else {
+                    dist = std::max(0.0, std::hypot(px, py) - sh.hl);
+                }
+                if (dist <= R) cells[(size_t)iy * nx + ix] |= bit;
+            }
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_grid) { HIP_TRY(c, hipFree(c->d_grid)); c->d_grid = nullptr; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_grid, cells.size() * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemcpy(c->d_grid, cells.data(), cells.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    c->obs.grid = c->d_grid; c->obs.gx0 = gx0; c->obs.gy0 = gy0; c->obs.ginv = 1.0 / cell; c->obs.gnx = nx; c->obs.gny = ny;
     return RP_OK;
 }
 
@@ -922,6 +1025,9 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
     c->obs.clus = c->d_clus; c->obs.clus_info = c->d_clus_info; c->obs.n_clus = n_clus; c->obs.clus_per = clus_per;
     c->obs.slot = c->d_slot;
+    c->h_sobb = a; c->h_tri = b; c->h_circ = d; c->h_clus_info = ci;
+    c->grid_valid = false;
+    c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0; c->obs.gx0 = c->obs.gy0 = 0.0; c->obs.ginv = 0.0;
     c->have_last = false;
     return RP_OK;
 }
@@ -974,6 +1080,10 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
 
     KArgs ka;
+    {   // (the grid over the static shapes belongs to the ego rectangle of the plan; fill_common copies its descriptor)
+        const int grc = ensure_static_grid(c, std::sqrt(0.25 * p->length * p->length + 0.25 * p->width * p->width));
+        if (grc != RP_OK) return grc;
+    }
     fill_common(c, p, cost, ka);
     const double *ds = reinterpret_cast<const double *>(c->d_stage);
     ka.nT = g->nT; ka.nL = g->nL; ka.nD = g->nD; ka.grids_inline = grids_inline ? 1 : 0;
@@ -1024,6 +1134,10 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)C)) != RP_OK) return rc;
     if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
     KArgs ka;
+    {   // (the grid over the static shapes belongs to the ego rectangle of the plan; fill_common copies its descriptor)
+        const int grc = ensure_static_grid(c, std::sqrt(0.25 * p->length * p->length + 0.25 * p->width * p->width));
+        if (grc != RP_OK) return grc;
+    }
     fill_common(c, p, cost, ka);
     const double *ds = reinterpret_cast<const double *>(c->d_stage);
     ka.lon_coeffs = ds; ka.lat_coeffs = ds + 6 * C;

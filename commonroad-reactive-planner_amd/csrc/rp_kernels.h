@@ -796,24 +796,7 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
         }
         f[PF_NEAR] = mask_as_double(m);
     }
-    if (ob.n_clus > 0) {
-        uint64_t m = ~0ull;
-        if (bounded) {
-            // cluster bit = some member can be reached
-            const gcdouble cl = (gcdouble)ob.clus;
-            const gcint info = (gcint)ob.clus_info;
-            m = 0;
-            for (int c = 0; c < ob.n_clus; ++c) {
-                const double dx = cl[4 * c] - cx, dy = cl[4 * c + 1] - cy, rr = R + cl[4 * c + 2];
-                if (!(dx * dx + dy * dy <= rr * rr * 1.000001)) continue;
-                const int kind = info[4 * c], first = info[4 * c + 1], count = info[4 * c + 2];
-                bool any = false;
-                for (int q = 0; q < count; ++q) any |= static_shape_near(ob, kind, first + q, cx, cy, R);
-                if (any) m |= 1ull << c;
-            }
-        }
-        f[PF_NEAR_S] = mask_as_double(m);
-    }
+    // (static shapes: no (pair, step) mask -- every pose looks its own cell of the grid over them up, rp_device.h: static_grid_mask)
 }
 
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
@@ -1207,7 +1190,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             else lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], cin.v[0], 0.0, 0.0, cin.lat_T);
             if (gl == 0) park_poly(sh_grp[grp].poly, lat);   // same-wave LDS ordering makes it visible to the group
         }
-        if (!COEFFS_IN && a.use_near_mask && a.has_obstacles) {
+        if (!COEFFS_IN && a.use_near_mask && a.has_obstacles && a.obs.n_dyn > 0) {   // (only dynamic obstacles have (pair, step) masks)
             // Broad phase of the collision query (near_mask_step), spread over the whole workgroup: one lane per
             // (item, shape) test; every lane derives its item's bound from the profile rows in LDS (one lane per item
             // walking every shape would sit on the critical path of the workgroup).
@@ -1250,7 +1233,6 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 RP_STAMP(23);
                 if (!bounded) {   // no bound: every bit
                     if (sub == 0 && dyn_here) atomicOr(mask_word(it, PF_NEAR), ~0ull);
-                    if (sub == 0 && n_slots > 0) atomicOr(mask_word(it, PF_NEAR_S), ~0ull);
                     continue;
                 }
                 if (dyn_here) {
@@ -1266,17 +1248,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     }
                     if (m) atomicOr(mask_word(it, PF_NEAR), m);
                 }
-                // static shapes: the slot rows in LDS, two slabs each (tight for the long thin strips of a road boundary, where a
-                // bounding circle says nothing).  Was: cluster descriptor -> shape row through dependent loads from device memory,
-                // ~20 slots per lane one after the other -- 13 k cycles of the prologue with 85 boundary rectangles.
-                uint64_t ms = 0;
-                if (COLL == 2)
-                for (int r = sub; r < n_slots; r += lanes_per_item) {
-                    const double *o = lds_slot + (size_t)r * RP_SLOT_ROW;
-                    const Obb b = {o[0], o[1], o[2], o[3], o[4], o[5]};
-                    if (!obb_slab_far(b, bx, by, bR)) ms |= double_as_mask(o[6]);
-                }
-                if (ms) atomicOr(mask_word(it, PF_NEAR_S), ms);
+                // (static shapes have no (pair, step) mask: static_grid_mask per pose)
             }
             __syncthreads();
         }
@@ -1580,6 +1552,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     }
                     cost_acc += cost_terms(i, acc, v, s, d, th_cl);
                 }
+                // static shapes: the pose's cell of the grid over them (static_grid_mask) is requested here for the valid steps,
+                // whose pose is final, and behind the extension for the extended ones -- and waited for IN FRONT of the row stores.
+                // Loads and stores share one in-order counter (vmcnt): a load that is waited for behind the write-through stores
+                // of the rows is waited for together with their acknowledgements from memory (6 000 cycles per step block, measured).
+                uint64_t near_sta_cell = 0;
+                const bool cell_wanted = COLL == 2 && !COEFFS_IN && live && alive && fail_step < 0 && ood_step < 0;
+                if (cell_wanted && act)
+                    near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
+                                                     x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
                 RP_STAMP(8);   // x, y + stores of valid steps
 
                 // -- horizon extension (trajectories.py:168-197, 302-332); only chunks that hold states >= L
@@ -1651,6 +1632,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         cumy = group_bcast<G>(scy, G - 1);
                     }
                 }
+                if (COLL == 2 && !COEFFS_IN) {
+                    if (cell_wanted && !act)
+                        near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
+                                                         x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
+                    uint32_t c_lo = (uint32_t)near_sta_cell, c_hi = (uint32_t)(near_sta_cell >> 32);
+                    asm volatile("" : "+v"(c_lo), "+v"(c_hi));   // the cell has arrived before the first row store is issued
+                    near_sta_cell = ((uint64_t)c_hi << 32) | c_lo;
+                }
                 // (lanes in the padding behind step N store too: their values are never read, and the run of the lane group
                 //  then ends on a line boundary)
                 if (LATE_STORE && store_ok && i < ns) {
@@ -1681,18 +1670,27 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     // lane of the wavefront has a bit set.  (Few obstacles: most wavefronts skip it at most steps.)
                     constexpr bool masked = !COEFFS_IN;   // (the host keeps use_near_mask set for grid plans with obstacles; a pair
                                                           //  without a bound gets all-ones masks)
-                    const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]), near_sta = double_as_mask(pf.f[PF_NEAR_S]);
+                    // dynamic obstacles: the (pair, step) mask of the profile; static shapes: the pose's own cell of the grid over them
+                    const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]);
+                    const double ego_cx = x + al.wb_rear_axle * cos_gl, ego_cy = y + al.wb_rear_axle * sin_gl;
+                    const uint64_t near_sta = want ? near_sta_cell : 0;
                     const bool ask = want && (!masked || (near_dyn | near_sta) != 0);
+                    RP_STAMP(44);
+#ifdef RP_WALK_COUNT
+                    if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) rp_walk_dbg = a.debug + 40;
+#endif
                     if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
                         ObsTables ob;   // (copied out of the constant address space, member by member)
                         ob.sobb = al.obs.sobb; ob.tri = al.obs.tri; ob.circ = al.obs.circ; ob.dyn = al.obs.dyn;
                         ob.clus = al.obs.clus; ob.clus_info = al.obs.clus_info;
                         ob.n_sobb = al.obs.n_sobb; ob.n_tri = al.obs.n_tri; ob.n_circ = al.obs.n_circ; ob.n_dyn = al.obs.n_dyn;
                         ob.n_steps = al.obs.n_steps; ob.dyn_t0 = al.obs.dyn_t0; ob.n_clus = al.obs.n_clus; ob.clus_per = al.obs.clus_per;
-                        const Obb ego = {x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl, cos_gl, sin_gl, al.half_length, al.half_width};
+                        const Obb ego = {ego_cx, ego_cy, cos_gl, sin_gl, al.half_length, al.half_width};
+                        RP_STAMP(45);
                         hit = pose_collides<masked, COLL == 2, LON_FUSED && masked && COLL == 2>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
                                                                                                  near_dyn, near_sta, slot_lds) && ask;
                     }
+                    RP_STAMP(46);
                     collide |= group_ballot<G>(hit, gbase) != 0;
                 }
                 RP_STAMP(11);  // collision
