@@ -403,12 +403,15 @@ static __device__ unsigned long long *rp_walk_dbg = nullptr;   // diagnostic: cl
 #else
 #define RP_WSTAMP(k) do { } while (0)
 #endif
-template <bool MASKED, bool STATIC, bool LDS_SLOTS = false>
+// STATIC_MASKED: `near_static` holds this lane's bits of static clusters (the evaluation kernels: the pose's cell of the grid over
+// the static shapes, whatever the plan; MASKED only says whether `near` is a mask of DYNAMIC obstacles); else every static shape
+// is tested behind a wave-level bounding-circle rejection (the swept-volume check, whose boxes the grid was not built for).
+template <bool MASKED, bool STATIC, bool LDS_SLOTS = false, bool STATIC_MASKED = MASKED>
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
                                               uint64_t near_static, const double *lds_slot = nullptr) {
     bool hit = false;
     const gcdouble sobb = (gcdouble)ob.sobb, tri = (gcdouble)ob.tri, circ = (gcdouble)ob.circ, dyn = (gcdouble)ob.dyn;
-    if (MASKED && STATIC && LDS_SLOTS) {
+    if (STATIC_MASKED && STATIC && LDS_SLOTS) {
         uint64_t mu = wave_or_u64(want ? near_static : 0);
         mu &= ob.n_clus >= 64 ? ~0ull : (1ull << ob.n_clus) - 1ull;
         const int per = ob.clus_per;
@@ -456,7 +459,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
             }
         }
         RP_WSTAMP(9);
-    } else if (MASKED && STATIC) {
+    } else if (STATIC_MASKED && STATIC) {
         // static shapes: the clusters whose bit is set in the (pair, step) mask of ANY lane of the wavefront, walked
         // with wave-uniform control flow -- rows come through scalar loads (one 64-byte row per instruction, no
         // per-lane gathers, no dependent vector-memory round trips), every lane runs the cheap rejection test

@@ -227,7 +227,7 @@ size_t fused_lon_lds(const rp_ctx *c, const KArgs &ka, int64_t count, int G, boo
     const int P = cin ? gpb : std::min<int64_t>(gpb, ((int64_t)gpb + ka.nD - 2) / ka.nD + 1);
     // reference tables + profile rows + pair headers + pre-filter votes + time sample per pair
     // (+ the member slots of the static clusters, which the broad phase of the prologue reads from LDS)
-    const size_t slot_bytes = (!cin && ka.use_near_mask && ka.has_obstacles) ? (size_t)ka.obs.n_clus * ka.obs.clus_per * RP_SLOT_ROW * sizeof(double) : 0;
+    const size_t slot_bytes = ka.has_obstacles ? (size_t)ka.obs.n_clus * ka.obs.clus_per * RP_SLOT_ROW * sizeof(double) : 0;
     const size_t bytes = (size_t)ka.table_words * sizeof(double) + slot_bytes +
                          (size_t)P * ((size_t)PF_STRIDE * (size_t)(ka.N + 1) * sizeof(double) + sizeof(PairHdr) + sizeof(int) + sizeof(double)) + 16;
     if (bytes > kFusedLonLdsLimit) return 0;

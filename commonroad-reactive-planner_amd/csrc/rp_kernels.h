@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         double *const lds_T = reinterpret_cast<double *>(lds_flags + ((a.lds_pairs + 1) & ~1));   // [lds_pairs] time sample of the pair
         // member slots of the static clusters (ObsTables::slot), 16-byte aligned behind the time samples
         double *const lds_slot = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_T + a.lds_pairs) + 15) & ~(uintptr_t)15);
-        const int n_slots = (COLL == 2 && !COEFFS_IN && a.use_near_mask && a.has_obstacles) ? a.obs.n_clus * a.obs.clus_per : 0;
+        const int n_slots = (COLL == 2 && a.has_obstacles) ? a.obs.n_clus * a.obs.clus_per : 0;
         slot_lds = lds_slot;
         // candidates of this workgroup: slots [blockIdx.x * GPB, ...) -- exactly one group of lanes each
         const int64_t s_first = (int64_t)blockIdx.x * GPB;
@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 // Loads and stores share one in-order counter (vmcnt): a load that is waited for behind the write-through stores
                 // of the rows is waited for together with their acknowledgements from memory (6 000 cycles per step block, measured).
                 uint64_t near_sta_cell = 0;
-                const bool cell_wanted = COLL == 2 && !COEFFS_IN && live && alive && fail_step < 0 && ood_step < 0;
+                const bool cell_wanted = COLL == 2 && live && alive && fail_step < 0 && ood_step < 0;
                 if (cell_wanted && act)
                     near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
                                                      x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
@@ -1632,7 +1632,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         cumy = group_bcast<G>(scy, G - 1);
                     }
                 }
-                if (COLL == 2 && !COEFFS_IN) {
+                if (COLL == 2) {
                     if (cell_wanted && !act)
                         near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
                                                          x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
@@ -1674,7 +1674,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     const uint64_t near_dyn = double_as_mask(pf.f[PF_NEAR]);
                     const double ego_cx = x + al.wb_rear_axle * cos_gl, ego_cy = y + al.wb_rear_axle * sin_gl;
                     const uint64_t near_sta = want ? near_sta_cell : 0;
-                    const bool ask = want && (!masked || (near_dyn | near_sta) != 0);
+                    // (explicit polynomials have no (pair, step) masks of dynamic obstacles: those are all tested; static shapes go
+                    //  through the grid for every kind of plan)
+                    const bool ask = want && ((!masked && al.obs.n_dyn > 0) || (near_dyn | near_sta) != 0);
                     RP_STAMP(44);
 #ifdef RP_WALK_COUNT
                     if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) rp_walk_dbg = a.debug + 40;
@@ -1687,8 +1689,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         ob.n_steps = al.obs.n_steps; ob.dyn_t0 = al.obs.dyn_t0; ob.n_clus = al.obs.n_clus; ob.clus_per = al.obs.clus_per;
                         const Obb ego = {ego_cx, ego_cy, cos_gl, sin_gl, al.half_length, al.half_width};
                         RP_STAMP(45);
-                        hit = pose_collides<masked, COLL == 2, LON_FUSED && masked && COLL == 2>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
-                                                                                                 near_dyn, near_sta, slot_lds) && ask;
+                        hit = pose_collides<masked, COLL == 2, LON_FUSED && COLL == 2, true>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
+                                                                                             near_dyn, near_sta, slot_lds) && ask;
                     }
                     RP_STAMP(46);
                     collide |= group_ballot<G>(hit, gbase) != 0;

@@ -414,12 +414,14 @@ def _dense_traffic(co, n_dyn, n_steps, seed=3, dt=0.1):
 
 
 @pytest.mark.parametrize("kind", ["more_than_63_dynamic", "stopping_mode", "lateral_start_velocity", "explicit_polynomials",
-                                  "many_static_clusters"])
+                                  "many_static_clusters", "explicit_polynomials_static", "static_far_apart", "static_nan_shape"])
 def test_collision_mask_edge_paths(ctx, kind):
     """Branches of the (pair, step) broad phase that the benchmark workloads do not reach: the overflow bit for
     dynamic obstacles 63, 64, ...; stopping trajectories (standstill at the last valid step: extended steps are not
     bounded, every bit is set); a lateral start velocity (Hermite overshoot bound); explicit polynomials (no masks at
-    all); more static shapes than cluster bits."""
+    all); more static shapes than cluster bits.  And of the grid over the static shapes (csrc/rp_host.hip: ensure_static_grid): explicit
+    polynomials with static shapes (the grid serves every kind of plan), shapes kilometres apart (the cell size grows with
+    the map; poses outside the grid), a shape without finite extent (no grid: every cluster is walked)."""
     from oracle import oracle
     from commonroad_rp_amd.collision import ObstacleTables
     from commonroad_rp_amd._capi import LON_STOPPING
@@ -428,6 +430,18 @@ def test_collision_mask_edge_paths(ctx, kind):
     co, inp = _synthetic_case(path, N=40)
     n_dyn = {"more_than_63_dynamic": 90, "stopping_mode": 40}.get(kind, 12)
     tables = ObstacleTables(dyn_obb=_dense_traffic(co, n_dyn, 60), dyn_t0=0)
+    if kind in ("explicit_polynomials_static", "static_far_apart", "static_nan_shape"):
+        rng = np.random.default_rng(13)
+        boxes = []
+        for k in range(70):
+            sx = rng.uniform(5.0, 290.0)
+            x, y = co.convert_to_cartesian_coords(sx, rng.choice([-1, 1]) * rng.uniform(1.8, 5.0))
+            boxes.append([x, y, rng.uniform(-3, 3), rng.uniform(0.3, 5.0), rng.uniform(0.05, 0.5)])
+        if kind == "static_far_apart":
+            boxes += [[9000.0, -7000.0, 0.3, 2.0, 1.0], [-8000.0, 6000.0, 1.0, 400.0, 0.5]]
+        if kind == "static_nan_shape":
+            boxes = boxes[:10] + [[float("nan"), 0.0, 0.0, 1.0, 1.0]]
+        tables = ObstacleTables(static_obb=boxes, static_circ=[[40.0, 3.0, 0.5]], dyn_obb=tables.dyn_obb[:4], dyn_t0=0)
     if kind == "many_static_clusters":
         rng = np.random.default_rng(11)
         boxes, tris, circs = [], [], []
@@ -452,7 +466,7 @@ def test_collision_mask_edge_paths(ctx, kind):
     tb = oracle.OracleTables.from_coordinate_system(co, tables)
     for extra in (0, FLAG_DRAW_ALL):
         i2 = _with_flags(inp, extra)
-        if kind == "explicit_polynomials":
+        if kind.startswith("explicit_polynomials"):
             oc = oracle.plan(i2, tb)   # coefficients of every candidate from the oracle, then the coefficient entry
             lon_T = np.repeat(i2.T, len(i2.L) * len(i2.D))
             tl = np.repeat(i2.traj_len, len(i2.L) * len(i2.D))
