@@ -176,7 +176,8 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
     pmc = load_json(PMC_FILE).get(f"{name}:{mode}") if single_gpu else None
     traffic = pmc.get("traffic_bytes") if pmc else None
     if mode == "fused":
-        fl = load_json(FLOP_FILE).get(name)
+        # (cfg2 + road boundary: the flop count of plain cfg2 -- the static-shape walk adds tests, so the fraction is a lower bound)
+        fl = load_json(FLOP_FILE).get("cfg2" if name == "cfg2rb" else name)
         if fl and kernel_ms > 0:
             flops = float(fl["flops_per_candidate_step"]) * cand_mean * n_steps_plus1
             ach = flops / (kernel_ms * 1e-3) / 1e12
@@ -305,11 +306,12 @@ def side_configs(args, torch, device, skip):
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import RpContext
     out = {}
-    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg3": 0.3, "cfg4": 1.8, "cfg5": 2.9}
-    for name in ("cfg3", "cfg4", "cfg5"):
+    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.3, "cfg4": 1.8, "cfg5": 2.9}
+    # (+ the headline scenario with its road boundary in the obstacle tables: 85 thin rectangles from the lanelet network)
+    for name in ("cfg2rb", "cfg3", "cfg4", "cfg5"):
         if name == skip:
             continue
-        w = W.WORKLOADS[name]()
+        w = W.cfg2(road_boundary=True) if name == "cfg2rb" else W.WORKLOADS[name]()
         ctx = RpContext(device)
         w.setup(ctx)
         seq = W.replan_sequence(w, 16 if name != "cfg5" else 8, device=device)
@@ -317,7 +319,7 @@ def side_configs(args, torch, device, skip):
         rec = {"workload": f"{w.name}: {w.description}", "horizon_steps": int(w.inputs.params.N)}
         for mode in ("draw", "fused"):
             k = steps_for(guess[name] * (1.0 if mode == "draw" else 0.5), args.steps)
-            rec[mode] = run_record(ctx, w, seq, mode, k, 3, args.min_seconds, torch.cuda.synchronize)
+            rec[mode] = run_record(ctx, w, seq, mode, k, 3, args.min_seconds, torch.cuda.synchronize, name=name)
         ctx.close()
         out[name] = rec
     return out

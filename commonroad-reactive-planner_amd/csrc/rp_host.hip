@@ -1025,9 +1025,13 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
     c->obs.clus = c->d_clus; c->obs.clus_info = c->d_clus_info; c->obs.n_clus = n_clus; c->obs.clus_per = clus_per;
     c->obs.slot = c->d_slot;
-    c->h_sobb = a; c->h_tri = b; c->h_circ = d; c->h_clus_info = ci;
-    c->grid_valid = false;
-    c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0; c->obs.gx0 = c->obs.gy0 = 0.0; c->obs.ginv = 0.0;
+    // (a replanning loop that brings new predictions of the dynamic obstacles every cycle keeps its static shapes: so does the grid)
+    const bool same_static = c->grid_valid && a == c->h_sobb && b == c->h_tri && d == c->h_circ && ci == c->h_clus_info;
+    if (!same_static) {
+        c->h_sobb = a; c->h_tri = b; c->h_circ = d; c->h_clus_info = ci;
+        c->grid_valid = false;
+        c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0; c->obs.gx0 = c->obs.gy0 = 0.0; c->obs.ginv = 0.0;
+    }
     c->have_last = false;
     return RP_OK;
 }
