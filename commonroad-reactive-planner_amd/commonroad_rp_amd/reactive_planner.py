@@ -41,7 +41,8 @@ from .polynomial_trajectory import QuarticTrajectory, QuinticTrajectory
 from .sampling import (FixedIntervalSampling, PositionSampling, SamplingSpace, TimeSampling, VelocitySampling,
                        sampling_space_factory)
 from .state import CustomState, LazyStateList, ReactivePlannerState, Trajectory
-from .trajectories import FeasibilityStatus, TrajectorySample, bind_states, label_from_status
+from .trajectories import (CartesianSample, CurviLinearSample, FeasibilityStatus, TrajectorySample, bind_states,
+                           label_from_status)
 
 logger = logging.getLogger("RP_LOGGER")
 
@@ -145,6 +146,8 @@ class _WinnerSample(TrajectorySample):
     def __init__(self, horizon, dt, make_polys):
         self._make_polys = make_polys
         self._polys = None
+        self._samples = None       # (CartesianSample, CurviLinearSample) once somebody reads them, or what a caller assigned
+        self._state_block = None   # the [14, N + 1] block the two samples are views of (bind_block)
         super().__init__(horizon, dt, None, None)
 
     def _get(self, k):
@@ -154,6 +157,35 @@ class _WinnerSample(TrajectorySample):
 
     trajectory_long = property(lambda self: self._get(0), lambda self, v: None)
     trajectory_lat = property(lambda self: self._get(1), lambda self, v: None)
+
+    # the two sample containers are built from the state block when somebody reads them: plan() packs its output straight from
+    # the block (_compute_trajectory_pair), and two container objects per replanning cycle were ~4 us of its Python time
+    def bind_block(self, block, cost):
+        self._state_block, self._samples = block, None
+        self.feasibility_label = FeasibilityStatus.FEASIBLE
+        self._cost = cost
+
+    def _sample(self, k):
+        if self._samples is None:
+            if self._state_block is None:
+                return None
+            blk = self._state_block
+            n = blk.shape[1]
+            x, y, theta, v, a, kappa, kappa_dot, s, d, theta_cl, s_dot, s_ddot, d_dot, d_ddot = blk
+            self._samples = [CartesianSample(x, y, theta, v, a, kappa, kappa_dot, current_time_step=n),
+                             CurviLinearSample(s, d, theta_cl, dd=d_dot, ddd=d_ddot, ss=s_dot, sss=s_ddot, current_time_step=n)]
+        return self._samples[k]
+
+    def _set_sample(self, k, value):
+        if value is None and self._samples is None:
+            return                       # (TrajectorySample.__init__ assigns None)
+        if self._samples is None:
+            self._samples = [self._sample(0), self._sample(1)] if self._state_block is not None else [None, None]
+        self._samples[k] = value
+        self._state_block = None         # a caller replaced a container: the block no longer describes the sample
+
+    cartesian = property(lambda self: self._sample(0), lambda self, v: self._set_sample(0, v))
+    curvilinear = property(lambda self: self._sample(1), lambda self, v: self._set_sample(1, v))
 
 
 _LON_ROWS, _LAT_ROWS = [7, 10, 11], [8, 12, 13]   # rows of a state block (include/rp_amd.h: RP_S, RP_S_DOT, RP_S_DDOT | RP_D, ...)
@@ -257,8 +289,11 @@ class GpuBackendMixin:
                             constraint_mask=mask, flags=0, x0_lon=(0.0, 0.0, 0.0), x0_lat=(0.0, 0.0, 0.0), x0_orientation=0.0,
                             wheelbase=vp.wheelbase, wb_rear_axle=vp.wb_rear_axle, length=vp.length, width=vp.width,
                             a_max=vp.a_max, v_switch=vp.v_switch, delta_max=vp.delta_max, v_delta_max=vp.v_delta_max)
-            cached = self._rp_params_cache = (key, p)
-        p = _capi.copy_params(cached[1])     # (a fresh struct per call: callers may keep the inputs of a plan)
+            cached = self._rp_params_cache = (key, p, [_capi.copy_params(p), _capi.copy_params(p)], [0])
+        # two structs used in turn (a copy per call costs ~1.5 us): the inputs of the previous plan stay intact while this one
+        # runs; whoever keeps inputs longer copies them (workloads.replan_sequence does)
+        cached[3][0] ^= 1
+        p = cached[2][cached[3][0]]
         p.time_step0 = int(self.x_0.time_step)
         p.low_vel_mode = 1 if self._low_vel_mode else 0
         p.flags = flags
@@ -272,8 +307,12 @@ class GpuBackendMixin:
         cf = self.cost_function
         if type(cf) is DefaultCostFunction or type(cf).__name__ == "DefaultCostFunction" and \
                 type(cf).evaluate.__qualname__ == "DefaultCostFunction.evaluate":
-            return make_cost(COST_DEFAULT, w_a=cf.w_a, desired_speed=cf.desired_speed, desired_d=cf.desired_d,
-                             desired_s=cf.desired_s)
+            key = (cf.w_a, cf.desired_speed, cf.desired_d, cf.desired_s)   # (the struct is kept while the weights stay)
+            hit = getattr(self, "_rp_cost_cache", None)
+            if hit is None or hit[0] != key:
+                hit = self._rp_cost_cache = (key, make_cost(COST_DEFAULT, w_a=cf.w_a, desired_speed=cf.desired_speed,
+                                                            desired_d=cf.desired_d, desired_s=cf.desired_s))
+            return hit[1]
         if type(cf) is DefaultCostFunctionFailSafe or type(cf).__name__ == "DefaultCostFunctionFailSafe" and \
                 type(cf).evaluate.__qualname__ == "DefaultCostFunctionFailSafe.evaluate":
             return make_cost(COST_FAILSAFE)
@@ -408,6 +447,9 @@ class GpuBackendMixin:
                 t = self._gpu_candidate_sample(b, o.best_index, o.best_lon_coeffs, o.best_lat_coeffs, o.best_lat_T)
                 return t.trajectory_long, t.trajectory_lat
             s = _WinnerSample(self.horizon, self.dt, polys)
+            s.bind_block(out.best_states, out.best_cost)
+            s._cost_function = self.cost_function
+            return s
         bind_states(s, out.best_states, 1, out.best_cost)
         s._cost_function = self.cost_function
         return s
@@ -632,7 +674,8 @@ class ReactivePlanner(GpuBackendMixin):
                 break
             i += 1
 
-        if (optimal is None or optimal.cartesian.v[self._standstill_lookahead] <= 0.05) and self.x_0.velocity <= 0.05:
+        # (reactive_planner.py:641; the cheap operand first: the winner's containers are built on access)
+        if self.x_0.velocity <= 0.05 and (optimal is None or optimal.cartesian.v[self._standstill_lookahead] <= 0.05):
             optimal = self._compute_standstill_trajectory()
             self._optimal_cost = optimal.cost
 
@@ -669,12 +712,19 @@ class ReactivePlanner(GpuBackendMixin):
     def _compute_trajectory_pair(self, trajectory: TrajectorySample):
         """Output packing, reactive_planner.py:514-568: (Cartesian trajectory, curvilinear trajectory, lon list, lat list).
         Same values as the reference's; the two state lists build their state objects on access (``LazyStateList``)."""
-        ca, cu = trajectory.cartesian, trajectory.curvilinear
-        n = len(ca.x)
         t0, factor, dt = self.x_0.time_step, self.config.planning.factor, self.dt
-        theta = np.asarray(ca.theta, dtype=float)
-        kappa = np.asarray(ca.kappa, dtype=float)
-        v, acc = np.asarray(ca.v, dtype=float), np.asarray(ca.a, dtype=float)
+        blk = getattr(trajectory, "_state_block", None)
+        whole = type(trajectory) is _WinnerSample and blk is not None and trajectory._samples is None
+        if whole:   # the winner of this build's own path: everything comes from rows of its [14, N + 1] block
+            n = blk.shape[1]
+            theta, v, acc, kappa = blk[2], blk[3], blk[4], blk[5]
+            ca = cu = None
+        else:
+            ca, cu = trajectory.cartesian, trajectory.curvilinear
+            n = len(ca.x)
+            theta = np.asarray(ca.theta, dtype=float)
+            kappa = np.asarray(ca.kappa, dtype=float)
+            v, acc = np.asarray(ca.v, dtype=float), np.asarray(ca.a, dtype=float)
         yaw = np.empty(n)
         yaw[0] = self.x_0.yaw_rate
         yaw[1:] = (theta[1:] - theta[:-1]) / dt                                   # :531-537
@@ -692,10 +742,11 @@ class ReactivePlanner(GpuBackendMixin):
                 th_c[i] = o
         # the winner's arrays are rows of one [14, N + 1] block (bind_states): positions and the lon / lat lists then come from
         # slices of it instead of column-by-column copies
-        blk = ca.x.base
-        whole = (blk is not None and blk.shape == (14, n) and ca.y.base is blk and cu.s.base is blk and cu.d.base is blk
-                 and cu.s_dot.base is blk and cu.s_ddot.base is blk and cu.d_dot.base is blk and cu.d_ddot.base is blk
-                 and getattr(trajectory, "_state_block", None) is blk)
+        if not whole:
+            blk = ca.x.base
+            whole = (blk is not None and blk.shape == (14, n) and ca.y.base is blk and cu.s.base is blk and cu.d.base is blk
+                     and cu.s_dot.base is blk and cu.s_ddot.base is blk and cu.d_dot.base is blk and cu.d_ddot.base is blk
+                     and getattr(trajectory, "_state_block", None) is blk)
         if whole:
             pos, sd = blk[0:2].T.copy(), blk[7:9].T.copy()          # rows x, y | s, d
         else:

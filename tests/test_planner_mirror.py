@@ -68,7 +68,9 @@ def test_output_packing_paths_agree():
     rp._compute_trajectory_pair = spy
     fast = rp.plan()
     t = seen["t"]
-    assert t._state_block is not None and t.cartesian.x.base is t._state_block   # the fast path was taken
+    assert t._state_block is not None and t._samples is None                     # the fast path was taken: no container was built
+    blk = t._state_block
+    assert t.cartesian.x.base is blk and t.curvilinear.d_ddot.base is blk        # containers on access: views of the block
     t._state_block = None                                                        # force the column-by-column path
     slow = orig(t)
     assert fast[2] == slow[2] and fast[3] == slow[3]
