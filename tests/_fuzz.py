@@ -148,9 +148,12 @@ def compare(ctx, seed):
         if not np.array_equal(out.reason_counts[:7], ro.reason_counts[:7]):
             problems.append(f"{variant}: reason counters {out.reason_counts[:7]} want {ro.reason_counts[:7]}")
         if out.best_index >= 0 and ro.best_index == out.best_index and out.best_states is not None:
-            dev = np.max(np.abs(out.best_states - ro.best_states))
+            # 1e-6 absolute (the contract), relative above magnitude 1 -- as for the materialised blocks below: with the checks
+            # that would reject them masked out, a winner can carry a curvature of -3.5e3 1/m or a d'' of -6.6e5 over a speed of
+            # 1e-4 m/s, where 1e-5 absolute is 1e-9 .. 1e-11 relative (seeds 28063, 28615: profiles/r02_fuzz_parity.txt)
+            dev = np.max(np.abs(out.best_states - ro.best_states) / np.maximum(1.0, np.abs(ro.best_states)))
             if not dev <= 1e-6:
-                problems.append(f"{variant}: winner states deviate {dev:.3g}")
+                problems.append(f"{variant}: winner states deviate {dev:.3g} (relative above 1)")
         if variant == "materialize":
             states = ctx.fetch_states()
             have = ((rs & 3) == 1) | ((rs & 3) == 3) | (bool(info["draw"]) & ((rs & 3) == 2))
