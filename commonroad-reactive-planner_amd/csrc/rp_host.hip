@@ -270,10 +270,13 @@ inline bool stage_out_applies(const KArgs &ka, int G, bool mat) {
 }
 
 // Doubles between two rows of a state block in device memory.  Rows stored directly (every variant but STAGE_OUT) start on
-// 64-byte lines: N + 1 rounded up to a multiple of 8 (rp_fetch_states hands out compact [14][N + 1] blocks either way).
+// 128-byte lines -- the line size of the L2: N + 1 rounded up to a multiple of 16, so that the 128-byte run of a group of 16
+// lanes never straddles two lines (a multiple of 8 only: 200 000 candidates at N = 100 38 % of the HBM peak instead of 55 %).
+// rp_fetch_states hands out compact [14][N + 1] blocks either way.
 inline int state_row_stride(int n, bool staged) {
     if (staged || std::getenv("RP_AMD_NO_ROW_PADDING")) return n;
-    return (n + 7) & ~7;
+    if (const char *e = std::getenv("RP_AMD_ROW_ALIGN")) { const int al = std::atoi(e); if (al == 8 || al == 16) return (n + al - 1) & ~(al - 1); }
+    return (n + 15) & ~15;
 }
 
 template <int G, bool MAT, bool CIN, int COLL>
@@ -307,10 +310,14 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
     // every wavefront has a SIMD to itself either way and one step block of 32 lanes is the shorter chain
     // (profiles/probe_small_n20.py: 120 candidates 28.8 vs 31.5 us per step, 630: 29.6 vs 32.2, 3 060: equal, 7 440: 41 vs 32)
     if (N + 1 <= 32) return (N + 1 > 16 && count <= (int64_t)c->num_cus * 4) ? 32 : 16;
-    // up to 64 steps (the reference's default horizon, N = 60): one wavefront per candidate as long as that is at most
-    // ~4 wavefronts per SIMD; beyond, and while the single-launch variant still applies, 16 lanes (4 candidates per
-    // wavefront, 4 step blocks) are 10 % faster (6 000 candidates: 68 vs 75 us per step; 2 600: equal; 400: 43 vs 60)
-    if (N + 1 <= 64 && count > (int64_t)c->num_cus * 16 && count <= (int64_t)fused_lon_max_blocks(c) * (RP_BLOCK / kFusedLonG)) return 16;
+    // longer horizons: one wavefront per candidate for the small batches (at most ~4 wavefronts per SIMD; up to 64 steps that is
+    // the single-launch variant with one step block: 400 candidates 36 vs 43 us per step, 2 600: equal), 16 lanes beyond -- 4
+    // candidates per wavefront, rows stored straight to memory in 128-byte runs on 128-byte lines (state_row_stride).  Round 1
+    // had one wavefront per candidate + LDS-staged linear copy-out for the large batches: with rows that start on line boundaries
+    // the direct stores win at every horizon measured (profiles/r02_lanes_per_candidate.txt: cfg3 0.210 -> 0.155 ms, cfg4
+    // 1.586 -> 1.487 ms, cfg5 2.738 -> 2.513 ms; 200 000 candidates without obstacles, N = 40 .. 100: 44-56 % of the HBM peak
+    // against 30-50 %)
+    if (count > (int64_t)c->num_cus * 16) return 16;
     return 64;
 }
 
@@ -511,8 +518,6 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         if (c->last_G) G = c->last_G;
     } else {
         if (!std::getenv("RP_AMD_NO_FUSED_LON")) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
-        // (16 lanes per candidate for mid-size batches of up to 64 steps only pay in the single-launch variant)
-        if (G == 16 && mat && ka.N + 1 > 32 && !fused_lds && !std::getenv("RP_AMD_G")) G = 64;
     }
     ka.lds_pairs = fused_pairs;
     if (!skip_eval) {
@@ -1081,7 +1086,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
 
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)count)) != RP_OK) return rc;
-    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)count * RP_N_ARRAYS * (size_t)((n + 15) & ~15))) != RP_OK) return rc;
 
     KArgs ka;
     {   // (the grid over the static shapes belongs to the ego rectangle of the plan; fill_common copies its descriptor)
@@ -1136,7 +1141,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)C)) != RP_OK) return rc;
-    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)((n + 7) & ~7))) != RP_OK) return rc;
+    if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)((n + 15) & ~15))) != RP_OK) return rc;
     KArgs ka;
     {   // (the grid over the static shapes belongs to the ego rectangle of the plan; fill_common copies its descriptor)
         const int grc = ensure_static_grid(c, std::sqrt(0.25 * p->length * p->length + 0.25 * p->width * p->width));
