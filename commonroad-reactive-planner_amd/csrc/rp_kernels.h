@@ -868,11 +868,13 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsG ag) {
 // batch then do not sit dirty in the L2s until the end-of-kernel write-back: measured 23.2 -> 21.8 us on cfg2
 // (profiles/r01_dead_ends.txt also records what did NOT pay: running the selection epilogue in the last workgroup on
 // top of such stores).
-template <bool WT>
+template <bool WT, bool NT = false>
 __device__ __forceinline__ void st_row(double *p, double v) {
     if (WT) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;   // (non-temporal stores of these partial-line runs measured 1.3-2.6x slower: no write combining)
+    else if (NT) __builtin_nontemporal_store(v, p);   // large batches: whole 128-byte lines, written once, never read by a kernel
+                                                      // (cfg5 2.53 -> 2.33 ms; on partial-line runs they measured 1.3-2.6x slower)
+    else *p = v;
 }
 
 // one step of a longitudinal profile in registers
@@ -977,6 +979,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
     constexpr bool RP_WT = LON_FUSED && RP_WRITE_THROUGH;
+    constexpr bool RP_NT = MAT && !LON_FUSED && !STAGE_OUT;   // rows of the two-kernel path stored straight to memory: streaming stores
     touch_kernargs<10>();
 
     const int tid = threadIdx.x;
@@ -1409,12 +1412,12 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 // 32-byte sector that holds the last valid step was written twice (+ 24 B per row on cfg2, PMC WRITE_SIZE).
                 if (!LATE_STORE && store_ok && act) {   // curvilinear rows of valid steps are final here
                     const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                    st_row<RP_WT>(row_at(off8, RP_S), s);
-                    st_row<RP_WT>(row_at(off8, RP_S_DOT), sd);
-                    st_row<RP_WT>(row_at(off8, RP_S_DDOT), sdd);
-                    st_row<RP_WT>(row_at(off8, RP_D), d);
-                    st_row<RP_WT>(row_at(off8, RP_D_DOT), dd);
-                    st_row<RP_WT>(row_at(off8, RP_D_DDOT), ddd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S), s);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DOT), sd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DDOT), sdd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D), d);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DOT), dd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DDOT), ddd);
                 }
                 RP_STAMP(3);   // profile loads + polynomial evaluation
 
@@ -1541,14 +1544,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (act) {   // Cartesian rows of valid steps are final here
                     if (!LATE_STORE && store_ok) {
                         const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                        st_row<RP_WT>(row_at(off8, RP_X), x);
-                        st_row<RP_WT>(row_at(off8, RP_Y), y);
-                        st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
-                        st_row<RP_WT>(row_at(off8, RP_V), v);
-                        st_row<RP_WT>(row_at(off8, RP_A), acc);
-                        st_row<RP_WT>(row_at(off8, RP_KAPPA), kappa);
-                        st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), kdot);
-                        st_row<RP_WT>(row_at(off8, RP_THETA_CL), th_cl);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_X), x);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_Y), y);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA), th_gl);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_V), v);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_A), acc);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA), kappa);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA_DOT), kdot);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA_CL), th_cl);
                     }
                     cost_acc += cost_terms(i, acc, v, s, d, th_cl);
                 }
@@ -1610,20 +1613,20 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                         } else if (store_ok && live) {
                             {
                                 const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                                st_row<RP_WT>(row_at(off8, RP_X), x);
-                                st_row<RP_WT>(row_at(off8, RP_Y), y);
-                                st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
-                                st_row<RP_WT>(row_at(off8, RP_V), vt);
-                                st_row<RP_WT>(row_at(off8, RP_A), o[4]);            // :179
-                                st_row<RP_WT>(row_at(off8, RP_KAPPA), o[5]);        // :190
-                                st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), o[6]);    // :192
-                                st_row<RP_WT>(row_at(off8, RP_S), e_s);
-                                st_row<RP_WT>(row_at(off8, RP_D), e_d);
-                                st_row<RP_WT>(row_at(off8, RP_THETA_CL), o[9]);     // :327
-                                st_row<RP_WT>(row_at(off8, RP_S_DOT), e_sd);
-                                st_row<RP_WT>(row_at(off8, RP_S_DDOT), o[11]);      // :323
-                                st_row<RP_WT>(row_at(off8, RP_D_DOT), e_dd);
-                                st_row<RP_WT>(row_at(off8, RP_D_DDOT), o[13]);      // :324
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_X), x);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_Y), y);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA), th_gl);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_V), vt);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_A), o[4]);            // :179
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA), o[5]);        // :190
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA_DOT), o[6]);    // :192
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_S), e_s);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_D), e_d);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA_CL), o[9]);     // :327
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DOT), e_sd);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DDOT), o[11]);      // :323
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DOT), e_dd);
+                                st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DDOT), o[13]);      // :324
                             }
                         }
                     }
@@ -1645,20 +1648,20 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 if (LATE_STORE && store_ok && i < ns) {   // (whole 128-byte lines: completing only the 64-byte half that holds step N
                                                           //  costs 15-20 % on the large batches -- cfg5 2.96 vs 2.51 ms)
                     const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                    st_row<RP_WT>(row_at(off8, RP_X), x);
-                    st_row<RP_WT>(row_at(off8, RP_Y), y);
-                    st_row<RP_WT>(row_at(off8, RP_THETA), th_gl);
-                    st_row<RP_WT>(row_at(off8, RP_V), v);
-                    st_row<RP_WT>(row_at(off8, RP_A), acc);
-                    st_row<RP_WT>(row_at(off8, RP_KAPPA), kappa);
-                    st_row<RP_WT>(row_at(off8, RP_KAPPA_DOT), kdot);
-                    st_row<RP_WT>(row_at(off8, RP_S), s);
-                    st_row<RP_WT>(row_at(off8, RP_D), d);
-                    st_row<RP_WT>(row_at(off8, RP_THETA_CL), th_cl);
-                    st_row<RP_WT>(row_at(off8, RP_S_DOT), sd);
-                    st_row<RP_WT>(row_at(off8, RP_S_DDOT), sdd);
-                    st_row<RP_WT>(row_at(off8, RP_D_DOT), dd);
-                    st_row<RP_WT>(row_at(off8, RP_D_DDOT), ddd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_X), x);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_Y), y);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA), th_gl);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_V), v);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_A), acc);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA), kappa);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA_DOT), kdot);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S), s);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D), d);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA_CL), th_cl);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DOT), sd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DDOT), sdd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DOT), dd);
+                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DDOT), ddd);
                 }
                 RP_STAMP(9);   // extension + scans + stores of the step block
 
