@@ -1499,11 +1499,11 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                     const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
                     const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
                     const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
-                    reason = ((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc ? RP_REASON_ACCELERATION : reason;
-                    reason = ((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd ? RP_REASON_KAPPA_DOT : reason;
-                    reason = ((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw ? RP_REASON_YAW_RATE : reason;
-                    reason = ((cm & RP_CHECK_KAPPA) != 0) & bad_k ? RP_REASON_KAPPA : reason;
-                    reason = ((cm & RP_CHECK_VELOCITY) != 0) & bad_v ? RP_REASON_VELOCITY : reason;
+                    reason = (((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc) ? RP_REASON_ACCELERATION : reason;
+                    reason = (((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd) ? RP_REASON_KAPPA_DOT : reason;
+                    reason = (((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw) ? RP_REASON_YAW_RATE : reason;
+                    reason = (((cm & RP_CHECK_KAPPA) != 0) & bad_k) ? RP_REASON_KAPPA : reason;
+                    reason = (((cm & RP_CHECK_VELOCITY) != 0) & bad_v) ? RP_REASON_VELOCITY : reason;
                     reason = act ? reason : RP_REASON_NONE;
                 }
 #else
