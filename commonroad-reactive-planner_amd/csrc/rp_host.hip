@@ -1185,17 +1185,23 @@ int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
         HIP_TRY(c, hipMemcpy(states, c->d_states + blk * first, sizeof(double) * blk * count, hipMemcpyDeviceToHost));
         return RP_OK;
     }
-    // padded rows: compact on the device (a copy at memory speed), then one linear transfer
+    // padded rows: compact on the device (a copy at memory speed), then a linear transfer -- in pieces of at most 256 MB, so that
+    // fetching every block of a 10^6-candidate batch does not need a second 11-GB buffer
+    const int64_t piece = std::max<int64_t>(1, (int64_t)((256u << 20) / (blk * sizeof(double))));
     int rc;
-    if ((rc = grow(c, c->d_compact, c->cap_compact, blk * (size_t)count)) != RP_OK) return rc;
-    const size_t total = blk * (size_t)count;
-    const int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)c->num_cus * 16);
-    hipLaunchKernelGGL(rp_compact_rows_kernel, dim3(grid), dim3(256), 0, c->stream,
-                       c->d_states + (size_t)RP_N_ARRAYS * (size_t)ns * (size_t)first, c->d_compact, n, ns,
-                       (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u, (unsigned long long)total);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(states, c->d_compact, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = grow(c, c->d_compact, c->cap_compact, blk * (size_t)std::min<int64_t>(piece, count))) != RP_OK) return rc;
+    const uint32_t inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
+    for (int64_t at = 0; at < count; at += piece) {
+        const int64_t cnt = std::min<int64_t>(piece, count - at);
+        const size_t total = blk * (size_t)cnt;
+        const int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)c->num_cus * 16);
+        hipLaunchKernelGGL(rp_compact_rows_kernel, dim3(grid), dim3(256), 0, c->stream,
+                           c->d_states + (size_t)RP_N_ARRAYS * (size_t)ns * (size_t)(first + at), c->d_compact, n, ns, inv_n,
+                           (unsigned long long)total);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(states + blk * (size_t)at, c->d_compact, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));   // (the piece buffer is reused)
+    }
     return RP_OK;
 }
 

@@ -595,3 +595,28 @@ def test_cost_range_entry(ctx, name):
     cmin, cmax, n = ctx.cost_range()
     if have.any():
         assert (cmin, cmax, n) == (user[have].min(), user[have].max(), int(have.sum()))
+
+
+def test_fetch_states_in_pieces(ctx):
+    """rp_fetch_states of padded rows compacts on the device in pieces of at most 256 MB: every block of cfg3 in draw mode
+    (427 MB: two pieces; the boundary lies at candidate 39 291), compared with the oracle around the boundary and at both ends."""
+    from oracle import oracle
+    from commonroad_rp_amd import workloads as W
+    w = W.cfg3()
+    w.setup(ctx)
+    tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+    inp = _with_flags(w.inputs, FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL)
+    ctx.plan(inp)
+    states = ctx.fetch_states()
+    C = inp.n_candidates
+    assert states.shape == (C, 14, inp.params.N + 1)
+    piece = (256 << 20) // (14 * (inp.params.N + 1) * 8)
+    compared = 0
+    for lo, hi in ((0, 64), (piece - 64, piece + 64), (C - 64, C)):
+        ref = oracle.plan(inp, tb, lo, hi, want_states=True)
+        keep = ((ref.status & 3) == 1) | ((ref.status & 3) == 3)      # blocks the reference keeps whole
+        np.testing.assert_allclose(states[lo:hi][keep], ref.states[keep], rtol=0, atol=STATE_ATOL)
+        compared += int(keep.sum())
+    assert compared > 0
+    part = ctx.fetch_states(piece - 3, 6)                             # a range that starts inside one piece of the whole
+    np.testing.assert_array_equal(part, states[piece - 3:piece + 3])
