@@ -788,6 +788,9 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
             const gcdouble dyn = (gcdouble)ob.dyn;
             const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
             m = 0;
+            // (eight obstacles' circles requested before the first is tested: the loop is a chain of memory round trips otherwise --
+            //  51 obstacles of cfg3: 28 us for a kernel that has 2 us of arithmetic)
+#pragma unroll 8
             for (int j = 0; j < ob.n_dyn; ++j) {
                 const gcdouble o = dyn + (size_t)j * ob.n_steps + k;
                 const double dx = o[0] - cx, dy = o[plane] - cy, rr = R + o[6 * plane];   // NaN centre: absent, no bit
