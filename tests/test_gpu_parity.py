@@ -620,3 +620,41 @@ def test_fetch_states_in_pieces(ctx):
     assert compared > 0
     part = ctx.fetch_states(piece - 3, 6)                             # a range that starts inside one piece of the whole
     np.testing.assert_array_equal(part, states[piece - 3:piece + 3])
+
+
+def test_static_grid_follows_vehicle_and_tables(ctx):
+    """The grid over the static shapes is built for the ego rectangle of the plan and kept while the static shapes stay
+    (csrc/rp_host.hip: ensure_static_grid): a larger vehicle after a smaller one rebuilds it, a smaller one after a larger one
+    reuses it (conservative), new dynamic obstacles with the same static shapes keep it, new static shapes replace it."""
+    from oracle import oracle
+    from commonroad_rp_amd.collision import ObstacleTables
+    s = np.arange(0.0, 300.0, 1.0)
+    path = np.stack((s, 18.0 * np.sin(s / 45.0)), axis=1)
+    co, inp = _synthetic_case(path, N=30)
+    rng = np.random.default_rng(21)
+
+    def boxes(n):
+        out = []
+        for _ in range(n):
+            x, y = co.convert_to_cartesian_coords(rng.uniform(60.0, 200.0), rng.choice([-1, 1]) * rng.uniform(1.8, 4.5))
+            out.append([x, y, rng.uniform(-3, 3), rng.uniform(0.3, 1.5), rng.uniform(0.05, 0.6)])
+        return out
+    static_a, static_b = boxes(40), boxes(26)
+    dyn1, dyn2 = _dense_traffic(co, 1, 40, seed=5), _dense_traffic(co, 2, 40, seed=6)
+    ctx.set_coordinate_system(co)
+    hits = []
+    for length, width, static, dyn in ((2.0, 1.0, static_a, dyn1), (6.0, 2.5, static_a, dyn1), (3.0, 1.5, static_a, dyn2),
+                                       (4.5, 1.8, static_b, dyn2), (4.5, 1.8, static_a, dyn1)):
+        tables = ObstacleTables(static_obb=static, dyn_obb=dyn, dyn_t0=0)
+        ctx.set_obstacles(tables)
+        tb = oracle.OracleTables.from_coordinate_system(co, tables)
+        p = copy_params(inp.params)
+        p.length, p.width = length, width
+        i2 = PlanInputs(p, inp.cost, inp.T, inp.traj_len, inp.L, inp.D)
+        orun = oracle.plan(i2, tb)
+        out = ctx.plan(i2)
+        status, cost = ctx.fetch_status()
+        _compare_status(status, cost, orun)
+        assert out.n_collision == orun.out.n_collision and out.best_index == orun.out.best_index
+        hits.append(orun.out.n_collision)
+    assert max(hits) > 0 and len(set(hits)) > 1
