@@ -1,5 +1,5 @@
 """Randomised differential cases for the HIP path against the CPU oracle (used by tests/test_fuzz_parity.py and by the
-sweep script profiles/fuzz_parity.py).  Random smooth reference paths, initial states (moving, slow, standstill), horizons,
+sweep script tests/sweeps/fuzz_parity.py).  Random smooth reference paths, initial states (moving, slow, standstill), horizons,
 grids in arbitrary order, obstacle sets of every kind, modes (velocity keeping / stopping, low velocity, draw), constraint
 subsets, planning.factor, sharded ranges.  Per case: labels / reasons / failing step / winner / counters exact, costs 1e-8
 relative (sums of squares of whatever a relaxed constraint mask lets through), states 1e-6."""

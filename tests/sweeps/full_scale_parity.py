@@ -1,7 +1,7 @@
 """One-off validation: labels / first-failure reasons / winner of the FULL benchmark workloads against the oracle's
-brute force (the unit tests check slices).  usage (GPU box): python profiles/full_scale_parity.py"""
+brute force (the unit tests check slices).  usage (GPU box): python tests/sweeps/full_scale_parity.py"""
 import sys, os, time, numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")]
 from commonroad_rp_amd import workloads as W
 from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL

@@ -1,7 +1,7 @@
 """Sweep of the randomised differential test (tests/_fuzz.py) over many seeds.
-usage (GPU box): python profiles/fuzz_parity.py [first_seed] [n_cases] [seed,seed,...]"""
+usage (GPU box): python tests/sweeps/fuzz_parity.py [first_seed] [n_cases] [seed,seed,...]"""
 import os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), os.path.join(REPO, "tests")]
 from commonroad_rp_amd._capi import RpContext
 from _fuzz import compare

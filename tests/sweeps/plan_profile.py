@@ -1,12 +1,12 @@
 """Python time of ReactivePlanner.plan() around the device call: the planner of a workload with a canned backend (the first
-oracle result replayed), so that what is measured is the host glue alone.  usage: python profiles/plan_profile.py [cfg2] [--profile]"""
+oracle result replayed), so that what is measured is the host glue alone.  usage: python tests/sweeps/plan_profile.py [cfg2] [--profile]"""
 import cProfile
 import os
 import pstats
 import sys
 import time
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), os.path.join(REPO, "tests")]
 import numpy as np  # noqa: E402
 from commonroad_rp_amd import workloads as W  # noqa: E402

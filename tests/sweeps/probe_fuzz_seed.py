@@ -1,8 +1,8 @@
 """Detail of one seed of the randomised differential test: which rows / steps of the winner's state block deviate.
-usage (GPU box): python profiles/probe_fuzz_seed.py 28615"""
+usage (GPU box): python tests/sweeps/probe_fuzz_seed.py 28615"""
 import os, sys
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), os.path.join(REPO, "tests")]
 from commonroad_rp_amd._capi import RpContext, ARRAY_NAMES
 from _fuzz import random_case
