@@ -8,6 +8,7 @@
 // on the context's stream; the result block arrives in pinned host memory straight from the kernels.  No torch types, no exceptions
 // across the ABI, no CPU fallback: if HIP fails the call returns RP_EHIP.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -44,6 +45,7 @@ struct rp_ctx {
     int profiling = 0;            // 0 off, k > 0: time the evaluation kernel of every k-th rp_plan with HIP events
     unsigned long long calls = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool time_next_launch = false, timed_by_launch = false;   // profiling: the next launch_block carries ev0 / ev1 | it did
 
     // reference tables
     double *d_tables = nullptr;
@@ -188,6 +190,15 @@ void launch_block(rp_ctx *c, const void *kernel, int grid, int block, size_t lds
         f = it->second;
     }
     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void *>(args_block), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    if (c->time_next_launch) {   // profiling: this launch carries the two events itself -- they take the kernel's own begin / end
+        c->time_next_launch = false;   // time stamps instead of bracketing it with two more commands on the stream
+        if (f && hipExtModuleLaunchKernel(f, (uint32_t)grid * (uint32_t)block, 1, 1, (uint32_t)block, 1, 1, lds, c->stream, nullptr, extra,
+                                          c->ev0, c->ev1, 0) == hipSuccess) {
+            c->timed_by_launch = true;
+            return;
+        }
+        (void)hipGetLastError();
+    }
     if (!f || hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, c->stream, nullptr, extra) != hipSuccess) {
         (void)hipGetLastError();
         void *args[] = {const_cast<void *>(args_block)};
@@ -548,6 +559,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     // (A selection epilogue run by the evaluation kernel's last workgroup was tried and measured slower -- cfg2: eval
     //  21.6 -> 37.8 us: every workgroup then pays an agent-scope release fence, an L2 write-back, before its ticket.)
     const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
+    bool time_valid = false;
     const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (!skip_eval) {
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
@@ -563,14 +575,21 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             ka.pair_hdr = c->d_pair_hdr;
             launch_lon(c, ka, cin);
         }
-        if (timed) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        // the evaluation kernel's duration: events attached to the launch itself (hipExtModuleLaunchKernel; RP_AMD_EVENT_BRACKET=1:
+        // two hipEventRecord around it, which adds the dispatch and completion handling of the bracket -- ~2.5 us on a 14-us kernel)
+        const bool by_launch = timed && count > 0 && !std::getenv("RP_AMD_EVENT_BRACKET");
+        c->timed_by_launch = false;
+        c->time_next_launch = by_launch;
+        if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         if (count > 0) {
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds, G);
             else launch_eval(c, ka, grid, mat, cin, G);
             if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
         }
-        if (timed) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        c->time_next_launch = false;
+        if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        time_valid = timed && (!by_launch || c->timed_by_launch);   // (a launch that could not carry the events: no duration this step)
         if (count == 0) n_partials = 0;
     } else {
         n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
@@ -699,7 +718,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         }
     }
     result->kernel_ms = 0.0;
-    if (timed) {
+    if (time_valid) {
         float ms = 0.f;
         hipError_t e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
         if (e == hipErrorNotReady) {   // ticket arrived ahead of the driver's bookkeeping
