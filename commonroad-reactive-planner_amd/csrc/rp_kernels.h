@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 // Loads and stores share one in-order counter (vmcnt): a load that is waited for behind the write-through stores
                 // of the rows is waited for together with their acknowledgements from memory (6 000 cycles per step block, measured).
                 uint64_t near_sta_cell = 0;
-                const bool cell_wanted = COLL == 2 && live && alive && fail_step < 0 && ood_step < 0;
+                const bool cell_wanted = COLL == 2 && live && alive && fail_step < 0 && ood_step < 0 && !collide;
                 if (cell_wanted && act)
                     near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
                                                      x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
@@ -1670,7 +1670,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
 
                 // -- eager collision query for every pose, reactive_planner.py:1033-1046
                 if (COLL) {
-                    const bool want = live && alive && fail_step < 0 && ood_step < 0;
+                    // (a candidate that has collided in an earlier step block is not asked again: the label is all the reference keeps
+                    //  of a collision, and the kinematic checks -- which can still turn it into INFEASIBLE_KINEMATIC -- go on)
+                    const bool want = live && alive && fail_step < 0 && ood_step < 0 && !collide;
                     bool hit = false;
                     // With the broad-phase masks of the (pair, step) profile a pose whose masks are empty has nothing to be
                     // tested against: the whole query (sin / cos of the heading, ego rectangle, walks) is skipped unless some
