@@ -774,13 +774,26 @@ __device__ __forceinline__ bool static_shape_near(const ObsTables &ob, int kind,
 }
 
 // f[PF_NEAR], f[PF_NEAR_S] of step i
+// `last`: the profile fields of the pair's last valid step L - 1 when the caller has them (rp_lon_kernel: handed on from the
+// lane that worked that step out); else they are worked out again for every extended step (lon_step is ~450 instructions).
 template <bool COEFFS_IN>
-__device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, double *f) {
+__device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, double *f,
+                                               const double *last = nullptr) {
     f[PF_NEAR] = f[PF_NEAR_S] = mask_as_double(0);
     if (COEFFS_IN || !a.use_near_mask || !a.has_obstacles) return;   // masks unused: every shape is tested
     const ObsTables &ob = a.obs;
     double cx = 0.0, cy = 0.0, R = 0.0;
-    const bool bounded = pair_step_bound_fields<COEFFS_IN>(a, rt, lp, i, f, cx, cy, R);
+    bool bounded;
+    if (last != nullptr && i >= lp.L) {
+        BoundIn in;
+        in.L = lp.L; in.T = lp.T; in.lat_T = lp.lat_T; in.s0 = lp.lon.c0;
+        in.s_i = f[PF_S]; in.px_i = f[PF_PX]; in.py_i = f[PF_PY];
+        in.sd1 = last[PF_SD]; in.sdd1 = last[PF_SDD]; in.kr1 = last[PF_KR]; in.krd1 = last[PF_KRD];
+        in.px1 = last[PF_PX]; in.py1 = last[PF_PY]; in.cs1 = last[PF_COS_REF]; in.sn1 = last[PF_SIN_REF]; in.inv_sd1 = last[PF_INV_SD];
+        bounded = pair_step_bound(a, i, in, cx, cy, R);
+    } else {
+        bounded = pair_step_bound_fields<COEFFS_IN>(a, rt, lp, i, f, cx, cy, R);
+    }
     const int k = a.time_step0 + i * a.factor - ob.dyn_t0;
     if (ob.n_dyn > 0 && k >= 0 && k < ob.n_steps) {   // (outside: no dynamic obstacle exists at this scenario step)
         uint64_t m = ~0ull;
@@ -840,12 +853,26 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsG ag) {
         const int L = lp.L;
         double *const prow = a.profile + ((size_t)slot * PF_FIELDS) * (size_t)n;
         bool bad_a = false, bad_v = false;
+        // fields of the last valid step L - 1 that the bound of the EXTENDED steps needs (pair_step_bound): handed on by the lane
+        // that works that step out, in the step block that holds it -- every later step of the pair lies in this or a later block
+        double last[PF_FIELDS];
+#pragma unroll
+        for (int k = 0; k < PF_FIELDS; ++k) last[k] = 0.0;
+        const bool masks = !COEFFS_IN && a.use_near_mask && a.has_obstacles;
 #pragma nounroll
         for (int c = 0; c < nchunks; ++c) {
             const int i = c * G + gl;
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
-            if (i <= N) near_mask_step<COEFFS_IN>(a, rt, lp, i, f);
+            if (masks && L - 1 >= c * G && L - 1 < c * G + G) {   // (group-uniform: all lanes of a group share the pair)
+                const int src = L - 1 - c * G;
+                last[PF_SD] = group_bcast<G>(f[PF_SD], src); last[PF_SDD] = group_bcast<G>(f[PF_SDD], src);
+                last[PF_KR] = group_bcast<G>(f[PF_KR], src); last[PF_KRD] = group_bcast<G>(f[PF_KRD], src);
+                last[PF_PX] = group_bcast<G>(f[PF_PX], src); last[PF_PY] = group_bcast<G>(f[PF_PY], src);
+                last[PF_COS_REF] = group_bcast<G>(f[PF_COS_REF], src); last[PF_SIN_REF] = group_bcast<G>(f[PF_SIN_REF], src);
+                last[PF_INV_SD] = group_bcast<G>(f[PF_INV_SD], src);
+            }
+            if (i <= N) near_mask_step<COEFFS_IN>(a, rt, lp, i, f, (masks && L >= 1) ? last : nullptr);
             else f[PF_NEAR] = f[PF_NEAR_S] = 0.0;
             bad_a |= (i < L) && (fabs(f[PF_SDD]) > a.a_max);   // pre-filter, :798
             bad_v |= (i < L) && (f[PF_SD] < -RP_EPS);          // pre-filter, :802
