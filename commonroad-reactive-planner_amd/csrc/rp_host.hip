@@ -638,7 +638,10 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
         if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds, G);
-        else launch_eval(c, kw, 1, true, cin, G);
+        // (two-kernel path: one candidate is one workgroup whatever the lanes -- a whole wavefront per candidate makes its chain
+        //  of step blocks four times shorter than the batch's 16 lanes: cfg3 19 -> ~10 us.  Nothing was materialised that these
+        //  rows could disagree with in their last bits.)
+        else launch_eval(c, kw, 1, true, cin, std::getenv("RP_AMD_WINNER_G_AS_BATCH") ? G : 64);
     }
     HIP_TRY(c, hipGetLastError());
     const auto tp1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
