@@ -171,6 +171,10 @@ def compare(ctx, seed):
                 infeasible = ((rs[idx] & 3) == 2)[:, None, None]
                 from_failure = np.arange(want.shape[2])[None, None, :] >= (rs[idx] >> 8)[:, None, None]
                 err = np.where(infeasible & from_failure, 0.0, err)
+                # ... and so is a value beyond 1e12 of an infeasible candidate ahead of its failing step when the check that
+                # would have caught it is masked out: an acceleration of -1.6e28 m/s^2 is s'^2 / cos(theta_cl) with the cosine a
+                # rounding residue (theta_cl = +-pi/2 at a standstill start); seeds 44106 and 58603 of a 90 000-seed sweep
+                err = np.where(infeasible & (np.abs(want) > 1e12), 0.0, err)
                 if not np.nanmax(err) <= 1e-6 or np.isnan(err).any():
                     c, r, i = np.unravel_index(np.nanargmax(np.where(np.isnan(err), np.inf, err)), err.shape)
                     problems.append(f"materialize: states deviate {err[c, r, i]:.3g} (relative above 1; candidate {idx[c]} label {rs[idx[c]] & 3} status {rs[idx[c]]:#x} "
