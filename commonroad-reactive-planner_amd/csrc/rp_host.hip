@@ -28,7 +28,7 @@ namespace {
 
 constexpr int kBlocksPerCU = 4;           // workgroups per CU of the grid-stride helper kernels (longitudinal profiles, counts)
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
-constexpr int kFoldThreshold = 2048;
+constexpr int kFoldThreshold = 4096;        // (RP_AMD_FOLD_THRESHOLD overrides; 2 048 -> 4 096: cfg3's 3 906 partials go straight to the epilogue, -5.5 us per step)
 constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass
                                           // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
@@ -601,7 +601,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     }
     {
         const BlockPartial *fin_in = c->d_partials;
-        if (n_partials > kFoldThreshold) {   // one partial per workgroup of a large batch: fold before the one-workgroup epilogue
+        static const int fold_threshold = std::getenv("RP_AMD_FOLD_THRESHOLD") ? std::atoi(std::getenv("RP_AMD_FOLD_THRESHOLD")) : kFoldThreshold;
+        if (n_partials > fold_threshold) {   // one partial per workgroup of a large batch: fold before the one-workgroup epilogue
             BlockPartial *folded = c->d_partials + c->cap_partials;
             hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, n_partials, folded);
             fin_in = folded;
