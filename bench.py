@@ -373,7 +373,9 @@ def corridor_sampling_cost(base, device, reps=15):
     p = base.inputs.params
     sp = CorridorSampling(rp.config)
     sp.samples_t._dict_level_to_sample_set[1] = set(float(t) for t in base.inputs.T)
-    sp.set_dict_number_of_samples(dict_level_to_num_samples={k: 21 for k in range(rp.config.sampling.num_sampling_levels)})
+    # (21 samples per interval at every level; written into the table itself: set_dict_number_of_samples(dict_level_to_num_samples=...)
+    #  only checks the keys, in the reference -- sampling.py:334-338 -- and here)
+    sp._dict_level_to_num_samples = {k: 21 for k in range(rp.config.sampling.num_sampling_levels)}
     s0, v0 = p.x0_lon[0], max(p.x0_lon[1], 1.0)
     cor = {}
     for q in range(p.N + 2):

@@ -241,11 +241,19 @@ class CollectiveExchange:
     ticket the host spins on.  Host path (CPU groups, oracle-backed test contexts, or a plan whose winner rows exist on
     the host only): messages packed on the host, ``all_gather`` of host tensors (through the device for a GPU group)."""
 
-    def __init__(self, dist, device, n: int):
+    def __init__(self, dist, device, n: int, device_path=None):
         import torch
         self.torch = torch
         self.dist, self.device, self.n = dist, device, n
         self.world = dist.get_world_size()
+        # Which path a step takes is decided ONCE, for the whole group: the two paths issue different collectives with
+        # different buffer sizes, so a rank-local choice per step could leave ranks in mismatched collectives.  (The
+        # constructor is collective by contract -- make_exchange.)  A step that cannot take the agreed path raises.
+        want = (device.type != "cpu") if device_path is None else bool(device_path and device.type != "cpu")
+        flag = torch.tensor([1 if want else 0], dtype=torch.int32, device=device)
+        if self.world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        self.device_path = bool(int(flag.item()))
         size = HEAD + N_ARRAYS * n
         pin = device.type != "cpu"
         self.h_send = torch.zeros(size, dtype=torch.float64, pin_memory=pin)
@@ -268,7 +276,13 @@ class CollectiveExchange:
     def __call__(self, ctx, out: PlanOutput) -> PlanOutput:
         dist = self.dist
         glob = owner = None
-        if self.device.type != "cpu" and hasattr(ctx, "result_device") and out.serial and out.serial == getattr(ctx, "_serial", None):
+        if self.device_path:
+            if not (hasattr(ctx, "result_device") and out.serial and out.serial == getattr(ctx, "_serial", None)):
+                raise RuntimeError(
+                    "CollectiveExchange (device path): `out` is not the result of the last call on `ctx` (serial "
+                    f"{out.serial} vs {getattr(ctx, '_serial', None)}) or the context has no device result block; the group "
+                    "agreed on the device path at construction -- exchange right after plan(), or build the exchange with "
+                    "device_path=False on every rank")
             ptr, nbytes, _ = ctx.result_device()
             send, recv = self._device_buffers(ptr, nbytes)
             dist.all_gather_into_tensor(recv, send)

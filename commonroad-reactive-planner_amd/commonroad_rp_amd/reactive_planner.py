@@ -726,8 +726,9 @@ class ReactivePlanner(GpuBackendMixin):
             kappa = np.asarray(ca.kappa, dtype=float)
             v, acc = np.asarray(ca.v, dtype=float), np.asarray(ca.a, dtype=float)
         yaw = np.empty(n)
-        yaw[0] = self.x_0.yaw_rate
+        yaw[0] = 0.0                                                              # (state 0 carries x_0.yaw_rate as it is, None included: cart_state)
         yaw[1:] = (theta[1:] - theta[:-1]) / dt                                   # :531-537
+        yaw0 = self.x_0.yaw_rate
         steer = np.arctan2(self.vehicle_params.wheelbase * kappa, 1.0)            # :539
         # shift_orientation (utility/general.py:49-55) on the Cartesian trajectory only; the curvilinear states keep theta
         lo, hi = self.x_0.orientation - np.pi, self.x_0.orientation + np.pi
@@ -760,7 +761,7 @@ class ReactivePlanner(GpuBackendMixin):
         def cart_state(i):
             st = new_state(RS)
             st.__dict__ = {"time_step": t0 + factor * i, "position": pos[i], "orientation": float(th_c[i]), "velocity": float(v[i]),
-                           "steering_angle": float(steer[i]), "acceleration": float(acc[i]), "yaw_rate": float(yaw[i])}
+                           "steering_angle": float(steer[i]), "acceleration": float(acc[i]), "yaw_rate": float(yaw[i]) if i else yaw0}
             return st
 
         def curv_state(i):

@@ -221,16 +221,19 @@ class CorridorSampling(SamplingSpace):
     samples_v = property(lambda self: None, lambda self, vs: self.__dict__.update(_v_min=getattr(vs, "low", None), _v_max=getattr(vs, "up", None)))
 
     def set_dict_number_of_samples(self, n_min: int = 3, dict_level_to_num_samples: dict = None):
-        """3, 5, 9, ... samples per level, or an explicit table (:327-343)."""
+        """3, 5, 9, ... samples per level (:327-343).  As in the reference, an explicit ``dict_level_to_num_samples`` is only
+        CHECKED for its keys (:334-338) -- it is not stored, the table in place stays (a reference quirk kept on purpose: the
+        candidates of a call must not differ from the reference's)."""
         if dict_level_to_num_samples is not None:
             for level in range(self.num_sampling_levels):
-                assert level in dict_level_to_num_samples, f"<SamplingSpace.set_dict_number_of_samples()>: input dictionary does not contain sampling level: {level}"
-            self._dict_level_to_num_samples = dict(dict_level_to_num_samples)
-            return
-        n = n_min
-        for i in range(self.num_sampling_levels):
-            self._dict_level_to_num_samples[i] = n
-            n = (n * 2) - 1
+                assert level in dict_level_to_num_samples.keys(), f"<SamplingSpace.set_dict_number_of_samples()>:" \
+                                                                  f"input dictionary does not contain sampling level:" \
+                                                                  f"{level}"
+        else:
+            n = n_min
+            for i in range(self.num_sampling_levels):
+                self._dict_level_to_num_samples[i] = n
+                n = (n * 2) - 1
 
     def _end_states(self, level_sampling: int, x_0_lon):
         """(T, lon polynomial, [lateral end positions]) per longitudinal sample, in the reference's iteration order

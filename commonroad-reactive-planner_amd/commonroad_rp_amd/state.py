@@ -53,42 +53,65 @@ class Trajectory:
         self.state_list = state_list
 
 
-class LazyStateList:
-    """The ``state_list`` of a planned trajectory as a read-only sequence whose state objects are built when they are
-    asked for.  The replanning loop reads one or two states of the optimal trajectory per cycle
-    (run_planner.py:81-86,102-107: ``optimal[0].state_list[1 + temp]``); building all 2 (N + 1) objects of both output
-    trajectories on every ``plan()`` was the largest single item of its Python time.  Indexing, slicing, ``len``,
-    iteration, ``list(...)`` and comparison with lists work; a built state is kept, so repeated access returns the
-    same object as a list would."""
+class LazyStateList(list):
+    """The ``state_list`` of a planned trajectory: a ``list`` whose state objects are built when they are asked for.  The
+    replanning loop reads one or two states of the optimal trajectory per cycle (run_planner.py:81-86,102-107:
+    ``optimal[0].state_list[1 + temp]``); building all 2 (N + 1) objects of both output trajectories on every ``plan()`` was the
+    largest single item of its Python time.  It IS a list (``isinstance``, ``+``, ``*``, slicing, pickling -- as a plain list --,
+    ``json``, mutation all work as on the reference's ``state_list``): indexing by an integer builds that one state, any other
+    operation builds the states still missing first and then is the list operation."""
 
-    __slots__ = ("_n", "_make", "_built")
+    __slots__ = ("_make", "_missing")
 
-    def __init__(self, n: int, make):
-        self._n, self._make, self._built = n, make, [None] * n
+    def __init__(self, n: int = 0, make=None):
+        list.__init__(self, [None] * n if make is not None else ())
+        self._make, self._missing = make, (n if make is not None else 0)
 
-    def __len__(self):
-        return self._n
+    def _fill(self):
+        if getattr(self, "_missing", 0):
+            get, put, make = list.__getitem__, list.__setitem__, self._make
+            for k in range(list.__len__(self)):
+                if get(self, k) is None:
+                    put(self, k, make(k))
+            self._missing, self._make = 0, None
+        return self
 
     def __getitem__(self, k):
-        if isinstance(k, slice):
-            return [self[i] for i in range(*k.indices(self._n))]
-        if k < 0:
-            k += self._n
-        if not 0 <= k < self._n:
-            raise IndexError("state index out of range")
-        st = self._built[k]
-        if st is None:
-            st = self._built[k] = self._make(k)
-        return st
+        if getattr(self, "_missing", 0):
+            if isinstance(k, slice):
+                self._fill()
+            else:
+                st = list.__getitem__(self, k)       # (IndexError as a list raises it)
+                if st is None:
+                    st = self._make(k if k >= 0 else k + list.__len__(self))
+                    list.__setitem__(self, k, st)
+                    self._missing -= 1
+                return st
+        return list.__getitem__(self, k)
 
     def __iter__(self):
-        return (self[k] for k in range(self._n))
+        return list.__iter__(self._fill())
 
-    def __eq__(self, other):
-        try:
-            return len(other) == self._n and all(a is b or a == b for a, b in zip(self, other))
-        except TypeError:
-            return NotImplemented
+    def __reduce_ex__(self, protocol):
+        return (list, (list(self),))
 
     def __repr__(self):
-        return f"LazyStateList({self._n} states, {sum(s is not None for s in self._built)} built)"
+        missing = getattr(self, "_missing", 0)
+        return list.__repr__(self) if not missing else f"LazyStateList({len(self)} states, {len(self) - missing} built)"
+
+
+def _filled(name):
+    op = getattr(list, name)
+
+    def method(self, *a, **k):
+        return op(self._fill(), *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _name in ("__add__", "__radd__", "__iadd__", "__mul__", "__rmul__", "__imul__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__",
+              "__ge__", "__contains__", "__reversed__", "__setitem__", "__delitem__", "append", "extend", "insert", "remove", "pop",
+              "index", "count", "copy", "sort", "reverse", "clear"):
+    if hasattr(list, _name):
+        setattr(LazyStateList, _name, _filled(_name))
+LazyStateList.__hash__ = None

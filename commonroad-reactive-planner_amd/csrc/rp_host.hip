@@ -458,6 +458,8 @@ int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result
         return fail(c, RP_EINVAL, "unknown lon_mode");
     if (cost->kind < RP_COST_DEFAULT || cost->kind > RP_COST_EXTERNAL) return fail(c, RP_EINVAL, "unknown cost kind");
     if (!(p->wheelbase > 0.0)) return fail(c, RP_EINVAL, "wheelbase must be positive");
+    if (!(p->length >= 0.0 && p->length < 1e300 && p->width >= 0.0 && p->width < 1e300))   // (NaN / inf: the grid over the static shapes has no meaning)
+        return fail(c, RP_EINVAL, "length / width must be finite and non-negative");
     return RP_OK;
 }
 
@@ -877,7 +879,8 @@ int ensure_static_grid(rp_ctx *c, double ego_r) {
     const int n_clus = (int)(c->h_clus_info.size() / 4);
     c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0;
     c->grid_valid = true; c->grid_ego_r = ego_r;
-    if (n_clus == 0 || !(ego_r == ego_r) || !(ego_r < 1e300)) return RP_OK;   // (no static shapes: every lookup says "nothing")
+    if (n_clus == 0) return RP_OK;   // (no static shapes: every lookup says "nothing")
+    if (!(ego_r == ego_r) || !(ego_r < 1e300)) { c->obs.gnx = c->obs.gny = -1; return RP_OK; }   // no grid for such an ego: every pose walks every cluster
     struct Shape { int clus, kind; double cx, cy, ux, uy, hl, hw; };   // triangles / circles: the circle (cx, cy), radius hl
     std::vector<Shape> shapes;
     double x0 = HUGE_VAL, y0 = HUGE_VAL, x1 = -HUGE_VAL, y1 = -HUGE_VAL;
@@ -1068,6 +1071,7 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
             rp_result *result, double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    c->have_last = false;   // (before anything of the last plan -- inline grids, staging area -- is overwritten: an early return leaves no half-valid plan behind)
     if (c->timing) c->t_entry = std::chrono::steady_clock::now();
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
     const int64_t total = (int64_t)g->nT * g->nL * g->nD;
@@ -1146,6 +1150,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
                    double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    c->have_last = false;
     (void)lon_T;
     if (C < 0 || (C > 0 && (!lon_coeffs || !lat_coeffs || !traj_len))) return fail(c, RP_EINVAL, "rp_plan_coeffs: bad arrays");
     const int n = p->N + 1;
@@ -1313,6 +1318,11 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
 int rp_result_device(rp_ctx *c, const void **ptr, size_t *bytes, int32_t *rows_valid) {
     if (!c) return RP_EINVAL;
     if (!c->have_last || !ptr || !bytes) return fail(c, RP_ESTATE, "rp_result_device: no plan / null output");
+    // The caller reads the block on ANOTHER stream (the collective's).  rp_plan returns on the host ticket, which says nothing
+    // about the device copy as seen from other streams: wait for the context's stream here (its kernels have delivered their
+    // ticket already: ~1 us), after which the block is visible to work enqueued anywhere.
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     *ptr = c->d_result;
     *bytes = sizeof(ResultBlock) + sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)(c->last.N + 1);
     if (rows_valid) *rows_valid = c->last_rows_on_device ? 1 : 0;

@@ -250,6 +250,7 @@ int rp_initial_state(int32_t n, const double *ref_xy, const double *ref_pos, con
    Candidate ranges sharded over GPUs (one process per GPU): every rank's rp_plan leaves its result block -- header +
    winner state rows -- in device memory.  rp_result_device hands out its address and size, so that the caller can pass
    it to a collective as it is (torch.distributed / RCCL all_gather_into_tensor: no host packing, no copies);
+   rp_result_device waits for the context's stream first, so the block may be read by work enqueued on any stream afterwards.
    rows_valid = 0 means the winner's rows exist on the host only (large batches in non-materialising mode, where the
    winner is re-evaluated straight into host memory); the header says so, the block is gathered all the same.
    rp_combine_results takes the gathered blocks [world][bytes] (device memory), enqueues the combining kernel on

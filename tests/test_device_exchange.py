@@ -119,11 +119,17 @@ def test_collective_exchange_device_path_single_rank_group():
                     np.testing.assert_array_equal(glob.best_states, out.best_states)
                     np.testing.assert_array_equal(glob.best_lat_coeffs, out.best_lat_coeffs)
             assert ex.device_path_steps == 3
-            # a result that is not the context's last one goes the host-packed way
+            # the path is decided once for the group: a result that is not the context's last one is refused (a rank that
+            # switched to the host-packed collectives on its own would leave its peers in a different collective)
             stale = ctx.plan(g.inputs)
             ctx.plan(g.inputs, 0, 5)
-            glob = ex(ctx, stale)
-            assert glob.best_index == stale.best_index and ex.device_path_steps == 3
+            with pytest.raises(RuntimeError, match="device path"):
+                ex(ctx, stale)
+            # ... and a group built without the device path packs on the host
+            ex_host = CollectiveExchange(dist, torch.device("cuda", 0), g.inputs.params.N + 1, device_path=False)
+            assert ex.device_path and not ex_host.device_path
+            glob = ex_host(ctx, stale)
+            assert glob.best_index == stale.best_index and ex_host.device_path_steps == 0
             ctx.close()
     finally:
         dist.destroy_process_group()

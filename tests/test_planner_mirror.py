@@ -78,3 +78,25 @@ def test_output_packing_paths_agree():
         assert np.array_equal(a.position, b.position) and a.orientation == b.orientation and a.velocity == b.velocity
     for a, b in zip(fast[1].state_list, slow[1].state_list):
         assert np.array_equal(a.position, b.position) and a.yaw_rate == b.yaw_rate
+
+
+def test_state_list_is_a_list_and_keeps_yaw_rate_none():
+    """The reference's ``state_list`` is a plain list and state 0 carries ``x_0.yaw_rate`` as it is -- ``None`` for a hand-built
+    state (state.py:20) (reactive_planner.py:536-539).  The lazily built list behaves the same."""
+    import pickle
+    from commonroad_rp_amd import workloads
+    from commonroad_rp_amd.state import LazyStateList
+    from _oracle_ctx import OracleContext
+    rp = workloads.make_planner(workloads.cfg2(), backend_factory=OracleContext)
+    rp.x_0.yaw_rate = None
+    res = rp.plan()
+    sl = res[0].state_list
+    assert isinstance(sl, list) and isinstance(sl, LazyStateList)
+    assert sl[0].yaw_rate is None and isinstance(sl[1].yaw_rate, float)
+    n = len(sl)
+    assert sl[1] is sl[1] and sl[-1] is sl[n - 1]
+    both = sl + res[1].state_list                       # list concatenation builds what is missing
+    assert type(both) is list and len(both) == 2 * n and both[2] is sl[2]
+    again = pickle.loads(pickle.dumps(sl))
+    assert type(again) is list and len(again) == n and again[3].velocity == sl[3].velocity
+    assert [s.time_step for s in sl] == [rp.x_0.time_step + i for i in range(n)]
