@@ -11,8 +11,10 @@ driven in closed loop, every step a new initial state, velocity grid and time in
 states), not one repeated input.  A timed region is exactly K steps; regions are repeated until at least
 ``--min-seconds`` of timed work has accumulated, ``ms_per_step`` is the median region, the spread is reported.
 
-N = 1 (default): headline = cfg2 (BASELINE.json configs[1]) in draw mode, plus -- in the same JSON line --
-  ``configs``          draw- and production-mode records of cfg3, cfg4, cfg5, each with its own roofline
+N = 1 (default): headline = cfg3 (BASELINE.json configs[2], the largest configuration tagged 1 x MI355X) in draw mode, plus --
+in the same JSON line --
+  ``configs``          draw- and production-mode records of cfg2, cfg2 + road boundary, cfg3f (cfg3's traffic on the opposite lane),
+                       cfg4, cfg5, each with its own roofline
   ``fused_mode``       the headline workload in production mode (12 B per candidate leave the kernel)
   ``plan_latency_ms``  p50 / p90 of ReactivePlanner.plan() over closed-loop replans (Python boundary included)
   ``cpu_baseline``     the C port of the reference algorithm (oracle/) on the host cores, bounded sample
@@ -46,8 +48,10 @@ for _p in (REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")):
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # half the FP32 vector peak of the same table (157.3 TFLOPS): 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2.4 GHz
-PMC_FILE = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-FLOP_FILE = os.path.join(REPO, "profiles", "r02_fp64_flops.json")
+# counter files written by profiles/collect_pmc.sh / collect_fp64.sh; every entry names the hash of the sources of the library it
+# was measured on (rp_source_hash): an entry is reported only when that is the library this run has loaded
+PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
+FLOP_FILE = os.path.join(REPO, "profiles", "r03_fp64_flops.json")
 
 
 def parse_args():
@@ -55,7 +59,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, help="default: cfg2 at N = 1, cfg4 (strong scaling) at N > 1")
+    ap.add_argument("--workload", default=None, help="default: cfg3 at N = 1 (the largest configuration BASELINE.json tags 1 x MI355X), cfg4 (strong scaling) at N > 1")
     ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: which record is the headline")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measured record (regions of K steps are repeated)")
@@ -166,6 +170,18 @@ def load_json(path):
         return {}
 
 
+def counter_entry(path, key):
+    """(entry, note): the entry of a counter file if it was measured on the sources of the loaded library, else (None, why)."""
+    from commonroad_rp_amd import _capi
+    e = load_json(path).get(key)
+    if not e:
+        return None, None
+    have = _capi.source_hash()
+    if e.get("source_hash") != have:
+        return None, {"file": os.path.basename(path), "key": key, "measured_on": e.get("source_hash"), "loaded": have}
+    return e, None
+
+
 def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_ms, single_gpu=True):
     """Roofline of rp_eval_kernel for one record.  draw / materialize: HBM write stream, algorithmic bytes per launch
      / average kernel duration (HIP events inside rp_plan, on the context's stream).  fused: 12 B per candidate
@@ -173,17 +189,20 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
     step) (profiles/count_fp64.py over the disassembly of the variant this workload takes; profiles/r02_fp64_flops.json)
     x candidates x steps / kernel duration against the FP64 vector peak."""
     blk = 112 * n_steps_plus1
-    pmc = load_json(PMC_FILE).get(f"{name}:{mode}") if single_gpu else None
+    pmc, stale = counter_entry(PMC_FILE, f"{name}:{mode}") if single_gpu else (None, None)
     traffic = pmc.get("traffic_bytes") if pmc else None
+    extra = {"stale_profile": stale} if stale else {}
     if mode == "fused":
         # (cfg2 + road boundary: the flop count of plain cfg2 -- the static-shape walk adds tests, so the fraction is a lower bound)
-        fl = load_json(FLOP_FILE).get("cfg2" if name == "cfg2rb" else name)
+        fl, stale_f = counter_entry(FLOP_FILE, "cfg2" if name == "cfg2rb" else name)
+        if stale_f:
+            extra = {"stale_profile": stale_f}
         if fl and kernel_ms > 0:
             flops = float(fl["flops_per_candidate_step"]) * cand_mean * n_steps_plus1
             ach = flops / (kernel_ms * 1e-3) / 1e12
             return {"bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
                     "traffic": traffic, "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "flops_per_launch": flops,
-                    "flops_per_candidate_step": fl["flops_per_candidate_step"], "flop_model": fl.get("model")}
+                    "flops_per_candidate_step": fl["flops_per_candidate_step"], "flop_model": fl.get("model"), **extra}
         bytes_per_launch = cand_mean * 12
     elif mode == "draw":
         bytes_per_launch = cand_mean * 12 + cand_mean * blk
@@ -191,13 +210,13 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
         bytes_per_launch = cand_mean * 12 + feasible_mean * blk
     ach = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else float("nan")
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch}
+            "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, **extra}
 
 
 def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=8):
     """One measured record on one GPU: the sequence in one mode."""
     inputs = with_mode(seq, mode)
-    kms, feas = [], []
+    kms, feas, paths = [], [], [0, 0, 0]
     ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 8th step (a bracket costs ~8 us of stream time)
 
     def step(k):
@@ -205,6 +224,7 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
         if out.kernel_ms > 0:
             kms.append(out.kernel_ms)
         feas.append(out.n_feasible)
+        paths[ctx.last_path()] += 1
     regions = measure(step, len(inputs), steps, warmup, min_seconds, sync)
     ctx.set_profiling(0)
     sp = spread(regions)
@@ -213,6 +233,8 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
     n1 = inputs[0].params.N + 1
     rec = {"mode": mode, "candidates_per_step": cand, "ms_per_step": sp["median"], "value": cand / (sp["median"] * 1e-3),
            "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms, "sequence": len(inputs),
+           # how the steps answered the collision query: eager (every pose of every candidate), cost-ordered stage, stage + eager fallback
+           "collision_path_steps": {"eager": paths[0], "cost_ordered": paths[1], "cost_ordered_then_eager": paths[2]},
            "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms)}
     return rec
 
@@ -262,7 +284,7 @@ def run(args):
 def run_single(args, torch, device):
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import RpContext
-    name = args.workload or "cfg2"
+    name = args.workload or "cfg3"
     base = W.WORKLOADS[name](road_boundary=True) if args.road_boundary else W.WORKLOADS[name]()
     ctx = RpContext(device)
     base.setup(ctx)
@@ -301,14 +323,15 @@ def run_single(args, torch, device):
 
 
 def side_configs(args, torch, device, skip):
-    """Draw- and production-mode records of the larger single-GPU configurations of BASELINE.json (cfg3, cfg4) and of the
-    stress grid cfg5, so that the driver-run line carries them (the headline is the smallest GPU configuration)."""
+    """Draw- and production-mode records of the other configurations of BASELINE.json (cfg2, cfg4), of the stress grid cfg5, of
+    cfg2 with its road boundary and of cfg3f -- cfg3 with its traffic on the opposite lane, where the collision query cannot end
+    at a candidate's first hit -- so that the driver-run line carries them."""
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import RpContext
     out = {}
-    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.3, "cfg4": 1.8, "cfg5": 2.9}
-    # (+ the headline scenario with its road boundary in the obstacle tables: 85 thin rectangles from the lanelet network)
-    for name in ("cfg2rb", "cfg3", "cfg4", "cfg5"):
+    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.2, "cfg3f": 0.2, "cfg4": 1.4, "cfg5": 2.5}
+    # (cfg2rb: the T-junction with its road boundary in the obstacle tables, 85 thin rectangles from the lanelet network)
+    for name in ("cfg2", "cfg2rb", "cfg3", "cfg3f", "cfg4", "cfg5"):
         if name == skip:
             continue
         w = W.cfg2(road_boundary=True) if name == "cfg2rb" else W.WORKLOADS[name]()
@@ -515,6 +538,13 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     except Exception as e:
         weak_other = {"error": f"{type(e).__name__}: {e}"}
     ctx.close()
+    # ---- ReactivePlanner.plan() with the planner's process group set: the sharding decision, the shard's rp_plan and the winner
+    #      exchange all happen inside plan() (every rank drives the same closed loop on the strong-scaling workload)
+    plan_lat = None
+    try:
+        plan_lat = sharded_plan_latency(ws, dist, xdev, local_rank, default_transport)
+    except Exception as e:
+        plan_lat = {"error": f"{type(e).__name__}: {e}"}
     if rank != 0:
         return None
     head, hw, kind = (strong, ws, "strong") if args.scaling == "strong" else (weak, ww, "weak")
@@ -532,8 +562,34 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
         "roofline": head["roofline"],
         "strong": {"sharded": strong, "sharded_other_transport": strong_other, "one_gpu_same_grid": alone},
         "weak": {"sharded": weak, "sharded_other_transport": weak_other},
+        "plan_latency_ms": plan_lat,
         "rehearsal": bool(rehearse),
     }
+
+
+def sharded_plan_latency(w, dist, xdev, local_rank, transport, n_replans=60, warm=8):
+    """p50 of ``ReactivePlanner.plan()`` on every rank of the group, the planner sharding the level itself
+    (``GpuBackendMixin.set_process_group``): same closed loop on every rank, identical inputs, identical decisions."""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd.harness import run_closed_loop
+    import math
+    c = w.inputs.cost
+    dv = None if math.isnan(c.desired_speed) else float(c.desired_speed)
+    lat, loops = [], 0
+    while len(lat) < n_replans + warm and loops < 8:
+        rp = W.make_planner(w, device=local_rank)
+        rp.set_process_group(dist, xdev, transport)
+        res = run_closed_loop(rp, max_steps=40, replanning_frequency=1, desired_velocity=dv)
+        lat += res.plan_times if res.completed else res.plan_times[:-1]
+        loops += 1
+        rp.close()
+    lat = np.asarray(lat[warm:]) * 1e3
+    if len(lat) == 0:
+        return None
+    return {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "n": int(len(lat)), "workload": w.name,
+            "world": dist.get_world_size(), "shard_min_candidates": int(rp.shard_min_candidates),
+            "what": "ReactivePlanner.plan() wall time per closed-loop replan on rank 0, the planner's own sharding (set_process_group): "
+                    "shard_range -> rp_plan on the shard -> exchange_winner inside _get_optimal_trajectory"}
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -559,9 +615,9 @@ def cpu_baseline(w, inp, budget_s: float):
                      f"~3.9e3 candidates/s/core in the build container, BASELINE.md)"}
     # the same port on the GPU box's CPU share (OpenMP over candidates), a few seconds ("1 core and all cores")
     try:
-        threads = max(1, min(16, len(os.sched_getaffinity(0))))
+        threads = max(1, len(os.sched_getaffinity(0)))   # every core this process may run on
     except AttributeError:
-        threads = max(1, min(16, os.cpu_count() or 1))
+        threads = max(1, os.cpu_count() or 1)
     if threads > 1:
         big = min(C, 20000 * threads)
         oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads)
@@ -570,7 +626,8 @@ def cpu_baseline(w, inp, budget_s: float):
         while time.perf_counter() - t0 < min(3.0, budget_s / 3):
             oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads)
             n += 1
-        out["all_cores"] = {"value": big * n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": threads}
+        out["all_cores"] = {"value": big * n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": threads,
+                            "nproc": os.cpu_count(), "what": "the same C port, OpenMP over candidates on every core of the affinity mask"}
     # the reference's own execution model -- one Python iteration per candidate, NumPy per trajectory, a
     # scalar Python loop over the steps, sort + lazy collision walk (oracle/numpy_loop.py) -- on one core, a few seconds
     from oracle import numpy_loop

@@ -198,10 +198,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     sig = {
         "rp_abi_version": (C.c_int, []),
+        "rp_source_hash": (C.c_char_p, []),
         "rp_create": (C.c_int, [C.POINTER(ctx), C.c_int]),
         "rp_destroy": (None, [ctx]),
         "rp_last_error": (C.c_char_p, [ctx]),
         "rp_set_profiling": (C.c_int, [ctx, C.c_int]),
+        "rp_last_path": (C.c_int, [ctx]),
         "rp_set_reference": (C.c_int, [ctx, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double]),
         "rp_set_obstacles": (C.c_int, [ctx, C.c_int32, dp, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32,
                                        C.c_int32, dp]),
@@ -231,7 +233,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_mailbox_stalled_rank": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)   # AttributeError here = the library does not export the header's symbol
+        try:
+            fn = getattr(lib, name)   # AttributeError here = the library does not export the header's symbol
+        except AttributeError:
+            if path == LIB_PATH or name not in _OPTIONAL_IN_AB_BUILDS:
+                raise
+            continue                  # (an older build named by RP_AMD_LIBRARY for an A/B run: entries added since are absent)
         fn.restype, fn.argtypes = res, args
     if lib.rp_abi_version() != 1:
         raise RpError(f"librp_amd.so ABI version {lib.rp_abi_version()} != 1")
@@ -240,11 +247,18 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-EXPORTED_SYMBOLS = ("rp_abi_version", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling",
+_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash")
+EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
+
+
+def source_hash() -> str:
+    """Hash of the sources the loaded library was built from ("unknown" for a build that does not carry one)."""
+    fn = getattr(load_library(), "rp_source_hash", None)
+    return (fn() or b"unknown").decode() if fn is not None else "unknown"
 
 
 # ---- reference-path front end (host-only entry points: no context, no GPU) -------------------------
@@ -344,6 +358,12 @@ class RpContext:
     def set_profiling(self, every: int):
         """Time the evaluation kernel of every ``every``-th plan with HIP events (0 / False = off)."""
         self._check(self._lib.rp_set_profiling(self._h, int(every)), "rp_set_profiling")
+
+    def last_path(self) -> int:
+        """How the last plan answered the collision query: 0 eager (every pose of every candidate), 1 cost-ordered (costs first,
+        candidates in ascending cost until the first free one), 2 cost-ordered stage exhausted, eager kernel decided."""
+        fn = getattr(self._lib, "rp_last_path", None)
+        return int(fn(self._h)) if fn is not None else 0
 
     def set_reference(self, ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit: float = 20.0):
         ref_pos, ref_theta, ref_curv, ref_curv_d = f64(ref_pos), f64(ref_theta), f64(ref_curv), f64(ref_curv_d)

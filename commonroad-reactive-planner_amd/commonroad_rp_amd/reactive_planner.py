@@ -191,12 +191,53 @@ class _WinnerSample(TrajectorySample):
 _LON_ROWS, _LAT_ROWS = [7, 10, 11], [8, 12, 13]   # rows of a state block (include/rp_amd.h: RP_S, RP_S_DOT, RP_S_DDOT | RP_D, ...)
 
 
+#: Candidates per sampling level from which a plan is sharded over the GPUs of the planner's process group (SURVEY 8e:
+#: "only when the sample grid exceeds one GPU's saturation point").  From the one-GPU step times of this build (MI355X,
+#: production mode): 7 440 candidates 31 us, 62 496: 163 us, 512 064: 521 us -- beyond the single-launch
+#: regime a step grows by ~2.4 us per 1 000 candidates, and the winner exchange costs 6-9 us (shared-memory mailbox of one node; a
+#: device collective ~40 us).  Halving a batch pays once C / 2 x 2.4 us / 1 000 exceeds the exchange with a margin of two:
+#: C > 15 000.  Below that every shard pays the whole launch chain for nothing (2 ranks on a 7 440-candidate grid: 35 -> 43 us).
+SHARD_MIN_CANDIDATES = 16384
+
+
 class GpuBackendMixin:
     """Routes the per-level hot path of ``plan()`` through the HIP library."""
 
     #: factory ``device -> context`` with the interface of ``_capi.RpContext``
     backend_factory = RpContext
     gpu_device = 0
+    # multi-GPU: the process group (``torch.distributed`` or an object with its interface) this planner's ranks share, and from
+    # how many candidates on a level is sharded over it (set_process_group)
+    shard_dist = None
+    shard_device = None
+    shard_transport = "auto"
+    shard_min_candidates = SHARD_MIN_CANDIDATES
+
+    def set_process_group(self, dist, device=None, transport: str = "auto", min_candidates: Optional[int] = None):
+        """One planner per rank, the same inputs on every rank (the reference's only parallel backend also lives inside
+        ``_get_optimal_trajectory``: the ``multiprocessing`` fan-out over ``config.debug.num_workers`` workers,
+        reactive_planner.py:1084-1111).  With a group of more than one rank, a sampling level of at least ``min_candidates``
+        candidates (default ``SHARD_MIN_CANDIDATES``) is evaluated in contiguous index ranges, one per rank
+        (``distributed.shard_range``), and the ranks exchange their winners (``distributed.exchange_winner``): every rank
+        returns the same optimal trajectory, counters and costs as an unsharded call.  Smaller levels, draw mode, plug-in cost
+        functions and sampling spaces without a product grid run whole on every rank.  ``dist=None`` switches sharding off.
+        Collective: call it on every rank with the same arguments."""
+        self.shard_dist = dist
+        if dist is not None and device is None:
+            import torch
+            device = torch.device("cuda", self.gpu_device) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
+        self.shard_device = device
+        self.shard_transport = transport
+        if min_candidates is not None:
+            self.shard_min_candidates = int(min_candidates)
+
+    def _shard_world(self, n_candidates: int, grid_plan: bool, external: bool) -> int:
+        """Ranks this level is sharded over (1: not sharded).  The same decision on every rank: it depends on the inputs only."""
+        dist = self.shard_dist
+        if dist is None or not grid_plan or external or self._draw_traj_set:
+            return 1
+        world = dist.get_world_size()
+        return world if (world > 1 and n_candidates >= self.shard_min_candidates) else 1
 
     # ---- context and tables -----------------------------------------------------------------------
     def _gpu_ctx(self):
@@ -353,12 +394,22 @@ class GpuBackendMixin:
             cost = make_cost(COST_EXTERNAL)
         params = self._gpu_params(bundle.x_0_lon, bundle.x_0_lat, flags)
 
+        sharded = False
         if bundle.grids is not None:
             T, traj_len, L, D = bundle.grids
-            if len(T) * len(L) * len(D) == 0:
+            C = len(T) * len(L) * len(D)
+            if C == 0:
                 self._infeasible_count_kinematics = 0
                 return None
-            out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D))
+            world = self._shard_world(C, True, external)
+            if world > 1:   # this rank's contiguous range of the reference list index, then the winner exchange
+                from .distributed import exchange_winner, shard_range
+                lo, hi = shard_range(C, self.shard_dist.get_rank(), world)
+                out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D), lo, hi)
+                out = exchange_winner(ctx, out, self.shard_dist, self.shard_device, self.shard_transport)
+                sharded = True
+            else:
+                out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D))
         elif bundle.coeffs is not None:
             lon, lat, lon_T, tl = bundle.coeffs[:4]
             if len(lon_T) == 0:
@@ -391,6 +442,8 @@ class GpuBackendMixin:
         # plan()'s standstill branch reads bundle.min_costs() / max_costs() (reactive_planner.py:650-651): two numbers, worked out
         # on the device when somebody asks (the reference's bundle then holds the kinematically feasible samples, :1128)
         bundle._range_fn, bundle._range = getattr(ctx, "cost_range", None), None
+        if sharded and bundle._range_fn is not None:   # (every rank takes the standstill branch or none: same inputs, same winner)
+            bundle._range_fn = self._gpu_sharded_cost_range(ctx)
         if self._draw_traj_set:
             self.stored_trajectories = self._gpu_stored_trajectories(ctx, bundle, status, costs)
         if out.best_index < 0:
@@ -406,6 +459,21 @@ class GpuBackendMixin:
         return self._gpu_winner_sample(bundle, out)
 
     # ---- helpers ----------------------------------------------------------------------------------
+    def _gpu_sharded_cost_range(self, ctx):
+        """min / max / number of the costs over ALL ranks' shards (``TrajectoryBundle.min_costs() / max_costs()``,
+        reactive_planner.py:650-651): each rank's range from its device, combined over the group."""
+        dist = self.shard_dist
+
+        def fn():
+            lo, hi, n = ctx.cost_range()
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, (lo, hi, n))
+            parts = [q for q in parts if q[2] > 0]
+            if not parts:
+                return float("nan"), float("nan"), 0
+            return min(q[0] for q in parts), max(q[1] for q in parts), sum(q[2] for q in parts)
+        return fn
+
     def _gpu_candidate_sample(self, bundle: GpuTrajectoryBundle, index: int, lon_coeffs=None, lat_coeffs=None,
                               lat_T=None) -> TrajectorySample:
         if bundle.coeffs is not None:   # polynomials straight from the coefficient arrays of the batch view

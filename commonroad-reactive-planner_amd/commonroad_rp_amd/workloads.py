@@ -66,7 +66,7 @@ def _with_d0(D: np.ndarray, d0: float) -> np.ndarray:
 
 
 def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired_speed=None, extra_obstacles=0,
-                       flags=0, description="", extra_jitter=1.5, extra_lane=4.0, road_boundary=False) -> Workload:
+                       flags=0, description="", extra_jitter=1.5, extra_lane=4.0, road_boundary=False, extra_sides=(-1.0, 1.0)) -> Workload:
     sc = _load_scenario(scen_name)
     dt = float(sc["dt"])
     co = CoordinateSystem(sc["centre"], smooth_reference=True)   # (the reference smooths a route by default, utils_coordinate_system.py:88,98-100)
@@ -88,7 +88,7 @@ def _scenario_workload(name, scen_name, N, T, nL, nD, low_vel_threshold, desired
         s_max = co.ref_pos[-1]
         for j in range(extra_obstacles):   # constant-velocity 4.5 x 2.0 m boxes along the route
             s0, vel, off = rng.uniform(0.0, s_max), rng.uniform(5.0, 15.0), rng.uniform(-extra_jitter, extra_jitter)
-            lane = rng.choice([-1.0, 1.0]) * extra_lane      # neighbouring lanes
+            lane = rng.choice(list(extra_sides)) * extra_lane      # neighbouring lanes
             for k in range(n_steps):
                 s = s0 + vel * dt * k
                 if s >= s_max - 1.0:
@@ -139,6 +139,17 @@ def cfg3(flags: int = 0, road_boundary: bool = False) -> Workload:
     return _scenario_workload("cfg3", "DEU_Test-1_1_T-1", N, T, 63, 31, low_vel_threshold=4.0, extra_obstacles=49,
                               flags=flags, extra_lane=5.0, road_boundary=road_boundary,
                               description="DEU_Test-1_1_T-1, 31x31x63 grid, N=60, 51 obstacles (49 synthetic, seed 0)")
+
+
+def cfg3f(flags: int = 0, road_boundary: bool = False) -> Workload:
+    """cfg3 with its 49 synthetic obstacles on ONE side of the route, 6 m out (the opposite lane): the same query load per pose,
+    but most candidates stay free -- cfg3 proper is a degenerate collision workload (97 % of the candidates collide, the query of
+    a candidate ends at its first hit).  The collision query is measured here where it cannot bail out early."""
+    dt, N = 0.1, 60
+    T = [dt * (30 + k) for k in range(31)]
+    return _scenario_workload("cfg3f", "DEU_Test-1_1_T-1", N, T, 63, 31, low_vel_threshold=4.0, extra_obstacles=49,
+                              flags=flags, extra_lane=6.0, extra_sides=(1.0,), road_boundary=road_boundary,
+                              description="DEU_Test-1_1_T-1, 31x31x63 grid, N=60, 51 obstacles (49 synthetic on the opposite lane, seed 0)")
 
 
 def cfg4(flags: int = 0, road_boundary: bool = False) -> Workload:
@@ -278,4 +289,4 @@ def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_fa
     return recorded[:n_states]
 
 
-WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg4": cfg4, "cfg5": cfg5}
+WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg3f": cfg3f, "cfg4": cfg4, "cfg5": cfg5}

@@ -28,10 +28,16 @@ namespace {
 
 constexpr int kBlocksPerCU = 4;           // workgroups per CU of the grid-stride helper kernels (longitudinal profiles, counts)
 constexpr int kFoldPartials = 256;        // large batches: workgroup partials are folded to this many before the epilogue
-constexpr int kFoldThreshold = 4096;        // (RP_AMD_FOLD_THRESHOLD overrides; 2 048 -> 4 096: cfg3's 3 906 partials go straight to the epilogue, -5.5 us per step)
+constexpr int kFoldThreshold = 8192;      // (RP_AMD_FOLD_THRESHOLD overrides) every workgroup of the selection epilogue reads all partials: up to
+                                          // here straight from the evaluation kernel's (cfg3: 3 906), beyond (cfg4 32 k, cfg5 64 k) folded first
 constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass
                                           // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
+// cost-ordered collision stage: capacity of the candidate lists of the three rounds and their places in d_lazy_lists
+constexpr int kLazyCap[RP_LAZY_LEVELS] = {1024, 4096, 16384};
+constexpr int kLazyOff[RP_LAZY_LEVELS] = {0, 1024, 5120};
+constexpr int kLazyListWords = 21504;
+constexpr uint32_t kLazyTarget[RP_LAZY_LEVELS] = {128, 1024, 8192};   // candidates (cumulative) the levels are meant to reach
 
 using ResultBlock = FinalizeOut;   // device -> host result block (rp_kernels.h)
 
@@ -81,8 +87,17 @@ struct rp_ctx {
     size_t cap_profile = 0, cap_profile_one = 0;
     PairHdr *d_pair_hdr = nullptr, *d_pair_hdr_one = nullptr;
     size_t cap_pair_hdr = 0;
-    BlockPartial *d_partials = nullptr;   // [cap_partials] one per workgroup, then [kFoldPartials] folded ones
+    void *d_partials = nullptr;   // Partials (rp_kernels.h): arrays of cap_partials + kFoldPartials slots -- one per workgroup, then the folded ones
     int cap_partials = 0;
+    unsigned long long *d_sel_scratch = nullptr;   // rp_select_kernel: counter totals and arrival ticket (zero between launches)
+    // cost-ordered collision stage (rp_kernels.h: LazyCtl): control block, the three candidate lists, state rows of a round's candidates
+    LazyCtl *d_lazy_ctl = nullptr;
+    int32_t *d_lazy_lists = nullptr;
+    uint32_t *d_lazy_hist = nullptr;       // [RP_LAZY_BINS + 1] histogram of the costs + arrival ticket (zero between launches)
+    double *d_lazy_states = nullptr;
+    size_t cap_lazy_states = 0;
+    int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
+    int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
@@ -103,7 +118,10 @@ struct rp_ctx {
     int last_G = 0;              // lanes per candidate of the last plan
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
-    KArgsG kargs_g{};            // launch block of the evaluation / profile kernels: KArgs + the grids of the last rp_plan (if they fit)
+    KArgsG kargs_g{};            // launch block of the evaluation kernels: KArgs + the grids of the last rp_plan (if they fit)
+    KArgsGL kargs_gl{};          // launch block of rp_lon_kernel: KArgs + room for larger grids (it publishes them to d_stage for the kernels behind it)
+    bool grids_pending = false;  // the grids of the last rp_plan (c->staged, h_stage) are neither in kargs_g nor in d_stage yet: run_pipeline
+                                 // hands them to rp_lon_kernel's kernarg segment (two-kernel path) or copies them
     std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
 };
 
@@ -277,7 +295,7 @@ void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin,
 // State rows leave through LDS as one linear stream (STAGE_OUT) for whole-wavefront candidates of the two-kernel path.
 inline bool stage_out_applies(const KArgs &ka, int G, bool mat) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
-    return mat && !ka.single_index && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
+    return mat && !ka.single_index && !ka.index_list && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
 }
 
 // Doubles between two rows of a state block in device memory.  Rows stored directly (every variant but STAGE_OUT) start on
@@ -288,6 +306,17 @@ inline int state_row_stride(int n, bool staged) {
     if (staged || std::getenv("RP_AMD_NO_ROW_PADDING")) return n;
     if (const char *e = std::getenv("RP_AMD_ROW_ALIGN")) { const int al = std::atoi(e); if (al == 8 || al == 16) return (n + al - 1) & ~(al - 1); }
     return (n + 15) & ~15;
+}
+// Split tail (rp_kernels.h: state_offset): when the last step block of 16 holds at most 8 steps (N = 100: 5 of 16), the rows keep
+// the full step blocks only and the partial one is stored two rows to a 128-byte line -- whole-line stores as before, without
+// 11 doubles of padding per row (cfg4 / cfg5: 12.8 GB written for 11.5 GB of rows).  Two-kernel path, 16 lanes per candidate.
+// Returns M (0: padded rows) and sets *ns.
+inline int state_layout(int n, int G, bool fused, bool staged, int *ns) {
+    *ns = state_row_stride(n, staged);
+    const int r = n & 15, M = n - r;
+    if (staged || fused || G != 16 || r == 0 || r > 8 || M < 16 || *ns != ((n + 15) & ~15) || std::getenv("RP_AMD_NO_TAIL_SPLIT")) return 0;
+    *ns = M;
+    return M;
 }
 
 template <int G, bool MAT, bool CIN, int COLL>
@@ -347,10 +376,11 @@ void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int G
 template <int G, bool CIN>
 void launch_lon_t(rp_ctx *c, const KArgs &ka, int grid) {
     const size_t tbytes = (size_t)ka.table_words * sizeof(double);
+    c->kargs_gl.k = ka;   // (the grid part is filled by rp_plan / run_pipeline and stays until the next plan: rp_eval_one)
     if (tbytes <= kLdsTableLimit)
-        launch_kargs(c, (const void *)rp_lon_kernel<G, CIN, true>, grid, RP_BLOCK, tbytes, ka);
+        launch_block(c, (const void *)rp_lon_kernel<G, CIN, true>, grid, RP_BLOCK, tbytes, &c->kargs_gl, sizeof(KArgsGL));
     else
-        launch_kargs(c, (const void *)rp_lon_kernel<G, CIN, false>, grid, RP_BLOCK, 0, ka);
+        launch_block(c, (const void *)rp_lon_kernel<G, CIN, false>, grid, RP_BLOCK, 0, &c->kargs_gl, sizeof(KArgsGL));
 }
 
 // longitudinal profiles of the pairs [ka.pair_begin, ka.pair_begin + ka.pair_count)
@@ -510,6 +540,103 @@ void host_winner_coeffs(const rp_ctx *c, const KArgs &ka, bool cin, rp_result *r
     r->best_lat_T = lat_T;
 }
 
+// Host wait for a completion ticket in the pinned result block (falls back to a stream sync after 200 ms)
+int wait_ticket(rp_ctx *c, unsigned long long seq) {
+    const volatile unsigned long long *flag = &reinterpret_cast<ResultBlock *>(c->h_result)->seq;
+    const auto t_start = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RP_OK;
+        if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
+        __builtin_ia32_pause();
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RP_OK;
+}
+
+// The cost-ordered collision stage (rp_kernels.h: LazyCtl): pass 1 without the collision query -> thresholds and candidate lists
+// -> rounds of (evaluation kernel in list mode WITH the query, one-workgroup epilogue) until a round has a free candidate.
+// The longitudinal profiles are in place (run_pipeline launched rp_lon_kernel).  *done: the result block in pinned host memory is
+// final (winner or "no candidate survives"); otherwise the caller runs the eager kernel over the whole batch.
+template <typename LaunchEval>
+int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_rows, LaunchEval &launch_main_eval, bool *done) {
+    *done = false;
+    (void)G;
+    const int n = ka.N + 1;
+    const int64_t count = ka.count;
+    ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
+    ResultBlock *hrb_dev = reinterpret_cast<ResultBlock *>(c->h_result_dev);
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    int rc;
+    // -- pass 1: kinematics + cost of every candidate, no collision query; workgroup 0 clears the control block
+    KArgs k1 = ka;
+    k1.flags |= RP_FLAG_SKIP_COLLISION;
+    k1.lazy_ctl = c->d_lazy_ctl;
+    k1.states = nullptr;
+    if ((rc = launch_main_eval(k1, false)) != RP_OK) return rc;
+    int n_partials = grid, p_first = 0;
+    static const int fold_threshold = std::getenv("RP_AMD_FOLD_THRESHOLD") ? std::atoi(std::getenv("RP_AMD_FOLD_THRESHOLD")) : kFoldThreshold;
+    if (n_partials > fold_threshold) {
+        hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, ka.partials_cap, n_partials,
+                           c->cap_partials);
+        p_first = c->cap_partials;
+        n_partials = kFoldPartials;
+    }
+    // -- thresholds and lists
+    GatherArgs ga;
+    ga.status = ka.status; ga.cost = ka.cost; ga.partials = c->d_partials; ga.lists = c->d_lazy_lists; ga.ctl = c->d_lazy_ctl;
+    ga.count = count; ga.cand_begin = ka.cand_begin;
+    ga.partials_cap = ka.partials_cap; ga.partials_first = p_first; ga.n_partials = n_partials; ga.pad_ = 0;
+    ga.hist = c->d_lazy_hist; ga.pad2_ = 0;
+    for (int l = 0; l < RP_LAZY_LEVELS; ++l) { ga.cap[l] = kLazyCap[l]; ga.off[l] = kLazyOff[l]; ga.target[l] = kLazyTarget[l]; }
+    const int ggrid = (int)std::max<int64_t>(16, std::min<int64_t>((count + 2047) / 2048, (int64_t)c->num_cus));
+    launch_block(c, (const void *)rp_lazy_hist_kernel, ggrid, RP_GATHER_THREADS, 0, &ga, sizeof(ga));
+    launch_block(c, (const void *)rp_lazy_gather_kernel, ggrid, RP_GATHER_THREADS, 0, &ga, sizeof(ga));
+    // -- rounds
+    const int ns = state_row_stride(n, false);
+    uint32_t cnt[RP_LAZY_LEVELS] = {(uint32_t)kLazyCap[0], 0, 0};   // (round 0 is launched for a full list: its size is on the device only)
+    for (int l = 0; l < RP_LAZY_LEVELS; ++l) {
+        if (l > 0 && cnt[l] == 0) continue;
+        const int rcount = (int)std::min<uint32_t>(cnt[l], (uint32_t)kLazyCap[l]);
+        const int rgrid = (rcount + RP_BLOCK / 64 - 1) / (RP_BLOCK / 64);
+        if (want_rows && (rc = grow(c, c->d_lazy_states, c->cap_lazy_states, (size_t)rcount * RP_N_ARRAYS * (size_t)ns)) != RP_OK) return rc;
+        KArgs kr = ka;
+        kr.index_list = c->d_lazy_lists + kLazyOff[l];
+        kr.list_count = &c->d_lazy_ctl->count[l];
+        kr.list_cap = kLazyCap[l];
+        kr.states = want_rows ? c->d_lazy_states : nullptr;
+        kr.row_stride = ns;
+        kr.tail_split = 0;
+        kr.lazy_ctl = nullptr;
+        launch_eval(c, kr, rgrid, want_rows, cin, 64);   // one wavefront per candidate
+        const unsigned long long seq = ++c->seq;
+        hrb_host->seq = 0;
+        FinArgs fa;
+        std::memset(&fa, 0, sizeof(fa));
+        fa.status = ka.status; fa.cost = ka.cost; fa.states = kr.states; fa.partials = c->d_partials;
+        fa.partials_cap = ka.partials_cap; fa.partials_first = 0;
+        fa.dev_out = drb; fa.host_out = hrb_dev;
+        fa.count = count; fa.cand_begin = ka.cand_begin; fa.seq = seq;
+        fa.debug = c->d_debug;
+        fa.N = ka.N; fa.n_partials = rgrid; fa.count_inline = 1; fa.copy_states = want_rows ? 1 : 0;
+        fa.row_stride = ns; fa.tail_split = 0; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
+        fa.scratch = c->d_sel_scratch;
+        fa.list = kr.index_list; fa.list_count = kr.list_count; fa.lazy = c->d_lazy_ctl; fa.list_cap = kLazyCap[l]; fa.level = l;
+        launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
+        HIP_TRY(c, hipGetLastError());
+        if ((rc = wait_ticket(c, seq)) != RP_OK) return rc;
+        // what the round left: winner, or the state of the stage (FinalizeOut.w_coeffs[0..3]: list sizes, overflow, checked, feasible)
+        unsigned long long ex[4];
+        std::memcpy(ex, hrb_host->w_coeffs, sizeof(ex));
+        const uint32_t overflow = (uint32_t)(ex[1] >> 32), checked = (uint32_t)ex[2];
+        const unsigned long long feasible = ex[3];
+        cnt[0] = (uint32_t)ex[0]; cnt[1] = (uint32_t)(ex[0] >> 32); cnt[2] = (uint32_t)ex[1];
+        if (overflow & ((2u << l) - 1u)) return RP_OK;              // this round's list (or an earlier one) was incomplete: not conclusive
+        if (hrb_host->r.best_index >= 0) { *done = true; return RP_OK; }
+        if ((unsigned long long)checked >= feasible) { *done = true; return RP_OK; }   // every feasible candidate collides: no winner
+    }
+    return RP_OK;   // lists exhausted without a free candidate: the eager kernel decides
+}
+
 // eval -> finalize (-> count for huge batches) (-> winner re-evaluation when nothing was materialised).
 // The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
 int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
@@ -535,35 +662,51 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     ka.lds_pairs = fused_pairs;
     if (!skip_eval) {
         c->last_fused_lds = fused_lds; c->last_G = G;
-        ka.row_stride = state_row_stride(n, !fused_lds && stage_out_applies(ka, G, mat));   // (rp_select keeps the plan's)
+        ka.tail_split = state_layout(n, G, fused_lds != 0, !fused_lds && stage_out_applies(ka, G, mat), &ka.row_stride);   // (rp_select keeps the plan's)
     }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
-    if (grid > c->cap_partials) {
+    if (std::max(grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
         c->cap_partials = 0;
-        int want = std::max(grid + grid / 4, c->num_cus * kBlocksPerCU);
-        HIP_TRY(c, hipMalloc((void **)&c->d_partials, sizeof(BlockPartial) * ((size_t)want + kFoldPartials)));
+        int want = std::max(std::max(grid + grid / 4, c->num_cus * kBlocksPerCU), kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64));
+        HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)RP_PARTIAL_BYTES * ((size_t)want + kFoldPartials)));
         c->cap_partials = want;
     }
     ka.partials = c->d_partials;
+    ka.partials_cap = c->cap_partials + kFoldPartials;   // slots per array (the folded ones sit behind the workgroups')
     int n_partials = grid;
 
     const bool small = count <= RP_FINALIZE_MAX;
     const bool copy_states = mat && best_states != nullptr && count > 0;
     const bool winner_pass = !mat && best_states != nullptr && count > 0;
     c->last_rows_on_device = copy_states || count == 0;
-    const bool ticket = c->spin_wait && small;
+    const bool ticket = c->spin_wait;   // (large batches too: their selection epilogue hands the ticket over itself)
     ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
-    const unsigned long long seq = ++c->seq;
+    unsigned long long seq = ++c->seq;
     if (ticket) hrb_host->seq = 0;
-    const unsigned long long fin_seq = (ticket && !winner_pass) ? seq : 0ull;
+    unsigned long long fin_seq = (ticket && !winner_pass) ? seq : 0ull;
     // (A selection epilogue run by the evaluation kernel's last workgroup was tried and measured slower -- cfg2: eval
     //  21.6 -> 37.8 us: every workgroup then pays an agent-scope release fence, an L2 write-back, before its ticket.)
     const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
     bool time_valid = false;
     const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    bool lazy_done = false;   // the cost-ordered collision stage delivered the result (its last round handed the ticket over)
     if (!skip_eval) {
+        // grids that did not fit the evaluation kernel's launch block: in rp_lon_kernel's (two-kernel path: its workgroup 0 publishes
+        // them to d_stage for the kernels behind it) or by a host-to-device copy (a 5-us blit kernel on the stream)
+        bool lon_inline = ka.grids_inline != 0, lon_publish = false;
+        if (c->grids_pending) {
+            const size_t sbytes = c->staged.size();
+            if (count > 0 && !fused_lds && !cin && sbytes + 8 <= sizeof(c->kargs_gl.grid) && !std::getenv("RP_AMD_NO_LON_PUBLISH")) {
+                std::memcpy(c->kargs_gl.grid, c->staged.data(), sbytes);
+                lon_inline = lon_publish = true;
+            } else {
+                HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+            }
+            c->grids_pending = false;
+            c->staged_on_device = true;
+        }
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
         if (count > 0 && !fused_lds) {
             if (cin) { ka.pair_begin = 0; ka.pair_count = count; }
@@ -575,59 +718,92 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
             if ((rc = grow(c, c->d_pair_hdr, c->cap_pair_hdr, (size_t)ka.pair_count)) != RP_OK) return rc;
             ka.profile = c->d_profile;
             ka.pair_hdr = c->d_pair_hdr;
-            launch_lon(c, ka, cin);
+            KArgs kl = ka;
+            kl.grids_inline = lon_inline ? 1 : 0;
+            kl.publish_grids = lon_publish ? 1 : 0;
+            launch_lon(c, kl, cin);
         }
         // the evaluation kernel's duration: events attached to the launch itself (hipExtModuleLaunchKernel; RP_AMD_EVENT_BRACKET=1:
         // two hipEventRecord around it, which adds the dispatch and completion handling of the bracket -- ~2.5 us on a 14-us kernel)
         const bool by_launch = timed && count > 0 && !std::getenv("RP_AMD_EVENT_BRACKET");
-        c->timed_by_launch = false;
-        c->time_next_launch = by_launch;
-        if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (count > 0) {
+        auto launch_main_eval = [&](const KArgs &k, bool mat_) -> int {   // the batch's evaluation kernel, timed if this step is
+            c->timed_by_launch = false;
+            c->time_next_launch = by_launch;
+            if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (fused_lds) launch_eval_fused(c, ka, grid, mat, cin, fused_lds, G);
-            else launch_eval(c, ka, grid, mat, cin, G);
+            if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);
+            else launch_eval(c, k, grid, mat_, cin, G);
             if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
+            c->time_next_launch = false;
+            if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            time_valid = timed && (!by_launch || c->timed_by_launch);   // (a launch that could not carry the events: no duration this step)
+            return RP_OK;
+        };
+        // Production-mode plans of large batches with obstacles: costs first, collision rounds over the cheapest candidates (the
+        // reference's own order of work, reactive_planner.py:1031-1062) -- see LazyCtl in rp_kernels.h.  RP_AMD_LAZY=0 never,
+        // =1 whenever the launch path allows it (tests), default: batches beyond the one-workgroup epilogue, unless the last
+        // attempts had to fall back to the eager kernel (a scene where nearly everything collides).
+        bool lazy_possible = count > 0 && !mat && !fused_lds && collision_level(ka) > 0 && !(ka.flags & RP_FLAG_DRAW_ALL) &&
+                             ka.cost_kind != RP_COST_EXTERNAL && !ka.single_index;
+        const char *lazy_e = lazy_possible ? std::getenv("RP_AMD_LAZY") : nullptr;   // (read per plan: the tests switch paths)
+        const int lazy_env = lazy_e ? std::atoi(lazy_e) : -1;
+        lazy_possible = lazy_possible && lazy_env != 0;
+        bool lazy_try = lazy_possible && (lazy_env == 1 || (!small && c->lazy_skip == 0));
+        if (lazy_possible && !lazy_try && lazy_env != 1 && !small && c->lazy_skip > 0) --c->lazy_skip;
+        c->last_lazy = 0;
+        if (lazy_try) {
+            if ((rc = run_lazy(c, ka, cin, G, grid, best_states != nullptr, launch_main_eval, &lazy_done)) != RP_OK) return rc;
+            if (lazy_done) { c->lazy_penalty = 0; c->last_lazy = 1; c->last_rows_on_device = best_states != nullptr; }
+            else {   // the eager kernel decides (profiles are in place); the next plans do not try again for a while
+                c->lazy_penalty = std::min(64, std::max(1, c->lazy_penalty * 2));
+                c->lazy_skip = c->lazy_penalty;
+                c->last_lazy = 2;
+                seq = ++c->seq;
+                if (ticket) hrb_host->seq = 0;
+                fin_seq = (ticket && !winner_pass) ? seq : 0ull;
+            }
         }
-        c->time_next_launch = false;
-        if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-        time_valid = timed && (!by_launch || c->timed_by_launch);   // (a launch that could not carry the events: no duration this step)
+        if (count > 0 && !lazy_done && (rc = launch_main_eval(ka, mat)) != RP_OK) return rc;
         if (count == 0) n_partials = 0;
     } else {
         n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
         if (count > 0)
             hipLaunchKernelGGL(rp_partials_kernel, dim3(n_partials), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
-                               ka.cand_begin, c->d_partials);
+                               ka.cand_begin, c->d_partials, ka.partials_cap);
         else
             n_partials = 0;
     }
-    {
-        const BlockPartial *fin_in = c->d_partials;
+    if (!lazy_done) {
+        int fin_first = 0;
         static const int fold_threshold = std::getenv("RP_AMD_FOLD_THRESHOLD") ? std::atoi(std::getenv("RP_AMD_FOLD_THRESHOLD")) : kFoldThreshold;
-        if (n_partials > fold_threshold) {   // one partial per workgroup of a large batch: fold before the one-workgroup epilogue
-            BlockPartial *folded = c->d_partials + c->cap_partials;
-            hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, n_partials, folded);
-            fin_in = folded;
+        if (n_partials > fold_threshold) {   // one partial per workgroup of a very large batch: fold before the epilogue
+            hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, ka.partials_cap, n_partials,
+                               c->cap_partials);
+            fin_first = c->cap_partials;
             n_partials = kFoldPartials;
         }
         const auto tf0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         FinArgs fa;
-        fa.status = ka.status; fa.cost = ka.cost; fa.states = ka.states; fa.partials = fin_in;
+        std::memset(&fa, 0, sizeof(fa));   // (list / lazy stay null: not a round of the cost-ordered stage)
+        fa.status = ka.status; fa.cost = ka.cost; fa.states = ka.states; fa.partials = c->d_partials;
+        fa.partials_cap = ka.partials_cap; fa.partials_first = fin_first;
         fa.dev_out = drb; fa.host_out = hrb_dev;
         fa.count = ka.count; fa.cand_begin = ka.cand_begin; fa.seq = fin_seq;
         fa.debug = c->d_debug;
-        fa.N = ka.N; fa.n_partials = n_partials; fa.count_inline = small ? 1 : 0; fa.copy_states = copy_states ? 1 : 0;
-        fa.row_stride = ka.row_stride; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
-        launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
+        fa.N = ka.N; fa.n_partials = n_partials; fa.copy_states = copy_states ? 1 : 0;
+        fa.row_stride = ka.row_stride; fa.tail_split = ka.tail_split; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
+        fa.scratch = c->d_sel_scratch;
+        if (small) {   // one workgroup does it all (count of the colliding candidates before the winner included)
+            fa.count_inline = 1;
+            launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
+        } else {       // many workgroups, the last one to arrive writes the result and the ticket (rp_kernels.h: rp_select_kernel)
+            fa.count_inline = (skip_eval || collision_level(ka) > 0) ? 1 : 0;   // (no collision test: nothing to count)
+            const int sgrid = (int)std::max<int64_t>(16, std::min<int64_t>((count + RP_SEL_SLICE - 1) / RP_SEL_SLICE, (int64_t)c->num_cus));
+            launch_block(c, (const void *)rp_select_kernel, sgrid, RP_SEL_THREADS, 0, &fa, sizeof(fa));
+        }
         if (c->timing) c->t_sum[5] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count();
     }
-    if (!small) {   // big batches: many-block count, then refresh the host mirror of the counter
-        const int cgrid = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, (int64_t)c->num_cus * 4));
-        hipLaunchKernelGGL(rp_count_before_kernel, dim3(cgrid), dim3(RP_BLOCK), 0, c->stream, ka.status, ka.cost, count,
-                           ka.cand_begin, &drb->r, 0.0, (int64_t)0, 0, &drb->n_before);
-        HIP_TRY(c, hipMemcpyAsync(&hrb_host->n_before, &drb->n_before, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    }
-    if (winner_pass) {
+    if (winner_pass && !lazy_done) {
         // nothing was materialised: re-evaluate the winner with its state block written to the host mirror
         KArgs kw = ka;
         kw.single_index = &drb->r.best_index;
@@ -636,6 +812,7 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         kw.cost = &drb->w_cost;
         kw.states = reinterpret_cast<double *>(hrb_dev + 1);
         kw.row_stride = n;   // the block behind the result header is compact
+        kw.tail_split = 0;
         kw.coeffs = nullptr;
         kw.partials = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
@@ -648,8 +825,8 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
     }
     HIP_TRY(c, hipGetLastError());
     const auto tp1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    bool done = false;
-    if (ticket) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
+    bool done = lazy_done;
+    if (ticket && !done) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
         const volatile unsigned long long *flag = &hrb_host->seq;
         const auto t_start = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
@@ -744,6 +921,11 @@ extern "C" {
 
 int rp_abi_version(void) { return RP_ABI_VERSION; }
 
+#ifndef RP_SRC_HASH
+#define RP_SRC_HASH "unknown"
+#endif
+const char *rp_source_hash(void) { return RP_SRC_HASH; }
+
 int rp_create(rp_ctx **out, int device) {
     if (!out) return RP_EINVAL;
     *out = nullptr;
@@ -763,6 +945,13 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipEventCreate(&c->ev1));
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_sel_scratch, RP_SEL_SCRATCH * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMemset(c->d_sel_scratch, 0, RP_SEL_SCRATCH * sizeof(unsigned long long)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lazy_ctl, sizeof(LazyCtl)));
+    HIP_TRY(c, hipMemset(c->d_lazy_ctl, 0, sizeof(LazyCtl)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lazy_lists, kLazyListWords * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_lazy_hist, (RP_LAZY_BINS + 1) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t)));
 #if defined(RP_STAMPS) || defined(RP_TIMELINE)
     HIP_TRY(c, hipMalloc((void **)&c->d_debug, (32 + 2 * 4096) * sizeof(unsigned long long)));
     HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
@@ -782,7 +971,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_grid, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
-                   c->d_pair_hdr, c->d_pair_hdr_one};
+                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_sel_scratch, c->d_lazy_ctl, c->d_lazy_lists, c->d_lazy_hist, c->d_lazy_states};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -795,6 +984,8 @@ void rp_destroy(rp_ctx *c) {
 }
 
 const char *rp_last_error(const rp_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int rp_last_path(const rp_ctx *c) { return c ? c->last_lazy : 0; }
 
 int rp_set_profiling(rp_ctx *c, int enable) {
     if (!c) return RP_EINVAL;
@@ -1101,14 +1292,16 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     std::memcpy(hs + g->nT + g->nL, g->D, sizeof(double) * g->nD);
     std::memcpy(hs + nd, g->traj_len, sizeof(int32_t) * g->nT);
     const bool grids_inline = sbytes <= sizeof(c->kargs_g.grid) && !std::getenv("RP_AMD_NO_INLINE_GRIDS");
+    c->grids_pending = false;
     if (grids_inline) {   // the grids ride in the kernarg segment of the launches: no copy on the stream
         std::memcpy(c->kargs_g.grid, c->h_stage, sbytes);
+        std::memcpy(c->kargs_gl.grid, c->h_stage, sbytes);
         c->staged.assign(c->h_stage, c->h_stage + sbytes);   // (host copy: the winner's coefficients are worked out from it)
         c->staged_on_device = false;
     } else if (sbytes && (!c->staged_on_device || c->staged.size() != sbytes || std::memcmp(c->staged.data(), c->h_stage, sbytes) != 0)) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
         c->staged.assign(c->h_stage, c->h_stage + sbytes);
-        c->staged_on_device = true;
+        c->staged_on_device = false;
+        c->grids_pending = true;   // (run_pipeline knows the launch path: rp_lon_kernel's launch block, or a copy)
     }
 
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)count)) != RP_OK) return rc;
@@ -1206,10 +1399,10 @@ int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
     if (first < 0 || count < 0 || first + count > c->last.count || (count && !states))
         return fail(c, RP_EINVAL, "rp_fetch_states: range");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int n = c->last.N + 1, ns = c->last.row_stride;
+    const int n = c->last.N + 1, ns = c->last.row_stride, tail = c->last.tail_split;
     const size_t blk = (size_t)RP_N_ARRAYS * (size_t)n;
     if (!count) return RP_OK;
-    if (ns == n) {
+    if (ns == n && !tail) {
         HIP_TRY(c, hipMemcpy(states, c->d_states + blk * first, sizeof(double) * blk * count, hipMemcpyDeviceToHost));
         return RP_OK;
     }
@@ -1224,7 +1417,7 @@ int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
         const size_t total = blk * (size_t)cnt;
         const int grid = (int)std::min<size_t>((total + 255) / 256, (size_t)c->num_cus * 16);
         hipLaunchKernelGGL(rp_compact_rows_kernel, dim3(grid), dim3(256), 0, c->stream,
-                           c->d_states + (size_t)RP_N_ARRAYS * (size_t)ns * (size_t)(first + at), c->d_compact, n, ns, inv_n,
+                           c->d_states + (size_t)state_block_doubles(ns, tail) * (size_t)(first + at), c->d_compact, n, ns, tail, inv_n,
                            (unsigned long long)total);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipMemcpyAsync(states + blk * (size_t)at, c->d_compact, sizeof(double) * total, hipMemcpyDeviceToHost, c->stream));
@@ -1253,6 +1446,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.cost = &drb->w_cost;
     kw.states = reinterpret_cast<double *>(c->d_result + sizeof(ResultBlock));
     kw.row_stride = n;
+    kw.tail_split = 0;
     kw.coeffs = nullptr;
     kw.partials = nullptr;
     // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own

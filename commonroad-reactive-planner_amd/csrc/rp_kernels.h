@@ -50,7 +50,7 @@ struct KArgs {
     double c_yaw;   // 1e5 / dt
     double c_kdot;  // dt * v_delta_max / wheelbase
     // cost
-    int32_t cost_kind, has_speed, has_s, pad0_;
+    int32_t cost_kind, has_speed, has_s, partials_cap;   // partials_cap: slots per array of the block partials (see Partials)
     double w_a, desired_speed, desired_d, desired_s;
     // grids (device pointers) or explicit polynomials
     int32_t nT, nL, nD, grids_inline;   // grids_inline: [T | L | D | traj_len] travel in the kernarg segment (KArgsG), not in device memory
@@ -64,6 +64,16 @@ struct KArgs {
     // candidate range: global indices [cand_begin, cand_begin + count)
     int64_t cand_begin, count;
     const int64_t *single_index;  // != nullptr: evaluate exactly this one (global) candidate -> slot 0
+    // list mode (a round of the cost-ordered collision stage; two-kernel path, one wavefront per candidate): slot s evaluates the
+    // global candidate index_list[s] for s < min(*list_count, list_cap); status goes to the candidate's own slot of `status`, the
+    // cost there (written by the first pass) is what the block partial carries, state rows go to slot s of `states`
+    const int32_t *index_list;
+    const uint32_t *list_count;
+    int32_t list_cap;
+    int32_t tail_split;           // 0: state rows of row_stride doubles each.  M > 0 (a multiple of 16, M < N + 1 <= M + 8; two-kernel path, 16 lanes
+                                  // per candidate): rows hold the first M steps (row_stride == M), the last N + 1 - M steps of rows 2q and
+                                  // 2q + 1 share 128-byte line q behind the rows -- see state_offset
+    struct LazyCtl *lazy_ctl;     // first pass of the cost-ordered collision stage: workgroup 0 clears the stage's control block
     // tables
     const double *tables;  // [TB_ROWS][n_ref]
     int32_t n_ref, search_iters, n_buckets, table_words;
@@ -72,7 +82,8 @@ struct KArgs {
     // single-launch variant: the part of the table block a launch can touch (rp_host.hip: table_window), staged instead of the
     // whole block; win_n == 0: the whole block.  Items whose s lies in [win_s_lo, win_s_hi) read staged entries only; any other
     // item makes its workgroup stage the whole block and start over.
-    int32_t win_k0, win_n, win_shift, win_b0, win_nb, pad3_;   // vertices [win_k0, win_k0 + win_n), win_n = 1 << win_shift; bucket entries [win_b0, win_b0 + win_nb)
+    int32_t win_k0, win_n, win_shift, win_b0, win_nb;   // vertices [win_k0, win_k0 + win_n), win_n = 1 << win_shift; bucket entries [win_b0, win_b0 + win_nb)
+    int32_t publish_grids;   // rp_lon_kernel: workgroup 0 copies the grids of its kernarg segment to T (device memory) for the kernels behind it
     double win_s_lo, win_s_hi;
     double pos_first, pos_last;   // ref_pos[0], ref_pos[n_ref - 1]
     ObsTables obs;         // obstacle table descriptor, by value: a pointer to a device copy costs a dependent
@@ -90,7 +101,7 @@ struct KArgs {
     double *cost;      // [count]
     double *states;    // [count][14][row_stride] (MAT) or nullptr
     double *coeffs;    // [count][13] or nullptr (lon 6, lat 6, lat_T)
-    struct BlockPartial *partials;  // [gridDim.x] or nullptr
+    void *partials;    // block partials (Partials, partials_cap slots per array; slot = blockIdx.x) or nullptr
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
     unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
     unsigned long long seq_value;
@@ -109,6 +120,17 @@ struct KArgsG {
     double grid[RP_GRID_INLINE];
 };
 static_assert(sizeof(KArgsG) <= 4096 - 256, "kernarg segment: at most 4 KB including the hidden arguments");
+// rp_lon_kernel -- the first launch of the two-kernel path of a large batch -- takes room for larger grids (cfg3: 126 doubles +
+// 31 int32, cfg5: 301 + 99): a 100-us step does not feel the microsecond a 3.8-KB kernarg segment adds to its first launch, a 5-us
+// host-to-device copy of the grids in front of every step it does.  Its workgroup 0 also writes them to device memory
+// (KArgs.publish_grids), where the kernels behind it -- whose launches stay small -- read them.
+constexpr int RP_GRID_INLINE_L = (int)((4096 - 256 - sizeof(KArgs)) / 8);   // what is left of a 4-KB segment behind the hidden arguments
+static_assert(RP_GRID_INLINE_L >= 360, "cfg5's grids (301 doubles + 99 int32) ride in rp_lon_kernel's launch block");
+struct KArgsGL {
+    KArgs k;
+    double grid[RP_GRID_INLINE_L];
+};
+static_assert(sizeof(KArgsGL) <= 4096 - 256, "kernarg segment: at most 4 KB including the hidden arguments");
 
 // base of the launch's grids: [T | L | D | traj_len]
 __device__ __forceinline__ const double *grid_base(const KArgs &a) {
@@ -122,6 +144,7 @@ __device__ __forceinline__ const double *grid_base(const KArgs &a) {
 // fields of one step of a longitudinal profile
 enum { PF_S = 0, PF_SD, PF_SDD, PF_INV_SD, PF_TH_REF, PF_KR, PF_KRD, PF_PX, PF_PY, PF_NX, PF_NY, PF_INDOM, PF_NEAR, PF_NEAR_S, PF_COS_REF, PF_SIN_REF,
        PF_FIELDS };
+#define PF_STRIDE (PF_FIELDS + 1)   // item-major profile rows in LDS: [pair][step][PF_STRIDE] (see load_profile_item)
 // PF_COS_REF / PF_SIN_REF: cos / sin of theta_ref -- with cos / sin of theta_cl known algebraically (atan branch) the heading's
 // cos / sin (ego rectangle of the collision query, direction of the horizon extension) need no transcendental per candidate
 // PF_NEAR: bit pattern of a 64-bit mask, bit j = dynamic obstacle j can touch SOME candidate of the pair at this step
@@ -134,11 +157,79 @@ struct PairHdr {
     int32_t L;           // number of valid steps (traj_len), clamped to [1, N+1]
 };
 
-struct BlockPartial {
-    double best_cost;
-    int64_t best_index;  // global index, -1 none
-    int64_t n_feasible, n_collision;
-    int64_t reasons[8];
+// Where element (row, step i) of a candidate's state block lies inside the block in device memory, and the block's size.
+//   rows of `ns` doubles (tail == 0): N + 1 rounded up to whole 128-byte lines where rows are stored straight to memory -- every
+//       store instruction of a 16-lane group then writes whole lines, at the price of the padding: 112 doubles for the 101 steps of
+//       N = 100, 11 % of the HBM stream of cfg4 / cfg5;
+//   split tail (tail == M): the step blocks that are full, [14][M], then the partial one -- at most 8 steps -- two rows to a line:
+//       line q = row 2q (doubles 0 .. 7) | row 2q + 1 (doubles 8 .. 15).  N = 100: 14 * 96 + 7 * 16 = 1 456 doubles for 1 414.
+// rp_fetch_states / the result block hand out compact [14][N + 1] blocks either way.
+__host__ __device__ __forceinline__ int state_block_doubles(int ns, int tail) { return tail ? RP_N_ARRAYS * tail + (RP_N_ARRAYS / 2) * 16 : RP_N_ARRAYS * ns; }
+__host__ __device__ __forceinline__ int state_offset(int row, int i, int ns, int tail) {
+    if (tail == 0 || i < tail) return row * ns + i;
+    return RP_N_ARRAYS * tail + (row >> 1) * 16 + (row & 1) * 8 + (i - tail);
+}
+
+// One partial per workgroup of the evaluation kernel: its best (cost, index) and its counters.  Three arrays in one allocation
+// (cap slots each) instead of an array of structs: the selection epilogue of a large batch runs in many workgroups, each of which
+// reads ALL (cost, index) pairs -- 16 contiguous bytes per partial -- but only its own slice of the counters.
+//   cost [cap] f64 | index [cap] i64 (global index, -1 none) | counters [cap][RP_PARTIAL_CNT] u32: n_feasible, n_collision, reasons[8]
+#define RP_PARTIAL_CNT 10
+struct Partials {
+    double *cost;
+    long long *idx;
+    uint32_t *cnt;
+};
+__host__ __device__ __forceinline__ Partials partials_at(void *base, int cap, int first = 0) {
+    Partials p;
+    p.cost = reinterpret_cast<double *>(base) + first;
+    p.idx = reinterpret_cast<long long *>(reinterpret_cast<double *>(base) + cap) + first;
+    p.cnt = reinterpret_cast<uint32_t *>(reinterpret_cast<double *>(base) + 2 * (size_t)cap) + (size_t)first * RP_PARTIAL_CNT;
+    return p;
+}
+#define RP_PARTIAL_BYTES (16 + 4 * RP_PARTIAL_CNT)   // per slot
+
+// ------------------------------------------------------------------------------------------------
+// Cost-ordered ("lazy") collision stage of production-mode plans on large batches -- the reference's own order of work
+// (ReactivePlanner._check_collisions, reactive_planner.py:1031-1062: candidates in ascending cost, stop at the first one that is
+// free; TrajectoryBundle.sort, trajectories.py:502-510):
+//   pass 1   rp_eval_kernel without the collision query: kinematics + cost of every candidate;
+//   gather   rp_lazy_hist_kernel + rp_lazy_gather_kernel: three cost thresholds e_0 < e_1 < e_2 and, for each, the list of the
+//            feasible candidates with e_(l-1) <= cost < e_l (exact threshold sets, any order);
+//   round l  rp_eval_kernel in list mode over list l WITH the query (state rows kept), rp_finalize_kernel picks the cheapest free
+//            candidate of the list: every cheaper feasible candidate is in lists 0 .. l and has been found colliding, so it is the
+//            winner, and infeasible_count_collision = candidates of the earlier rounds + colliding ones before it in this list.
+//            No free candidate: next round; lists exhausted, or a list over its capacity: the eager kernel decides (rp_host.hip).
+// Thresholds: a histogram of the costs over bins that are fine next to the cheapest cost c* and coarse far from it -- bin of a
+// cost c = position of k(c) - k(c*) on a logarithmic scale with 16 steps per octave, k = the order-preserving integer image of a
+// double (cost_key), so that a bin is an exact integer interval of keys -- built by every workgroup of rp_lazy_hist_kernel over its
+// slice of the batch; the last workgroup to arrive takes the prefix sums and the first bin edges behind 128, 1 024 and 8 192
+// candidates.  rp_lazy_gather_kernel appends every feasible candidate below an edge to the list of its level.
+// ------------------------------------------------------------------------------------------------
+#define RP_LAZY_LEVELS 3
+#define RP_LAZY_BINS 1024
+struct LazyCtl {   // 20 eight-byte words, cleared by pass 1
+    unsigned long long totals[RP_PARTIAL_CNT];   // counters of pass 1 (n_feasible, -, reasons[8]), summed by the histogram kernel's workgroups
+    uint32_t count[RP_LAZY_LEVELS];              // candidates appended to the list of each level
+    uint32_t overflow;                           // bit l: the candidates of level l do not fit its list (the level is not conclusive)
+    uint32_t checked, found;                     // candidates of the rounds run so far / colliding ones among them
+    unsigned long long edge[RP_LAZY_LEVELS];     // level l: feasible candidates with edge[l-1] <= k(cost) - key_min < edge[l]
+    unsigned long long key_min;                  // k(c*), c* = cheapest feasible cost of the batch
+    uint32_t expect[RP_LAZY_LEVELS], pad_[3];    // candidates of each level by the histogram
+};
+static_assert(sizeof(LazyCtl) == 160, "LazyCtl layout");
+
+struct GatherArgs {
+    const uint32_t *status;      // [count]
+    const double *cost;          // [count]
+    void *partials;              // Partials of pass 1
+    int32_t *lists;              // list of level l at lists + off[l], cap[l] entries (global candidate indices)
+    LazyCtl *ctl;
+    uint32_t *hist;              // [RP_LAZY_BINS + 1] global histogram + arrival ticket, zero between launches
+    int64_t count, cand_begin;
+    int32_t partials_cap, partials_first, n_partials, pad_;
+    int32_t cap[RP_LAZY_LEVELS], off[RP_LAZY_LEVELS];
+    uint32_t target[RP_LAZY_LEVELS], pad2_;   // cumulative number of candidates each level is meant to reach
 };
 
 struct DevResult {
@@ -302,14 +393,22 @@ struct FinArgs {
     const uint32_t *status;      // [count]
     const double *cost;          // [count]
     const double *states;        // [count][14][N+1] or nullptr
-    const BlockPartial *partials;
+    void *partials;              // Partials of partials_cap slots per array, read from slot partials_first on
     FinalizeOut *dev_out, *host_out;
     int64_t count, cand_begin;
     unsigned long long seq;      // completion ticket for the host (0: none)
     int32_t N, n_partials, count_inline, copy_states;
     int32_t row_stride;          // doubles between the rows of `states`
+    int32_t tail_split;          // layout of the state blocks (state_offset)
     uint32_t inv_n;              // floor(2^32 / (N + 1)) + 1: k / (N + 1) == umulhi(k, inv_n) for k < 14 (N + 1)
+    int32_t partials_cap, partials_first;
     unsigned long long *debug;   // diagnostic build (-DRP_STAMPS): s_memtime stamps of the phases, slots 26..31
+    unsigned long long *scratch; // rp_select_kernel: [RP_SEL_SCRATCH] zero between launches (counter totals, count, arrival ticket)
+    // a round of the cost-ordered collision stage (rp_finalize_kernel; see LazyCtl): the candidates of the round, its control block
+    const int32_t *list;
+    const uint32_t *list_count;
+    struct LazyCtl *lazy;
+    int32_t list_cap, level;
 };
 #ifdef RP_STAMPS
 #define RP_FSTAMP(k)                                                                             \
@@ -330,6 +429,39 @@ __device__ __forceinline__ unsigned long long cost_key(double c) {
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
+// system-scope store into the pinned host mirror of the result block: past the L2, no write-back needed afterwards
+__device__ __forceinline__ void result_host_store(void *p, unsigned long long v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Result header, one 8-byte word per lane (lanes 0 .. 43 of the calling workgroup), to the device block and the host mirror:
+// rp_result (28 words) | n_before | w_status, pad | w_cost | w_coeffs[13] (coefficients, lat_T: filled in by the host)
+__device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, FinalizeOut *host_out, int tid, int64_t widx, double wcost, int64_t count,
+                                                    const unsigned int *c32 /* [10] n_feasible, n_collision, reasons[8] */,
+                                                    unsigned long long before, bool rows_here,
+                                                    const unsigned long long *extra = nullptr /* [4]: words 31 .. 34 (w_coeffs[0..3]) */) {
+    constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
+    static_assert(words == 44 && sizeof(rp_result) == 28 * 8, "FinalizeOut layout");
+    if (tid < words) {
+        const int k = tid;
+        const bool have = widx >= 0;
+        const unsigned long long nanb = 0x7ff8000000000000ull;
+        const unsigned long long costb = have ? (unsigned long long)__double_as_longlong(wcost) : nanb;
+        const int ci = k == 3 ? 0 : (k == 5 ? 1 : k - 4);   // counter behind words 3, 5, 6..13
+        unsigned long long v = nanb;
+        if (k == 0) v = (unsigned long long)widx;
+        else if (k == 1 || k == 30) v = costb;
+        else if (k == 2) v = (unsigned long long)count;
+        else if (k == 3 || k == 5 || (k >= 6 && k < 14)) v = (unsigned long long)c32[ci];
+        else if (k == 4 || k == 28) v = before;
+        else if (k == 27) v = 0ull;                                  // kernel_ms
+        else if (k == 29) v = have ? (unsigned long long)(RP_LABEL_FEASIBLE | (rows_here ? 0u : RP_WSTATUS_ROWS_ON_HOST)) : 0ull;   // w_status | pad
+        else if (extra && k >= 31 && k < 35) v = extra[k - 31];
+        reinterpret_cast<unsigned long long *>(dev_out)[k] = v;
+        result_host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
+    }
+}
+
 // Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).  One workgroup that lives a few microseconds: what it costs is
 // (a) memory round trips -- the winner's state rows are requested as soon as the winner is known and travel while the
 // colliding candidates before it are counted -- and (b) the LENGTH of its instruction chains (a lone wavefront issues an
@@ -347,13 +479,15 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     double bc = 0.0;
     long long bi = -1;
     unsigned int cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // (a thread holds a few partials of < 2^23 candidates each)
+    const Partials pp = partials_at(a.partials, a.partials_cap, a.partials_first);
     for (int k = tid; k < n_partials; k += RP_FIN_THREADS) {
-        const BlockPartial p = a.partials[k];
-        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
-        cnt[0] += (unsigned int)p.n_feasible;
-        cnt[1] += (unsigned int)p.n_collision;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) cnt[2 + r] += (unsigned int)p.reasons[r];
+        const double pc = pp.cost[k];
+        const long long pi = pp.idx[k];
+        const uint2 *pq = reinterpret_cast<const uint2 *>(pp.cnt + (size_t)k * RP_PARTIAL_CNT);   // (40-byte rows: 8-byte aligned)
+        const uint2 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
+        if (pi >= 0 && better(pc, (int64_t)pi, bc, (int64_t)bi)) { bc = pc; bi = pi; }
+        cnt[0] += q0.x; cnt[1] += q0.y; cnt[2] += q1.x; cnt[3] += q1.y; cnt[4] += q2.x;
+        cnt[5] += q2.y; cnt[6] += q3.x; cnt[7] += q3.y; cnt[8] += q4.x; cnt[9] += q4.y;
     }
     if (tid == 0) sh_before = 0;
     if (tid < 10) sh_c32[tid] = 0;
@@ -371,22 +505,26 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     for (int w = 1; w < RP_FIN_THREADS / 64; ++w)
         if (sh_idx[w] >= 0 && better(sh_cost[w], (int64_t)sh_idx[w], wcost, (int64_t)widx_)) { wcost = sh_cost[w]; widx_ = sh_idx[w]; }
     const int64_t widx = (int64_t)widx_;
-    const bool have = widx >= 0;
     const int n = a.N + 1;
     // the winner's state rows are requested now: their round trip overlaps the counter sums and the count below
     constexpr int kRowsPerThread = 4;   // covers 14 (N+1) <= 1024 doubles in registers; longer blocks loop at the end
     double wrow[kRowsPerThread];
     const bool want_rows = a.copy_states && widx >= 0;
     const int ns = a.row_stride;
-    const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * RP_N_ARRAYS * (size_t)ns : nullptr;
-    auto padded = [&](int k) -> int {   // element k of the compact [14][N + 1] block inside the [14][row_stride] one
+    const bool lazy = a.list != nullptr;   // a round of the cost-ordered collision stage: the candidates are the round's list, their
+                                           // state rows lie by list slot (found in the count loop below, requested behind it)
+    __shared__ int sh_wslot;
+    if (tid == 0) sh_wslot = 0;
+    const int blk = state_block_doubles(ns, a.tail_split);
+    const double *wsrc = (want_rows && !lazy) ? a.states + (size_t)(widx - a.cand_begin) * (size_t)blk : nullptr;
+    auto padded = [&](int k) -> int {   // element k of the compact [14][N + 1] block inside the block in device memory
         const int row = (int)__umulhi((uint32_t)k, a.inv_n);
-        return k + row * (ns - n);
+        return state_offset(row, k - row * n, ns, a.tail_split);
     };
 #pragma unroll
     for (int q = 0; q < kRowsPerThread; ++q) {
         const int k = tid + q * RP_FIN_THREADS;
-        wrow[q] = (want_rows && k < RP_N_ARRAYS * n) ? wsrc[padded(k)] : 0.0;
+        wrow[q] = (want_rows && !lazy && k < RP_N_ARRAYS * n) ? wsrc[padded(k)] : 0.0;
     }
     // counters: wavefront sums through 32-bit DPP adds, one LDS add per wavefront and counter
 #pragma unroll
@@ -403,8 +541,10 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     __syncthreads();
     RP_FSTAMP(26);   // winner known, rows requested
     // colliding feasible samples that sort before the winner (reactive_planner.py:1031-1046)
-    const int ccount = a.count_inline ? (int)a.count : 0;   // count_inline: at most RP_FINALIZE_MAX
-    if (ccount > 0 && sh_c32[1] > 0) {
+    int lcount = 0;
+    if (lazy) { const uint32_t lc = *a.list_count; lcount = (int)(lc < (uint32_t)a.list_cap ? lc : (uint32_t)a.list_cap); }
+    const int ccount = lazy ? lcount : (a.count_inline ? (int)a.count : 0);   // count_inline: at most RP_FINALIZE_MAX
+    if (ccount > 0 && (lazy || sh_c32[1] > 0)) {
         // status and cost of kUnroll candidates per lane are requested together (both unconditionally, 12 B per candidate):
         // one candidate per trip with the cost load behind the label test was a chain of dependent round trips
         constexpr int kUnroll = 8;
@@ -412,47 +552,59 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
         for (int i0 = tid; i0 < ccount; i0 += RP_FIN_THREADS * kUnroll) {
             uint32_t st[kUnroll];
             double cs[kUnroll];
+            int64_t gi[kUnroll];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const int i = i0 + u * RP_FIN_THREADS, ic = i < ccount ? i : ccount - 1;
-                st[u] = a.status[ic];
-                cs[u] = a.cost[ic];
+                const int64_t fs = lazy ? (int64_t)a.list[ic] - a.cand_begin : (int64_t)ic;
+                gi[u] = a.cand_begin + fs;
+                st[u] = a.status[fs];
+                cs[u] = a.cost[fs];
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 const int i = i0 + u * RP_FIN_THREADS;
                 const bool coll = i < ccount && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
-                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
+                nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && gi[u] < widx))) ? 1 : 0;
+                if (lazy && i < ccount && gi[u] == widx) sh_wslot = i;   // (list entries are distinct)
             }
         }
         if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
         __syncthreads();   // (uniform: sh_c32 is final)
     }
-    RP_FSTAMP(27);   // count done
-    FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
-    auto host_store = [](void *p, unsigned long long v) {   // system scope: past the L2, no write-back needed afterwards
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    };
-    {   // result header, one 8-byte word per lane: rp_result (28 words) | n_before | w_status, pad | w_cost | w_coeffs[13]
-        constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
-        static_assert(words == 44 && sizeof(rp_result) == 28 * 8, "FinalizeOut layout");
-        if (tid < words) {
-            const int k = tid;
-            const unsigned long long nanb = 0x7ff8000000000000ull;
-            const unsigned long long costb = have ? (unsigned long long)__double_as_longlong(wcost) : nanb;
-            const int ci = k == 3 ? 0 : (k == 5 ? 1 : k - 4);   // counter behind words 3, 5, 6..13
-            unsigned long long v = nanb;                        // coefficients, lat_T: filled in by the host
-            if (k == 0) v = (unsigned long long)widx;
-            else if (k == 1 || k == 30) v = costb;
-            else if (k == 2) v = (unsigned long long)a.count;
-            else if (k == 3 || k == 5 || (k >= 6 && k < 14)) v = (unsigned long long)sh_c32[ci];
-            else if (k == 4 || k == 28) v = sh_before;
-            else if (k == 27) v = 0ull;                                  // kernel_ms
-            else if (k == 29) v = have ? (unsigned long long)(RP_LABEL_FEASIBLE | (want_rows ? 0u : RP_WSTATUS_ROWS_ON_HOST)) : 0ull;   // w_status | pad
-            reinterpret_cast<unsigned long long *>(dev_out)[k] = v;
-            host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
+    __shared__ unsigned long long sh_extra[4];
+    if (lazy) {
+        // counters of the batch come from pass 1 (the control block); the collisions are the ones FOUND so far, and the candidates
+        // of the earlier rounds -- all colliding -- sort before this round's winner
+        LazyCtl *const lz = a.lazy;
+        __syncthreads();
+        const unsigned int round_coll = sh_c32[1];
+        const unsigned int checked0 = lz->checked, found0 = lz->found;
+        __syncthreads();
+        if (tid < RP_PARTIAL_CNT) sh_c32[tid] = tid == 1 ? found0 + round_coll : (unsigned int)lz->totals[tid];
+        if (tid == 0) {
+            sh_before += checked0;
+            const unsigned int checked1 = checked0 + (unsigned int)lcount, found1 = found0 + round_coll;
+            if (widx < 0) { lz->checked = checked1; lz->found = found1; }   // this round failed: its candidates all collide
+            sh_extra[0] = (unsigned long long)lz->count[0] | ((unsigned long long)lz->count[1] << 32);
+            sh_extra[1] = (unsigned long long)lz->count[2] | ((unsigned long long)lz->overflow << 32);
+            sh_extra[2] = (unsigned long long)checked1 | ((unsigned long long)found1 << 32);
+            sh_extra[3] = lz->totals[0];
+        }
+        __syncthreads();
+        if (want_rows) {   // the winner's rows, by its slot in the round's list
+            wsrc = a.states + (size_t)sh_wslot * (size_t)blk;
+#pragma unroll
+            for (int q = 0; q < kRowsPerThread; ++q) {
+                const int k = tid + q * RP_FIN_THREADS;
+                wrow[q] = k < RP_N_ARRAYS * n ? wsrc[padded(k)] : 0.0;
+            }
         }
     }
+    RP_FSTAMP(27);   // count done
+    FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
+    auto host_store = [](void *p, unsigned long long v) { result_host_store(p, v); };
+    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows, lazy ? sh_extra : nullptr);
     RP_FSTAMP(28);   // header stored
     if (want_rows) {   // winner's state block straight from the materialised states
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
@@ -477,8 +629,356 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
 }
 
 __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const FinArgs a) {
-    touch_kernargs<2>();
+    touch_kernargs<3>();
     finalize_body(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection epilogue of a LARGE batch (more than RP_FINALIZE_MAX candidates): the same result as rp_finalize_kernel, in one
+// launch of many workgroups instead of fold -> one-workgroup epilogue -> count kernel -> copy of the count -> stream sync.
+//   every workgroup   reduces ALL (cost, index) partials -- 16 contiguous bytes each -- to the winner (the same in all of them),
+//                     sums the counters of ITS slice of the partials and counts the colliding candidates of ITS slice of the
+//                     batch that sort before the winner (lazy semantics of _check_collisions, reactive_planner.py:1031-1046):
+//                     device-scope atomic adds into a[scratch];
+//   workgroup 0       also copies the winner's state rows to the result block (device + host mirror);
+//   the LAST one      to arrive (ticket = device-scope atomic counter behind a release fence: the "last block" pattern -- no
+//                     workgroup ever waits for another) reads the totals, writes the result header and the completion ticket the
+//                     host spins on, and clears the scratch words for the next launch.
+// ------------------------------------------------------------------------------------------------
+#define RP_SEL_THREADS 256
+#define RP_SEL_SCRATCH 16   // 8-byte words: [0..9] counter totals | [10] colliding before the winner | [11] arrival ticket
+#define RP_SEL_SLICE 2048   // candidates per workgroup (one trip of the count loop: 8 per lane, requested together with the partials)
+// What passes between the workgroups are the totals, and those are device-scope atomic adds: complete at the device's point of
+// coherence once acknowledged.  A workgroup therefore only WAITS for its adds (s_waitcnt) before it takes its ticket -- no
+// release / acquire fences (each an L2 write-back or invalidate, a microsecond or two on a chain that is nothing but round trips).
+__global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs a) {
+    touch_kernargs<3>();
+    __shared__ double sh_cost[RP_SEL_THREADS / 64];
+    __shared__ long long sh_idx[RP_SEL_THREADS / 64];
+    __shared__ unsigned int sh_c32[RP_PARTIAL_CNT];
+    __shared__ unsigned int sh_nb, sh_ticket;
+    __shared__ unsigned long long sh_before;
+    const int tid = threadIdx.x, nwg = (int)gridDim.x, w = (int)blockIdx.x;
+    const int n_partials = a.n_partials;
+    const Partials pp = partials_at(a.partials, a.partials_cap, a.partials_first);
+    // -- everything this workgroup reads is requested up front, one round trip: its slice of the batch (status + cost: the count of
+    //    the colliding candidates before the winner needs the winner only for the comparison), all (cost, index) partials
+    constexpr int kUnroll = RP_SEL_SLICE / RP_SEL_THREADS;
+    const int ccount = a.count_inline ? (int)a.count : 0;   // (< 2^31: checked by the host)
+    const int per_c = (ccount + nwg - 1) / nwg, i_lo = w * per_c, i_hi = i_lo + per_c < ccount ? i_lo + per_c : ccount;
+    uint32_t st[kUnroll];
+    double cs[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+        const int i = i_lo + tid + u * RP_SEL_THREADS, ic = i < i_hi ? i : (i_hi > 0 ? i_hi - 1 : 0);
+        st[u] = ccount > 0 ? a.status[ic] : 0u;
+        cs[u] = ccount > 0 ? a.cost[ic] : 0.0;
+    }
+    double bc = 0.0;
+    long long bi = -1;
+    for (int k = tid; k < n_partials; k += RP_SEL_THREADS) {
+        const double pc = pp.cost[k];
+        const long long pi = pp.idx[k];
+        if (pi >= 0 && better(pc, (int64_t)pi, bc, (int64_t)bi)) { bc = pc; bi = pi; }
+    }
+    // counters of this workgroup's slice of the partials
+    unsigned int cnt[RP_PARTIAL_CNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int per_p = (n_partials + nwg - 1) / nwg, k0 = w * per_p, k1 = k0 + per_p < n_partials ? k0 + per_p : n_partials;
+    for (int k = k0 + tid; k < k1; k += RP_SEL_THREADS) {
+        const uint2 *pq = reinterpret_cast<const uint2 *>(pp.cnt + (size_t)k * RP_PARTIAL_CNT);
+        const uint2 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
+        cnt[0] += q0.x; cnt[1] += q0.y; cnt[2] += q1.x; cnt[3] += q1.y; cnt[4] += q2.x;
+        cnt[5] += q2.y; cnt[6] += q3.x; cnt[7] += q3.y; cnt[8] += q4.x; cnt[9] += q4.y;
+    }
+    if (tid < RP_PARTIAL_CNT) sh_c32[tid] = 0;
+    if (tid == 0) sh_nb = 0;
+    // -- the winner: the same in every workgroup
+    wave_min_pair(bc, bi);
+    if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
+    __syncthreads();
+    double wcost = sh_cost[0];
+    long long widx_ = sh_idx[0];
+#pragma unroll
+    for (int q = 1; q < RP_SEL_THREADS / 64; ++q)
+        if (sh_idx[q] >= 0 && better(sh_cost[q], (int64_t)sh_idx[q], wcost, (int64_t)widx_)) { wcost = sh_cost[q]; widx_ = sh_idx[q]; }
+    const int64_t widx = (int64_t)widx_;
+    const int n = a.N + 1, ns = a.row_stride;
+    // -- the winner's state rows travel while the slices are summed -- in EVERY workgroup (a few KB from the L2 each): whichever
+    //    arrives last has them at hand and sends rows and header to the host in one batch, with one wait for the acknowledgements
+    //    (rows by workgroup 0 ahead of its ticket + header by the last one: two waits on the same chain)
+    constexpr int kRowsPerThread = 4;
+    double wrow[kRowsPerThread];
+    const bool want_rows = a.copy_states && widx >= 0;
+    const bool my_rows = want_rows;
+    const double *const wsrc = want_rows ? a.states + (size_t)(widx - a.cand_begin) * (size_t)state_block_doubles(ns, a.tail_split) : nullptr;
+    auto padded = [&](int k) -> int { const int row = (int)__umulhi((uint32_t)k, a.inv_n); return state_offset(row, k - row * n, ns, a.tail_split); };
+#pragma unroll
+    for (int q = 0; q < kRowsPerThread; ++q) {
+        const int k = tid + q * RP_SEL_THREADS;
+        wrow[q] = (my_rows && k < RP_N_ARRAYS * n) ? wsrc[padded(k)] : 0.0;
+    }
+    if (__any(k0 + tid < k1)) {   // (wave-uniform: wavefronts without a partial skip the sums)
+#pragma unroll
+        for (int r = 0; r < RP_PARTIAL_CNT; ++r) {
+            unsigned int t = cnt[r];
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);
+            if ((tid & 63) == 63 && t) atomicAdd(&sh_c32[r], t);
+        }
+    }
+    // -- colliding feasible candidates of this workgroup's slice of the batch that sort before the winner (reactive_planner.py:1031-1046)
+    {
+        int nloc = 0;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = i_lo + tid + u * RP_SEL_THREADS;
+            const bool coll = i < i_hi && RP_STATUS_LABEL(st[u]) == RP_LABEL_INFEASIBLE_COLLISION;
+            nloc += (coll && (widx < 0 || cs[u] < wcost || (cs[u] == wcost && a.cand_begin + i < widx))) ? 1 : 0;
+        }
+        for (int i = i_lo + tid + RP_SEL_SLICE; i < i_hi; i += RP_SEL_THREADS) {   // (slices beyond RP_SEL_SLICE: the grid was capped)
+            const bool coll = RP_STATUS_LABEL(a.status[i]) == RP_LABEL_INFEASIBLE_COLLISION;
+            const double c = a.cost[i];
+            nloc += (coll && (widx < 0 || c < wcost || (c == wcost && a.cand_begin + i < widx))) ? 1 : 0;
+        }
+        if (nloc) atomicAdd(&sh_nb, (unsigned int)nloc);
+    }
+    __syncthreads();
+    if (tid < RP_PARTIAL_CNT && sh_c32[tid])
+        __hip_atomic_fetch_add(&a.scratch[tid], (unsigned long long)sh_c32[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == RP_PARTIAL_CNT && sh_nb) __hip_atomic_fetch_add(&a.scratch[10], (unsigned long long)sh_nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
+    // -- arrival: this workgroup's adds have been acknowledged before its ticket is taken
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0) sh_ticket = (unsigned int)__hip_atomic_fetch_add(&a.scratch[11], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_ticket != (unsigned int)(nwg - 1)) return;   // (workgroup-uniform)
+    // -- the last workgroup: totals -> result header -> completion ticket; scratch cleared for the next launch
+    if (tid < RP_PARTIAL_CNT) sh_c32[tid] = (unsigned int)__hip_atomic_load(&a.scratch[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == RP_PARTIAL_CNT) sh_before = __hip_atomic_load(&a.scratch[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid < 12) __hip_atomic_store(&a.scratch[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows);
+    if (want_rows) {
+        double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
+#pragma unroll
+        for (int q = 0; q < kRowsPerThread; ++q) {
+            const int k = tid + q * RP_SEL_THREADS;
+            if (k < RP_N_ARRAYS * n) { d1[k] = wrow[q]; result_host_store(d2 + k, (unsigned long long)__double_as_longlong(wrow[q])); }
+        }
+        for (int k = tid + kRowsPerThread * RP_SEL_THREADS; k < RP_N_ARRAYS * n; k += RP_SEL_THREADS) {
+            const double v = wsrc[padded(k)];
+            d1[k] = v;
+            result_host_store(d2 + k, (unsigned long long)__double_as_longlong(v));
+        }
+    }
+    if (a.seq) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&host_out->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// bin of a key difference d = k(c) - k(c*): d itself below 16, then 16 bins per octave; lazy_bin_lower = smallest d of a bin
+__device__ __forceinline__ int lazy_bin(unsigned long long d) {
+    if (d < 16ull) return (int)d;
+    const int msb = 63 - __clzll((long long)d);
+    return (msb - 3) * 16 + (int)((d >> (msb - 4)) & 15ull);
+}
+__device__ __forceinline__ unsigned long long lazy_bin_lower(int b) {
+    if (b < 16) return (unsigned long long)b;
+    if (b >= 61 * 16) return ~0ull;   // (behind the last bin)
+    return (unsigned long long)(16 + (b & 15)) << (b / 16 - 1);
+}
+
+#define RP_GATHER_THREADS 256
+// pass 1 -> counters, histogram, thresholds
+__global__ __launch_bounds__(RP_GATHER_THREADS) void rp_lazy_hist_kernel(const GatherArgs a) {
+    touch_kernargs<2>();
+    __shared__ unsigned int sh_hist[RP_LAZY_BINS];
+    __shared__ unsigned int sh_c32[RP_PARTIAL_CNT];
+    __shared__ double sh_cost[RP_GATHER_THREADS / 64];
+    __shared__ long long sh_idx[RP_GATHER_THREADS / 64];
+    __shared__ unsigned int sh_ticket;
+    const int tid = threadIdx.x, nwg = (int)gridDim.x, w = (int)blockIdx.x;
+    const int n_partials = a.n_partials;
+    const Partials pp = partials_at(a.partials, a.partials_cap, a.partials_first);
+    // -- the cheapest feasible cost (every workgroup, the same) and the counters of this workgroup's slice of the partials
+    double bc = 0.0;
+    long long bi = -1;
+    for (int k = tid; k < n_partials; k += RP_GATHER_THREADS) {
+        const double pc = pp.cost[k];
+        const long long pi = pp.idx[k];
+        if (pi >= 0 && better(pc, (int64_t)pi, bc, (int64_t)bi)) { bc = pc; bi = pi; }
+    }
+    unsigned int cnt[RP_PARTIAL_CNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int per_p = (n_partials + nwg - 1) / nwg, k0 = w * per_p, k1 = k0 + per_p < n_partials ? k0 + per_p : n_partials;
+    for (int k = k0 + tid; k < k1; k += RP_GATHER_THREADS) {
+        const uint2 *pq = reinterpret_cast<const uint2 *>(pp.cnt + (size_t)k * RP_PARTIAL_CNT);
+        const uint2 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
+        cnt[0] += q0.x; cnt[1] += q0.y; cnt[2] += q1.x; cnt[3] += q1.y; cnt[4] += q2.x;
+        cnt[5] += q2.y; cnt[6] += q3.x; cnt[7] += q3.y; cnt[8] += q4.x; cnt[9] += q4.y;
+    }
+    for (int b = tid; b < RP_LAZY_BINS; b += RP_GATHER_THREADS) sh_hist[b] = 0;
+    if (tid < RP_PARTIAL_CNT) sh_c32[tid] = 0;
+    wave_min_pair(bc, bi);
+    if ((tid & 63) == 0) { sh_cost[tid >> 6] = bc; sh_idx[tid >> 6] = bi; }
+    __syncthreads();
+    double wcost = sh_cost[0];
+    long long widx = sh_idx[0];
+#pragma unroll
+    for (int q = 1; q < RP_GATHER_THREADS / 64; ++q)
+        if (sh_idx[q] >= 0 && better(sh_cost[q], (int64_t)sh_idx[q], wcost, (int64_t)widx)) { wcost = sh_cost[q]; widx = sh_idx[q]; }
+    const unsigned long long key_min = widx >= 0 ? cost_key(wcost) : 0ull;
+    if (__any(k0 + tid < k1)) {
+#pragma unroll
+        for (int r = 0; r < RP_PARTIAL_CNT; ++r) {
+            unsigned int t = cnt[r];
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);
+            t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);
+            if ((tid & 63) == 63 && t) atomicAdd(&sh_c32[r], t);
+        }
+    }
+    // -- histogram of this workgroup's slice of the batch (eight candidates per lane requested together: one round trip per 2 048)
+    if (widx >= 0) {
+        const int ccount = (int)a.count;
+        const int per_c = (ccount + nwg - 1) / nwg, i_lo = w * per_c, i_hi = i_lo + per_c < ccount ? i_lo + per_c : ccount;
+        constexpr int kUnroll = 8;
+        for (int i0 = i_lo + tid; i0 < i_hi; i0 += RP_GATHER_THREADS * kUnroll) {
+            uint32_t st[kUnroll];
+            double cs[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = i0 + u * RP_GATHER_THREADS, ic = i < i_hi ? i : i_hi - 1;
+                st[u] = a.status[ic];
+                cs[u] = a.cost[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (i0 + u * RP_GATHER_THREADS < i_hi && RP_STATUS_LABEL(st[u]) == RP_LABEL_FEASIBLE && cs[u] == cs[u])
+                    atomicAdd(&sh_hist[lazy_bin(cost_key(cs[u]) - key_min)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < RP_LAZY_BINS; b += RP_GATHER_THREADS)
+        if (sh_hist[b]) __hip_atomic_fetch_add(&a.hist[b], sh_hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < RP_PARTIAL_CNT && sh_c32[tid])
+        __hip_atomic_fetch_add(&a.ctl->totals[tid], (unsigned long long)sh_c32[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);   // this workgroup's adds have been acknowledged before it takes its ticket (see rp_select_kernel)
+    __syncthreads();
+    if (tid == 0) sh_ticket = __hip_atomic_fetch_add(&a.hist[RP_LAZY_BINS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (sh_ticket != (unsigned int)(nwg - 1)) return;
+    // -- the last workgroup: prefix sums over the bins, the edges behind the levels' targets; histogram cleared for the next launch
+    unsigned int h[4], run = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = __hip_atomic_load(&a.hist[4 * tid + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run += h[q];
+    }
+    __syncthreads();   // (sh_hist is reused)
+    sh_hist[tid] = run;
+    __syncthreads();
+    for (int d = 1; d < RP_GATHER_THREADS; d <<= 1) {   // inclusive scan of the 256 four-bin sums
+        const unsigned int v = tid >= d ? sh_hist[tid - d] : 0u;
+        __syncthreads();
+        sh_hist[tid] += v;
+        __syncthreads();
+    }
+    unsigned int before = tid ? sh_hist[tid - 1] : 0u;   // candidates in the bins ahead of this thread's four
+    __shared__ int sh_bin[RP_LAZY_LEVELS];
+    __shared__ unsigned int sh_cum[RP_LAZY_LEVELS];
+    if (tid < RP_LAZY_LEVELS) { sh_bin[tid] = RP_LAZY_BINS - 1; sh_cum[tid] = sh_hist[RP_GATHER_THREADS - 1]; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned int after = before + h[q];
+#pragma unroll
+        for (int l = 0; l < RP_LAZY_LEVELS; ++l)
+            if (before < a.target[l] && after >= a.target[l]) { sh_bin[l] = 4 * tid + q; sh_cum[l] = after; }   // (exactly one bin per level, if any)
+        before = after;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __hip_atomic_store(&a.hist[4 * tid + q], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&a.hist[RP_LAZY_BINS], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        LazyCtl *const z = a.ctl;
+        z->key_min = key_min;
+        unsigned int prev = 0, ov = 0;
+        for (int l = 0; l < RP_LAZY_LEVELS; ++l) {
+            z->edge[l] = widx >= 0 ? lazy_bin_lower(sh_bin[l] + 1) : 0ull;
+            const unsigned int ex = widx >= 0 ? sh_cum[l] - prev : 0u;
+            z->expect[l] = ex;
+            if (ex > (unsigned int)a.cap[l]) ov |= 1u << l;
+            prev = widx >= 0 ? sh_cum[l] : 0u;
+        }
+        z->overflow = ov;
+    }
+}
+
+// thresholds -> the candidate lists of the levels (any order inside a list)
+__global__ __launch_bounds__(RP_GATHER_THREADS) void rp_lazy_gather_kernel(const GatherArgs a) {
+    touch_kernargs<2>();
+    const int tid = threadIdx.x, lane = tid & 63, nwg = (int)gridDim.x, w = (int)blockIdx.x;
+    const LazyCtl *const z = a.ctl;
+    const unsigned long long key_min = z->key_min, e0 = z->edge[0], e1 = z->edge[1], e2 = z->edge[2];
+    const int ccount = (int)a.count;
+    const int per_c = (ccount + nwg - 1) / nwg, i_lo = w * per_c, i_hi = i_lo + per_c < ccount ? i_lo + per_c : ccount;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    constexpr int kUnroll = 8;   // eight candidates per lane requested together: one round trip per 2 048 candidates of the slice
+    for (int base0 = i_lo + (tid & ~63); base0 < i_hi; base0 += RP_GATHER_THREADS * kUnroll) {   // wave-uniform: ballots inside
+        uint32_t stv[kUnroll];
+        double csv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = base0 + u * RP_GATHER_THREADS + lane, ic = i < i_hi ? i : i_hi - 1;
+            stv[u] = a.status[ic];
+            csv[u] = a.cost[ic];
+        }
+        // level of each of this lane's eight candidates (3: none)
+        int lvl[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = base0 + u * RP_GATHER_THREADS + lane;
+            const double c = csv[u];
+            const unsigned long long d = cost_key(c) - key_min;
+            const bool feas = i < i_hi && RP_STATUS_LABEL(stv[u]) == RP_LABEL_FEASIBLE && c == c && d < e2;
+            lvl[u] = !feas ? 3 : (d < e0 ? 0 : (d < e1 ? 1 : 2));
+        }
+        // one reservation per level and wavefront for all eight rounds of ballots (the good candidates cluster in a few wavefronts:
+        // a reservation per ballot was a chain of up to 24 device-scope round trips there -- 18 us for a 10-us kernel)
+        unsigned int total[RP_LAZY_LEVELS] = {0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+            for (int l = 0; l < RP_LAZY_LEVELS; ++l) total[l] += (unsigned int)__popcll(__ballot(lvl[u] == l));
+        unsigned int at[RP_LAZY_LEVELS] = {0, 0, 0};
+#pragma unroll
+        for (int l = 0; l < RP_LAZY_LEVELS; ++l)
+            if (total[l] && lane == 0) at[l] = atomicAdd(&a.ctl->count[l], total[l]);   // (the three are in flight together)
+#pragma unroll
+        for (int l = 0; l < RP_LAZY_LEVELS; ++l) at[l] = (unsigned int)__builtin_amdgcn_readfirstlane((int)at[l]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = base0 + u * RP_GATHER_THREADS + lane;
+#pragma unroll
+            for (int l = 0; l < RP_LAZY_LEVELS; ++l) {
+                const unsigned long long bm = __ballot(lvl[u] == l);
+                const unsigned int pos = at[l] + (unsigned int)__popcll(bm & lt_mask);
+                if (lvl[u] == l && pos < (unsigned int)a.cap[l]) a.lists[a.off[l] + (int)pos] = (int32_t)(a.cand_begin + i);
+                at[l] += (unsigned int)__popcll(bm);
+            }
+        }
+    }
 }
 
 // Per-group LDS scratch of the evaluation kernel.  Values that are identical in all lanes of a group
@@ -818,12 +1318,18 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
 // and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
-__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsG ag) {
+__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
     const KArgs &a = ag.k;
     extern __shared__ double lds[];
     touch_kernargs<10>();
     const int tid = threadIdx.x;
     const int n_ref = a.n_ref;
+    if (a.publish_grids && blockIdx.x == 0) {   // the grids of this launch's kernarg segment -> device memory, for the kernels behind
+        const int words = a.nT + a.nL + a.nD + ((a.nT + 1) >> 1);   // [T | L | D | traj_len (int32)]
+        const double *src = grid_base(a);
+        double *dst = const_cast<double *>(a.T);
+        for (int k = tid; k < words; k += RP_BLOCK) dst[k] = src[k];
+    }
     const double *tab;
     if (LDS_TABLES) {   // 16-byte loads, four in flight per lane
         const double2 *src = reinterpret_cast<const double2 *>(a.tables);
@@ -929,7 +1435,6 @@ __device__ __forceinline__ ProfStep load_profile(const char *base, uint32_t off8
 // fields of one (pair, step) next to each other -- so that every field sits at a compile-time offset from ONE address per
 // lane (the field-major layout of the global rows costs a scalar row offset per field, 16 registers held across the step
 // loop and spilled).  PF_STRIDE = 17 doubles: lanes of consecutive steps start 17 eight-byte banks apart, conflict-free.
-#define PF_STRIDE (PF_FIELDS + 1)
 template <int FIELDS = PF_FIELDS>
 __device__ __forceinline__ ProfStep load_profile_item(const double *item) {
     ProfStep p;
@@ -1030,7 +1535,22 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         return;
     }
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave
-    const int64_t count = a.single_index ? 1 : a.count;
+    int64_t count_ = a.single_index ? 1 : a.count;
+    if (!LON_FUSED && a.index_list) {   // list mode: as many candidates as the list holds (workgroups beyond it leave an empty partial)
+        const uint32_t lc = *a.list_count;
+        count_ = (int64_t)(lc < (uint32_t)a.list_cap ? lc : (uint32_t)a.list_cap);
+        if ((int64_t)blockIdx.x * GPB >= count_) {
+            if (a.partials) {
+                const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+                if (tid == 0) { bp.cost[0] = 0.0; bp.idx[0] = -1; }
+                if (tid >= 8 && tid < 8 + RP_PARTIAL_CNT) bp.cnt[tid - 8] = 0u;
+            }
+            return;
+        }
+    }
+    const int64_t count = count_;
+    if (!LON_FUSED && a.lazy_ctl && blockIdx.x == 0 && tid < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
+        reinterpret_cast<unsigned long long *>(a.lazy_ctl)[tid] = 0ull;
 
     __shared__ GroupScratch sh_grp[GPB];
     __shared__ double sh_best_cost[GPB];
@@ -1293,7 +1813,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     } else {
         // (lanes without a candidate shadow the first candidate of their wavefront: its profile rows exist and are close)
         const int64_t slot0 = wave_first + group_in_wave;
-        const int64_t g0 = a.single_index ? *a.single_index : a.cand_begin + (slot0 < count ? slot0 : (wave_first < count ? wave_first : 0));
+        const int64_t ls0 = slot0 < count ? slot0 : (wave_first < count ? wave_first : (a.index_list ? (int64_t)blockIdx.x * GPB : 0));
+        const int64_t g0 = a.single_index ? *a.single_index : (a.index_list ? (int64_t)a.index_list[ls0] : a.cand_begin + ls0);
         cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
         const int32_t ps0 = (int32_t)((COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0);
         const int32_t pw0 = __builtin_amdgcn_readfirstlane(ps0);   // pair of the wavefront's first candidate (wave-uniform)
@@ -1357,7 +1878,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
         const bool valid = slot < count;
         // (lanes without a candidate shadow the first candidate of their wavefront, whose profile rows exist)
-        const int64_t gidx = al.single_index ? *al.single_index : al.cand_begin + (valid ? slot : w0);
+        const int64_t gidx = al.single_index ? *al.single_index
+                             : ((!LON_FUSED && al.index_list) ? (int64_t)al.index_list[valid ? slot : w0] : al.cand_begin + (valid ? slot : w0));
 
         // ---- lateral polynomial: sampling.py:226-238, 268-270
         const int L = cin.L;
@@ -1397,11 +1919,15 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             // G consecutive steps then starts on a line boundary and covers whole lines, which is what a write-through store
             // needs to reach memory as one full-line write (248-byte rows cost 1.28 x the bytes: profiles/r02_pmc_traffic.json).
             const int ns = (MAT && !STAGE_OUT) ? al.row_stride : n;
+            // split tail (state_offset): only where 16 lanes store rows straight to memory on the two-kernel path
+            constexpr bool SPLIT_OK = MAT && !STAGE_OUT && !LON_FUSED && G == 16;
+            const int tail_m = SPLIT_OK ? al.tail_split : 0;
+            const uint32_t cand8 = (uint32_t)state_block_doubles(ns, tail_m) * 8u;   // bytes of one candidate's block
             char *const obase = !MAT ? nullptr
                                 : (STAGE_OUT ? reinterpret_cast<char *>(lds_out + (size_t)(wave_in_block * GPW) * RP_N_ARRAYS * (size_t)n)
-                                             : reinterpret_cast<char *>(al.states + ((size_t)w0 * RP_N_ARRAYS) * (size_t)ns));
+                                             : reinterpret_cast<char *>(al.states) + (size_t)w0 * (size_t)cand8);
             const uint32_t n8 = (uint32_t)ns * 8u;
-            const uint32_t lane_off8 = (uint32_t)group_in_wave * RP_N_ARRAYS * n8;   // this group's candidate inside the wavefront
+            const uint32_t lane_off8 = (uint32_t)group_in_wave * (STAGE_OUT ? RP_N_ARRAYS * n8 : cand8);   // this group's candidate inside the wavefront
             // row * n8 is formed where it is used, from a per-lane copy of n8 the compiler cannot see through (one
             // v_mad_u32_u24 per row): as a loop invariant it would be hoisted into 14 scalar registers that live across
             // the whole step loop -- the kernel runs out of those first (spilled ones cost a v_readlane per use)
@@ -1675,6 +2201,18 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 }
                 // (lanes in the padding behind step N store too: their values are never read, and the run of the lane group
                 //  then ends on a line boundary)
+                if (SPLIT_OK && tail_m > 0 && base >= tail_m) {   // (wave-uniform) the partial step block: two rows to a 128-byte line
+                    if (store_ok) {
+                        char *const tbase = obase + (size_t)(lane_off8 + (uint32_t)(RP_N_ARRAYS * tail_m) * 8u + (uint32_t)gl * 8u);
+                        const bool lo = gl < 8;
+                        auto pair_store = [&](int q, double r0, double r1) {   // lanes 0 .. 7: row 2q, lanes 8 .. 15: row 2q + 1 of lanes 0 .. 7
+                            const double up = dpp_f64<DPP_ROW_SHR8, 0xf>(r1);
+                            st_row<RP_WT, RP_NT>(reinterpret_cast<double *>(tbase + q * 128), lo ? r0 : up);
+                        };
+                        pair_store(0, x, y); pair_store(1, th_gl, v); pair_store(2, acc, kappa); pair_store(3, kdot, s);
+                        pair_store(4, d, th_cl); pair_store(5, sd, sdd); pair_store(6, dd, ddd);
+                    }
+                } else
                 if (LATE_STORE && store_ok && i < ns) {   // (whole 128-byte lines: completing only the 64-byte half that holds step N
                                                           //  costs 15-20 % on the large batches -- cfg5 2.96 vs 2.51 ms)
                     const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
@@ -1766,8 +2304,14 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         double cost = group_sum_last<G>(cost_acc);
         if (decided_bad) cost = __builtin_nan("");
         if (valid && gl == G - 1) {
-            al.status[slot] = status;
-            al.cost[slot] = cost;
+            if (!LON_FUSED && al.index_list) {   // a round of the lazy stage: the label of the candidate itself; its cost stays the first pass's
+                const int64_t fs = gidx - al.cand_begin;
+                al.status[fs] = status;
+                cost = decided_bad ? cost : al.cost[fs];
+            } else {
+                al.status[slot] = status;
+                al.cost[slot] = cost;
+            }
             const uint32_t lab = RP_STATUS_LABEL(status), rs = RP_STATUS_REASON(status);
             if (rs) atomicAdd(&sh_cnt[2 + rs], 1);
             if (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION) atomicAdd(&sh_cnt[0], 1);
@@ -1795,11 +2339,9 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
                 for (int k = 0; k < GPB; ++k)
                     if (sh_best_idx[k] >= 0 && better(sh_best_cost[k], (int64_t)sh_best_idx[k], bc, (int64_t)bi)) { bc = sh_best_cost[k]; bi = sh_best_idx[k]; }
             }
-            BlockPartial *const bp = al.partials + blockIdx.x;
-            if (tid == 0) { bp->best_cost = bi >= 0 ? bc : 0.0; bp->best_index = (int64_t)bi; }
-            if (tid == 1) bp->n_feasible = sh_cnt[0];
-            if (tid == 2) bp->n_collision = sh_cnt[1];
-            if (tid >= 8 && tid < 16) bp->reasons[tid - 8] = sh_cnt[2 + tid - 8];
+            const Partials bp = partials_at(al.partials, al.partials_cap, (int)blockIdx.x);
+            if (tid == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
+            if (tid >= 8 && tid < 8 + RP_PARTIAL_CNT) bp.cnt[tid - 8] = (uint32_t)sh_cnt[tid - 8];
         }
     }
     RP_STAMP(14);
@@ -1885,15 +2427,16 @@ __global__ __launch_bounds__(RP_COMBINE_THREADS) void rp_combine_kernel(const ch
 // rp_fetch_states of padded state rows: [rows][ns] -> compact [rows][n] in device memory (grid-stride, one element per
 // thread and turn; the transfer to the host that follows is the slow part).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rp_compact_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int ns,
+__global__ __launch_bounds__(256) void rp_compact_rows_kernel(const double *__restrict__ src, double *__restrict__ dst, int n, int ns, int tail,
                                                              uint32_t inv_n, unsigned long long total) {
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    const unsigned long long blk_dev = (unsigned long long)state_block_doubles(ns, tail);
     for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
         // one state block (14 n elements) at a time keeps the row index inside the exact range of the reciprocal
         const unsigned long long blk = k / (unsigned long long)(RP_N_ARRAYS * n);
         const uint32_t r = (uint32_t)(k - blk * (unsigned long long)(RP_N_ARRAYS * n));
         const uint32_t row = __umulhi(r, inv_n);
-        dst[k] = src[blk * (unsigned long long)(RP_N_ARRAYS * ns) + (unsigned long long)(r + row * (uint32_t)(ns - n))];
+        dst[k] = src[blk * blk_dev + (unsigned long long)state_offset((int)row, (int)(r - row * (uint32_t)n), ns, tail)];
     }
 }
 
@@ -1901,30 +2444,26 @@ __global__ __launch_bounds__(256) void rp_compact_rows_kernel(const double *__re
 // Large batches leave one partial per workgroup (tens of thousands): fold them to gridDim.x partials
 // before the one-workgroup selection epilogue.  One wavefront per output partial.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rp_fold_partials_kernel(const BlockPartial *in, int n_in, BlockPartial *out) {
+__global__ __launch_bounds__(64) void rp_fold_partials_kernel(void *base, int cap, int n_in, int out_first) {
     const int lane = threadIdx.x;
+    const Partials in = partials_at(base, cap), out = partials_at(base, cap, out_first);
     double bc = 0.0;
     long long bi = -1;
-    double cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // exact in double: counts are far below 2^53
+    double cnt[RP_PARTIAL_CNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // exact in double: counts are far below 2^53
     for (int k = blockIdx.x * 64 + lane; k < n_in; k += gridDim.x * 64) {
-        const BlockPartial p = in[k];
-        if (p.best_index >= 0 && better(p.best_cost, p.best_index, bc, (int64_t)bi)) { bc = p.best_cost; bi = p.best_index; }
-        cnt[0] += (double)p.n_feasible;
-        cnt[1] += (double)p.n_collision;
+        const double pc = in.cost[k];
+        const long long pi = in.idx[k];
+        if (pi >= 0 && better(pc, (int64_t)pi, bc, (int64_t)bi)) { bc = pc; bi = pi; }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) cnt[2 + r] += (double)p.reasons[r];
+        for (int r = 0; r < RP_PARTIAL_CNT; ++r) cnt[r] += (double)in.cnt[(size_t)k * RP_PARTIAL_CNT + r];
     }
     wave_min_pair(bc, bi);
 #pragma unroll
-    for (int r = 0; r < 10; ++r) cnt[r] = group_sum_last<64>(cnt[r]);
+    for (int r = 0; r < RP_PARTIAL_CNT; ++r) cnt[r] = group_sum_last<64>(cnt[r]);
     if (lane == 63) {
-        BlockPartial o;
-        o.best_cost = bc;
-        o.best_index = bi;
-        o.n_feasible = (int64_t)cnt[0];
-        o.n_collision = (int64_t)cnt[1];
-        for (int r = 0; r < 8; ++r) o.reasons[r] = (int64_t)cnt[2 + r];
-        out[blockIdx.x] = o;
+        out.cost[blockIdx.x] = bc;
+        out.idx[blockIdx.x] = bi;
+        for (int r = 0; r < RP_PARTIAL_CNT; ++r) out.cnt[(size_t)blockIdx.x * RP_PARTIAL_CNT + r] = (uint32_t)cnt[r];
     }
 }
 
@@ -2003,7 +2542,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_cost_range_kernel(const uint32_t 
 // Block partials from the status / cost arrays (plug-in cost path, rp_select).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *status, const double *cost, int64_t count,
-                                                               int64_t cand_begin, BlockPartial *partials) {
+                                                               int64_t cand_begin, void *partials, int partials_cap) {
     double bc = 0.0;
     int64_t bi = -1;
     int nf = 0, nc = 0, rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2030,18 +2569,17 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *s
         if (rs[r]) atomicAdd(&sh_cnt[2 + r], rs[r]);
     __syncthreads();
     if (threadIdx.x == 0) {
-        BlockPartial bp;
-        bp.best_cost = 0.0;
-        bp.best_index = -1;
+        double best_cost = 0.0;
+        int64_t best_index = -1;
         for (int k = 0; k < RP_BLOCK; ++k)
-            if (sh_idx[k] >= 0 && better(sh_cost[k], sh_idx[k], bp.best_cost, bp.best_index)) {
-                bp.best_cost = sh_cost[k];
-                bp.best_index = sh_idx[k];
+            if (sh_idx[k] >= 0 && better(sh_cost[k], sh_idx[k], best_cost, best_index)) {
+                best_cost = sh_cost[k];
+                best_index = sh_idx[k];
             }
-        bp.n_feasible = sh_cnt[0];
-        bp.n_collision = sh_cnt[1];
-        for (int r = 0; r < 8; ++r) bp.reasons[r] = sh_cnt[2 + r];
-        partials[blockIdx.x] = bp;
+        const Partials bp = partials_at(partials, partials_cap, (int)blockIdx.x);
+        bp.cost[0] = best_cost;
+        bp.idx[0] = best_index;
+        for (int r = 0; r < RP_PARTIAL_CNT; ++r) bp.cnt[r] = (uint32_t)sh_cnt[r];
     }
 }
 

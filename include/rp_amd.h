@@ -55,9 +55,12 @@ extern "C" {
 #define RP_LABEL_NONE 0u                 /* reference label None: pre-filtered or left the projection domain */
 #define RP_LABEL_FEASIBLE 1u             /* FeasibilityStatus.FEASIBLE and (eagerly checked) collision-free */
 #define RP_LABEL_INFEASIBLE_KINEMATIC 2u /* FeasibilityStatus.INFEASIBLE_KINEMATIC */
-#define RP_LABEL_INFEASIBLE_COLLISION 3u /* kinematically feasible but colliding.  The reference marks
-                                            these lazily (only samples cheaper than the winner); here
-                                            every colliding feasible sample carries the label. */
+#define RP_LABEL_INFEASIBLE_COLLISION 3u /* kinematically feasible but colliding.  The reference marks these
+                                            lazily (only samples cheaper than the winner).  Plans that ran the
+                                            eager collision query (rp_last_path() == RP_PATH_EAGER) label every
+                                            colliding feasible sample; plans that ran the cost-ordered stage
+                                            (RP_PATH_LAZY) label the ones they had to look at -- at least every
+                                            sample that sorts before the winner -- the others keep FEASIBLE. */
 #define RP_STATUS_LABEL(s) ((s) & 3u)
 #define RP_STATUS_REASON(s) (((s) >> 4) & 7u)
 #define RP_STATUS_STEP(s) (((s) >> 8) & 0xFFFu)
@@ -142,7 +145,8 @@ typedef struct rp_result {
     int64_t n_feasible;       /* kinematically feasible (colliding ones included):
                                  infeasible_count_kinematics = n_candidates - n_feasible */
     int64_t n_collision_before_best; /* infeasible_count_collision (lazy semantics of _check_collisions) */
-    int64_t n_collision;      /* all colliding feasible candidates (eager) */
+    int64_t n_collision;      /* colliding feasible candidates FOUND: all of them after an eager plan, the ones the
+                                 cost-ordered stage looked at (>= n_collision_before_best) after a lazy one */
     int64_t reason_counts[8]; /* [RP_REASON_*]: 1..5 = infeasible_reason_dict, 6 = out of domain */
     double best_lon_coeffs[6];
     double best_lat_coeffs[6];
@@ -155,6 +159,9 @@ typedef struct rp_ctx rp_ctx;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
 int rp_abi_version(void);
+/* first 16 hex digits of the SHA-256 of the sources this library was built from (csrc/Makefile): measurement files name
+   the code they were taken on */
+const char *rp_source_hash(void);
 int rp_create(rp_ctx **out, int device);
 void rp_destroy(rp_ctx *ctx);
 const char *rp_last_error(const rp_ctx *ctx);
@@ -188,6 +195,18 @@ int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
                    const int32_t *traj_len, rp_result *result, double *best_states);
 
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
+/* How the last plan answered the collision query (reactive_planner.py:1019-1063):
+ *   RP_PATH_EAGER          every pose of every candidate inside the evaluation kernel (draw / materialising plans, small
+ *                          batches, plug-in costs);
+ *   RP_PATH_LAZY           the reference's own order of work: costs first, then the candidates in ascending (cost, index)
+ *                          until the first free one -- production-mode plans of large batches with obstacles;
+ *   RP_PATH_LAZY_FALLBACK  the cost-ordered stage ran out of candidates (a scene where nearly everything collides) and the
+ *                          eager kernel decided; results as RP_PATH_EAGER.
+ * Winner, cost, infeasible_count_collision and the kinematic counters are the same on every path. */
+#define RP_PATH_EAGER 0
+#define RP_PATH_LAZY 1
+#define RP_PATH_LAZY_FALLBACK 2
+int rp_last_path(const rp_ctx *ctx);
 /* status[count], cost[count] (NaN where no cost) for local candidates first .. first+count-1
  * (local = relative to cand_begin).  Either pointer may be NULL. */
 int rp_fetch_status(rp_ctx *ctx, int64_t first, int64_t count, uint32_t *status, double *cost);

@@ -24,7 +24,7 @@ for wl in cfg2 cfg3 cfg4 cfg5; do
   rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
   echo "$wl counters done"
 done
-cp profiles/r02_pmc_traffic.json profiles/r02_fp64_flops.json $OUT/
+cp profiles/r03_pmc_traffic.json profiles/r03_fp64_flops.json $OUT/
 bash profiles/collect_sq.sh cfg2 20 draw > $OUT/${TAG}_sq_cfg2.json 2> $OUT/sq_cfg2.err
 bash profiles/collect_sq.sh cfg5 6 fused > $OUT/${TAG}_sq_cfg5_fused.json 2> $OUT/sq_cfg5.err
 rm -rf $ROOT/gpurun_out/sq_cfg2_draw $ROOT/gpurun_out/sq_cfg5_fused

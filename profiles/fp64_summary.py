@@ -1,6 +1,15 @@
 """FP64 instruction classes of the main rp_eval_kernel launches (largest grid) -> flops per (candidate, step);
-written to profiles/r02_fp64_flops.json, which bench.py reads for the "valu" roofline of production mode."""
-import collections, csv, glob, json, sys
+written to profiles/r03_fp64_flops.json, which bench.py reads for the "valu" roofline of production mode."""
+import collections, csv, glob, json, os, sys
+
+
+def _source_hash():
+    """hash of the sources of the library these counters were measured on (rp_source_hash)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "commonroad-reactive-planner_amd")]
+    from commonroad_rp_amd import _capi
+    return _capi.source_hash()
+
 wl, out, mode, bench = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 line = json.load(open(bench))
 cand, n1 = float(line["config"]["candidates_per_step"]), int(line["config"]["horizon_steps"]) + 1
@@ -22,10 +31,11 @@ rec = {"workload": wl, "mode": mode, "kernel": name, "candidates": cand, "steps"
        "model": "64 lanes x (ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) wavefront instructions counted by the SQ block (rocprofv3 --pmc), "
                 "median launch, / (candidates x (N + 1))"}
 print(json.dumps(rec))
-path = "profiles/r02_fp64_flops.json"
+path = "profiles/r03_fp64_flops.json"
 try:
     allr = json.load(open(path))
 except Exception:
     allr = {}
+rec["source_hash"] = _source_hash()
 allr[wl] = rec
 json.dump(allr, open(path, "w"), indent=1)

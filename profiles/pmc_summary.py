@@ -1,7 +1,16 @@
 """Median WRITE_SIZE / FETCH_SIZE (KB) of the main rp_eval_kernel launches (largest grid, MAT variant) -> bytes per launch.
 FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md section HBM);
 WRITE_SIZE is taken as is (exact for 16-B-per-lane streaming stores; 8-B stores are uncalibrated per the guide)."""
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+
+
+def _source_hash():
+    """hash of the sources of the library these counters were measured on (rp_source_hash)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "commonroad-reactive-planner_amd")]
+    from commonroad_rp_amd import _capi
+    return _capi.source_hash()
+
 wl, out = sys.argv[1], sys.argv[2]
 mode = sys.argv[3] if len(sys.argv) > 3 else "draw"
 res = {}
@@ -21,10 +30,11 @@ w = res["WRITE_SIZE"]["median_KB"] * 1024.0
 r = res["FETCH_SIZE"]["median_KB"] * 1024.0 * 2.0
 summary = {"workload": wl, "mode": mode, "write_bytes": w, "fetch_bytes_corrected_x2": r, "traffic_bytes": w + r, "detail": res}
 print(json.dumps(summary))
-path = "profiles/r02_pmc_traffic.json"   # read back by bench.py (roofline.traffic), key "<workload>:<mode>"
+path = "profiles/r03_pmc_traffic.json"   # read back by bench.py (roofline.traffic), key "<workload>:<mode>"
 try:
     allr = json.load(open(path))
 except Exception:
     allr = {}
+summary["source_hash"] = _source_hash()
 allr[f"{wl}:{mode}"] = summary
 json.dump(allr, open(path, "w"), indent=1)

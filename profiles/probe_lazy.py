@@ -1,0 +1,34 @@
+"""Cost-ordered collision stage against the eager kernel, production mode, on the benchmark workloads: winner, cost, counters
+must agree (labels: eager marks every colliding candidate, lazy only those it had to look at), and what each costs per step.
+usage (GPU box): python profiles/probe_lazy.py [cfg3 cfg3f cfg4 cfg5o ...]"""
+import os, sys, time
+import numpy as np
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "commonroad-reactive-planner_amd")]
+from commonroad_rp_amd import workloads as W
+from commonroad_rp_amd._capi import RpContext
+
+names = sys.argv[1:] or ["cfg3", "cfg3f", "cfg4", "cfg5o"]
+for name in names:
+    w = W.cfg5(obstacles=50) if name == "cfg5o" else W.WORKLOADS[name]()
+    ctx = RpContext(0); w.setup(ctx)
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["RP_AMD_LAZY"] = mode
+        for _ in range(3): out = ctx.plan(w.inputs)
+        ts = []
+        for _ in range(20):
+            t = time.perf_counter(); out = ctx.plan(w.inputs); ts.append(time.perf_counter() - t)
+        st, cost = ctx.fetch_status()
+        res[mode] = (out, st, cost, np.median(ts) * 1e6)
+    e, l = res["0"], res["1"]
+    oe, ol = e[0], l[0]
+    same = (oe.best_index == ol.best_index and oe.best_cost == ol.best_cost and oe.n_feasible == ol.n_feasible and
+            oe.n_collision_before_best == ol.n_collision_before_best and np.array_equal(oe.reason_counts, ol.reason_counts))
+    rows = oe.best_index < 0 or np.allclose(oe.best_states, ol.best_states, rtol=0, atol=1e-9)
+    # labels: identical except colliding candidates the lazy stage never looked at (FEASIBLE there)
+    lab_e, lab_l = e[1] & 3, l[1] & 3
+    diff = lab_e != lab_l
+    ok_lab = np.all((lab_e[diff] == 3) & (lab_l[diff] == 1))
+    print(f"{name}: C={w.n_candidates} eager {e[3]:.1f} us lazy {l[3]:.1f} us | winner {oe.best_index}/{ol.best_index} before {oe.n_collision_before_best}/{ol.n_collision_before_best} "
+          f"n_collision {oe.n_collision}/{ol.n_collision} feasible {oe.n_feasible} | result same={same} rows={rows} labels ok={ok_lab} ({int(diff.sum())} unlabelled)")
+    ctx.close()

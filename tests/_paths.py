@@ -1,7 +1,9 @@
 """The launch paths of the library that the GPU tests run on (the environment switches are read per plan call):
   single_launch  small batches: one kernel computes the longitudinal profiles in LDS and evaluates (default)
   two_kernel     rp_lon_kernel + rp_eval_kernel (what large batches take), 16 lanes per candidate
-  g32 / g64      two-kernel path with 32 / 64 lanes per candidate (g64: LDS-staged linear copy-out of state rows)"""
+  g32 / g64      two-kernel path with 32 / 64 lanes per candidate (g64: LDS-staged linear copy-out of state rows)
+  lazy           two-kernel path with the cost-ordered collision stage forced for every production-mode plan with obstacles
+                 (by default only batches beyond 16 384 candidates take it): costs first, collision rounds over the cheapest"""
 import contextlib
 import os
 
@@ -10,12 +12,13 @@ LAUNCH_PATHS = {
     "two_kernel": {"RP_AMD_NO_FUSED_LON": "1"},
     "g32": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "32"},
     "g64": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "64"},
+    "lazy": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_LAZY": "1", "RP_AMD_NO_AUTO_MATERIALIZE": "1"},
 }
 
 
 @contextlib.contextmanager
 def launch_path_env(name):
-    saved = {k: os.environ.get(k) for k in ("RP_AMD_NO_FUSED_LON", "RP_AMD_G")}
+    saved = {k: os.environ.get(k) for k in ("RP_AMD_NO_FUSED_LON", "RP_AMD_G", "RP_AMD_LAZY", "RP_AMD_NO_AUTO_MATERIALIZE")}
     for k in saved:
         os.environ.pop(k, None)
     os.environ.update(LAUNCH_PATHS[name])

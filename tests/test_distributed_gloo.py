@@ -165,3 +165,33 @@ def test_exchange_posts_only_the_result_it_was_given():
     assert b.serial == 2 and a.serial != ctx._serial and b.best_index == a.best_index and b.n_candidates == a.n_candidates
     foreign = PlanOutput.from_c(r, None)
     assert foreign.serial == 0              # ... and a result that did not come from this context never matches
+
+
+PLAN_CASES = ["plan_arc_hv_obs", "plan_all_collide", "plan_standstill", "plan_scurve_lv", "plan_arc_swept_hit", "cfg4_slice"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_plan_matches_single_rank(tmp_path, world):
+    """Row N1: sharding lives inside ``ReactivePlanner.plan()`` -- the reference's only parallel backend also sits inside
+    ``_get_optimal_trajectory`` (reactive_planner.py:1084-1111).  Every rank of a gloo group runs ``plan()`` with the planner's
+    process group set; trajectory, counters and reasons must equal a single-rank run on every rank: several sampling levels
+    (plan_all_collide visits them all), the standstill branch with its cost range over all shards (plan_standstill), low-velocity
+    mode, the continuous collision check of the winner (plan_arc_swept_hit), and a 32 768-candidate slice of cfg4 that
+    crosses the planner's own saturation threshold while a small level stays whole on every rank."""
+    worker = os.path.join(HERE, "_dist_plan_worker.py")
+    base_env = dict(os.environ, OMP_NUM_THREADS="1")
+    single = subprocess.Popen([sys.executable, worker, str(tmp_path)] + PLAN_CASES, env=dict(base_env, RANK="0", WORLD_SIZE="1"))
+    env = dict(base_env, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29730 + world), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path)] + PLAN_CASES, env=dict(env, RANK=str(r))) for r in range(world)]
+    assert single.wait(timeout=600) == 0
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    ref = json.load(open(tmp_path / "rank0_of1.json"))
+    for r in range(world):
+        got = json.load(open(tmp_path / f"rank{r}_of{world}.json"))
+        assert got.pop("_small_level_sharded_calls") == 0
+        for name in PLAN_CASES:
+            a, b = dict(got[name]), dict(ref[name])
+            assert b.pop("sharded_calls") == 0
+            assert a.pop("sharded_calls") >= 1, name          # the level(s) really went through the exchange
+            assert a == b, (name, r)
