@@ -592,6 +592,21 @@ def sharded_plan_latency(w, dist, xdev, local_rank, transport, n_replans=60, war
                     "shard_range -> rp_plan on the shard -> exchange_winner inside _get_optimal_trajectory"}
 
 
+def cpu_quota():
+    """CPUs the control group of this process may use at a time (cgroup v2 cpu.max / v1 cfs quota), or None without a limit."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, int(round(q / per)))
+    except Exception:
+        return None
+
+
 # --------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(w, inp, budget_s: float):
     """The CPU oracle (C port of the reference's algorithm, oracle/rp_oracle.c) timed on one host
@@ -600,14 +615,15 @@ def cpu_baseline(w, inp, budget_s: float):
     tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
     C = inp.n_candidates
     sample = min(C, 20000)
-    oracle.plan(inp, tb, 0, sample, want_states=True)   # (library load, page faults of the output arrays)
+    keep = {}   # (the output arrays are reused between the calls: page faults of fresh ones are not part of the algorithm)
+    oracle.plan(inp, tb, 0, sample, want_states=True, scratch=keep)   # (library load, page faults of the output arrays)
     t0 = time.perf_counter()
-    oracle.plan(inp, tb, 0, sample, want_states=True)
+    oracle.plan(inp, tb, 0, sample, want_states=True, scratch=keep)
     one = time.perf_counter() - t0
     reps = max(1, int(budget_s / max(one, 1e-4)))
     t0 = time.perf_counter()
     for _ in range(reps):
-        oracle.plan(inp, tb, 0, sample, want_states=True)
+        oracle.plan(inp, tb, 0, sample, want_states=True, scratch=keep)
     el = time.perf_counter() - t0
     out = {"value": sample * reps / el, "unit": "candidates/s", "cores": 1, "kind": "port",
            "sample": f"first {sample} candidates of the first cycle of the same sequence and mode, {reps} repetitions, "
@@ -615,19 +631,24 @@ def cpu_baseline(w, inp, budget_s: float):
                      f"~3.9e3 candidates/s/core in the build container, BASELINE.md)"}
     # the same port on the GPU box's CPU share (OpenMP over candidates), a few seconds ("1 core and all cores")
     try:
-        threads = max(1, len(os.sched_getaffinity(0)))   # every core this process may run on
+        affinity = max(1, len(os.sched_getaffinity(0)))   # every core this process may run on ...
     except AttributeError:
-        threads = max(1, os.cpu_count() or 1)
+        affinity = max(1, os.cpu_count() or 1)
+    quota = cpu_quota()                                    # ... of which the container's CPU share lets this many run at a time
+    threads = max(1, min(affinity, quota) if quota else affinity)
     if threads > 1:
         big = min(C, 20000 * threads)
-        oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads)
+        keep = {}
+        oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads, scratch=keep)
         t0 = time.perf_counter()
         n = 0
         while time.perf_counter() - t0 < min(3.0, budget_s / 3):
-            oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads)
+            oracle.plan(inp, tb, 0, big, want_states=True, nthreads=threads, scratch=keep)
             n += 1
         out["all_cores"] = {"value": big * n / (time.perf_counter() - t0), "unit": "candidates/s", "cores": threads,
-                            "nproc": os.cpu_count(), "what": "the same C port, OpenMP over candidates on every core of the affinity mask"}
+                            "nproc": os.cpu_count(), "affinity": affinity, "cpu_quota": quota,
+                            "what": "the same C port, OpenMP over candidates on every core this process can use: the affinity mask, "
+                                    "capped by the CPU share of its control group (cpu.max) -- more threads than that only contend"}
     # the reference's own execution model -- one Python iteration per candidate, NumPy per trajectory, a
     # scalar Python loop over the steps, sort + lazy collision walk (oracle/numpy_loop.py) -- on one core, a few seconds
     from oracle import numpy_loop

@@ -96,6 +96,14 @@ class PlanInputs:
         self.traj_len = np.ascontiguousarray(self.traj_len, dtype=np.int32)
         assert self.T.ndim == self.L.ndim == self.D.ndim == 1 and self.traj_len.shape == self.T.shape
 
+    @classmethod
+    def trusted(cls, params, cost, T, traj_len, L, D) -> "PlanInputs":
+        """Without the conversions of ``__post_init__``: the caller hands C-contiguous float64 / int32 arrays (the planner's
+        own grids, once per replanning cycle)."""
+        self = object.__new__(cls)
+        self.params, self.cost, self.T, self.traj_len, self.L, self.D = params, cost, T, traj_len, L, D
+        return self
+
     @property
     def n_candidates(self) -> int:
         return len(self.T) * len(self.L) * len(self.D)
@@ -209,6 +217,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                        C.c_int32, dp]),
         "rp_plan": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64,
                               C.POINTER(RpResult), dp]),
+        "rp_plan_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64, C.c_int32]),
+        "rp_plan_wait": (C.c_int, [ctx, C.POINTER(RpResult), dp]),
+        "rp_pack_trajectory": (C.c_int, [C.c_int32, dp, C.c_double, C.c_double, C.c_double, dp]),
         "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
                                      C.POINTER(RpResult), dp]),
         "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
@@ -247,9 +258,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash")
+_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_coeffs", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -259,6 +270,17 @@ def source_hash() -> str:
     """Hash of the sources the loaded library was built from ("unknown" for a build that does not carry one)."""
     fn = getattr(load_library(), "rp_source_hash", None)
     return (fn() or b"unknown").decode() if fn is not None else "unknown"
+
+
+def pack_trajectory(states: np.ndarray, dt: float, wheelbase: float, x0_orientation: float) -> np.ndarray:
+    """``rp_pack_trajectory``: [n, 13] = x, y | s, d | s, s', s'' | d, d', d'' | shifted orientation | steering angle | yaw rate of a
+    state block [14, n] (what ``_compute_trajectory_pair`` packs, reactive_planner.py:514-568)."""
+    n = states.shape[1]
+    out = np.empty((n, 13))
+    rc = load_library().rp_pack_trajectory(n, states.ctypes.data_as(_DP), dt, wheelbase, x0_orientation, out.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RpError(f"rp_pack_trajectory -> {rc}")
+    return out
 
 
 # ---- reference-path front end (host-only entry points: no context, no GPU) -------------------------
@@ -398,6 +420,28 @@ class RpContext:
                                C.byref(res), best.ctypes.data_as(_DP) if best is not None else None)
         if rc != 0:
             self._check(rc, "rp_plan")
+        self._N = inp.params.N
+        self._last_count = res.n_candidates
+        return self._output(res, best)
+
+    def plan_begin(self, inp: PlanInputs, cand_begin: int = 0, cand_end: int = -1, want_best_states: bool = True):
+        """First half of ``plan``: the kernels of the plan go onto the context's stream and the call returns; ``plan_wait``
+        collects the result.  One plan in flight per context; ``inp`` must stay as it is until then."""
+        g = inp.grids()
+        rc = self._lib.rp_plan_begin(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end,
+                                     1 if want_best_states else 0)
+        if rc != 0:
+            self._check(rc, "rp_plan_begin")
+        self._inflight = (inp, want_best_states)
+
+    def plan_wait(self) -> PlanOutput:
+        inp, want = self._inflight
+        self._inflight = None
+        res = self._res
+        best = np.empty((N_ARRAYS, inp.params.N + 1)) if want else None
+        rc = self._lib.rp_plan_wait(self._h, C.byref(res), best.ctypes.data_as(_DP) if best is not None else None)
+        if rc != 0:
+            self._check(rc, "rp_plan_wait")
         self._N = inp.params.N
         self._last_count = res.n_candidates
         return self._output(res, best)

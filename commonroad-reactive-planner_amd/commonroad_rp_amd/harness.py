@@ -10,6 +10,11 @@ Per simulated time step (run_planner.py:62-107):
     objects are handed back).
 Works with ``commonroad_rp_amd.reactive_planner.ReactivePlanner`` and with the reference's class (or the
 ``GpuBackendMixin`` mixed into it): only the reference's public methods are used.
+
+``overlap=True`` ("overlap next-cycle preparation with current-cycle output packing"): the bookkeeping of a cycle --
+the ``on_step`` callback, e.g. recording / logging / visualising its optimal trajectory, whose state objects are built on access
+-- runs while the kernels of the NEXT cycle are on the device, between ``rp_plan_begin`` and ``rp_plan_wait``
+(``ReactivePlanner.on_device_launched``).  The planner's inputs never depend on it, so the loop's results are the same.
 """
 from __future__ import annotations
 
@@ -28,12 +33,20 @@ class LoopResult:
 
 def run_closed_loop(planner, max_steps: int, replanning_frequency: Optional[int] = None,
                     goal_reached: Optional[Callable[[], bool]] = None, desired_velocity: Optional[float] = None,
-                    on_step: Optional[Callable] = None) -> LoopResult:
+                    on_step: Optional[Callable] = None, overlap: bool = False) -> LoopResult:
     freq = replanning_frequency or planner.config.planning.replanning_frequency
     planner.record_state_and_input(planner.x_0)
     plan_times: List[float] = []
     optimal = None
     done = goal_reached or (lambda: False)
+    deferred: List = []   # on_step calls of finished cycles, run while the next cycle's kernels are on the device
+    overlap = overlap and on_step is not None and hasattr(planner, "on_device_launched")
+
+    def flush():
+        while deferred:
+            on_step(*deferred.pop(0))
+    if overlap:
+        planner.on_device_launched = flush
     while not done() and len(planner.record_state_list) - 1 < max_steps:
         current_count = len(planner.record_state_list) - 1
         temp = current_count % freq
@@ -46,6 +59,9 @@ def run_closed_loop(planner, max_steps: int, replanning_frequency: Optional[int]
             optimal = planner.plan()
             plan_times.append(time.perf_counter() - t0)
             if not optimal:
+                flush()
+                if overlap:
+                    planner.on_device_launched = None
                 return LoopResult(list(planner.record_state_list), plan_times, len(plan_times), False)
         k = 1 + temp
         planner.record_state_and_input(optimal[0].state_list[k])
@@ -53,5 +69,11 @@ def run_closed_loop(planner, max_steps: int, replanning_frequency: Optional[int]
                       initial_state_curv=(optimal[2][k], optimal[3][k]),
                       collision_checker=planner.collision_checker, coordinate_system=planner.coordinate_system)
         if on_step is not None:
-            on_step(current_count, planner, optimal)
+            if overlap:
+                deferred.append((current_count, planner, optimal))
+            else:
+                on_step(current_count, planner, optimal)
+    flush()
+    if overlap:
+        planner.on_device_launched = None
     return LoopResult(list(planner.record_state_list), plan_times, len(plan_times), True)

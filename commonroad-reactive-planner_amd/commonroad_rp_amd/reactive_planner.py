@@ -188,6 +188,7 @@ class _WinnerSample(TrajectorySample):
     curvilinear = property(lambda self: self._sample(1), lambda self, v: self._set_sample(1, v))
 
 
+_REASON_ITEMS = tuple(enumerate(_capi.REASON_NAMES[1:6], start=1))   # (reason code, name in infeasible_reason_dict)
 _LON_ROWS, _LAT_ROWS = [7, 10, 11], [8, 12, 13]   # rows of a state block (include/rp_amd.h: RP_S, RP_S_DOT, RP_S_DDOT | RP_D, ...)
 
 
@@ -212,6 +213,10 @@ class GpuBackendMixin:
     shard_device = None
     shard_transport = "auto"
     shard_min_candidates = SHARD_MIN_CANDIDATES
+    #: called once per ``plan()`` of the stand-alone planner, between the launch of the cycle's kernels and the wait for their
+    #: result (``rp_plan_begin`` / ``rp_plan_wait``): the caller's own work overlaps the device (harness.run_closed_loop)
+    on_device_launched = None
+    _levels_ahead = False
 
     def set_process_group(self, dist, device=None, transport: str = "auto", min_candidates: Optional[int] = None):
         """One planner per rank, the same inputs on every rank (the reference's only parallel backend also lives inside
@@ -261,6 +266,22 @@ class GpuBackendMixin:
             self._rp_obs_id = tables
         return ctx
 
+    def _gpu_ctx2(self):
+        """A second context with the same tables: the next sampling level starts on it while the current one is still on the
+        device (``_plan_fast``).  Created when a cycle first needs it."""
+        ctx = getattr(self, "_rp_ctx2", None)
+        if ctx is None:
+            ctx = self._rp_ctx2 = self.backend_factory(self.gpu_device)
+            self._rp_ref_id2 = self._rp_obs_id2 = None
+        if self._rp_ref_id2 is not self._co:
+            ctx.set_coordinate_system(self._co)
+            self._rp_ref_id2 = self._co
+        tables = self._obstacle_tables
+        if self._rp_obs_id2 is not tables:
+            ctx.set_obstacles(tables)
+            self._rp_obs_id2 = tables
+        return ctx
+
     def set_collision_checker(self, scenario=None, collision_checker=None, road_boundary_obstacle=None):
         """When mixed into the reference class: keep its pycrcc checker (other code may use it) and, in
         addition, keep the obstacle tables the GPU check needs in step with it:
@@ -307,10 +328,12 @@ class GpuBackendMixin:
         self._rp_tables_checker = getattr(self, "_cc", None)   # (drop-in mode: these tables stand for the planner's checker)
 
     def close(self):
-        ctx = getattr(self, "_rp_ctx", None)
-        if ctx is not None:
-            ctx.close()
-            self._rp_ctx = None
+        for name in ("_rp_ctx", "_rp_ctx2"):
+            ctx = getattr(self, name, None)
+            if ctx is not None:
+                ctx.close()
+                setattr(self, name, None)
+        self._rp_inflight = None
 
     # ---- per-call inputs ---------------------------------------------------------------------------
     def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
@@ -735,6 +758,13 @@ class ReactivePlanner(GpuBackendMixin):
 
         optimal, bundle = None, None
         i = 1 if current_sampling_level is None else current_sampling_level
+        if self._fast_path_ok():
+            result = self._plan_fast(x_0_lon, x_0_lat, i, current_sampling_level is not None)
+            if result is not NotImplemented:
+                self._planning_times_list.append(time.time() - start)
+                if result is None:
+                    logger.warning("Planner failed to find an optimal trajectory with given sampling configuration!")
+                return result
         while optimal is None and i < self.sampling_level:
             bundle = self._create_trajectory_bundle(x_0_lon, x_0_lat, samp_level=i)
             optimal = self._get_optimal_trajectory(bundle)
@@ -752,6 +782,110 @@ class ReactivePlanner(GpuBackendMixin):
         if result is None:
             logger.warning("Planner failed to find an optimal trajectory with given sampling configuration!")
         return result
+
+    # ---- the same cycle without the objects in between ---------------------------------------------
+    def _fast_path_ok(self) -> bool:
+        """The standard configuration of a moving vehicle -- fixed-interval sampling, a built-in cost function, no drawing, no
+        continuous collision check, no sharding -- and nobody has replaced one of the three methods the cycle goes through
+        (subclass or instance attribute): then ``plan()`` may skip the bundle, winner-sample and container objects, none of
+        which it reads itself (the standstill branch, which does, is left to the general loop)."""
+        cls, d = type(self), self.__dict__
+        return (type(self.sampling_space) is FixedIntervalSampling and not self._draw_traj_set and self.shard_dist is None
+                and self.x_0.velocity > 0.05 and not self.config.planning.continuous_collision_check
+                and cls._get_optimal_trajectory is GpuBackendMixin._get_optimal_trajectory
+                and cls._create_trajectory_bundle is GpuBackendMixin._create_trajectory_bundle
+                and cls._compute_trajectory_pair is ReactivePlanner._compute_trajectory_pair
+                and cls._compute_standstill_trajectory is ReactivePlanner._compute_standstill_trajectory
+                and "_compute_trajectory_pair" not in d and "_get_optimal_trajectory" not in d and "_create_trajectory_bundle" not in d)
+
+    def _plan_fast(self, x_0_lon, x_0_lat, level: int, single_level: bool):
+        """The level loop of ``plan()`` (reactive_planner.py:616-636) on the arrays themselves: grids -> ``rp_plan`` ->
+        counters, then the output packing of :514-568 in one host call (``rp_pack_trajectory``).  Same results, same
+        counters as the general loop (tests/test_planner_mirror.py runs both)."""
+        cost = self._gpu_cost()
+        if cost is None:
+            return NotImplemented
+        ctx = self._gpu_ctx()
+        sp, mode = self.sampling_space, self.config.sampling.longitudinal_mode
+        params = self._gpu_params(x_0_lon, x_0_lat, 0)
+        rd = self._infeasible_reason_dict
+        hook = self.on_device_launched
+        split = hasattr(ctx, "plan_begin")
+        # A level without a winner costs a whole round trip before the next one can start (reactive_planner.py:616-636).  When the
+        # last cycle needed a second level, this one puts level i + 1 on the device -- on a second context -- right behind level i
+        # and collects it only if level i fails: one round trip for both.
+        ahead = split and self._levels_ahead and not single_level
+        stale = getattr(self, "_rp_inflight", None)
+        if stale is not None:   # a level started ahead in the last cycle and never needed: its context is free once collected
+            stale.plan_wait()
+            self._rp_inflight = None
+        out, started, first = None, None, level   # started: (level, context, inputs) of the plan begun ahead
+        while level < self.sampling_level:
+            if started is not None and started[0] == level:
+                cur, inp = started[1], started[2]
+                started = None
+            else:
+                T, traj_len, L, D = sp.grids_at_level(level, x_0_lon, x_0_lat, mode)
+                cur, inp = ctx, (PlanInputs.trusted(params, cost, T, traj_len, L, D) if len(T) * len(L) * len(D) else None)
+                if inp is not None and (ahead or hook is not None) and split:
+                    cur.plan_begin(inp)
+                elif inp is not None:
+                    cur = None   # (one blocking call below)
+            if ahead and level + 1 < self.sampling_level and inp is not None:
+                other = self._gpu_ctx2() if cur is ctx else ctx
+                T, traj_len, L, D = sp.grids_at_level(level + 1, x_0_lon, x_0_lat, mode)
+                if len(T) * len(L) * len(D):
+                    nxt = PlanInputs.trusted(params, cost, T, traj_len, L, D)
+                    other.plan_begin(nxt)
+                    started = (level + 1, other, nxt)
+            self._reset_statistics()
+            if inp is None:
+                out = None
+            else:
+                if cur is None:
+                    out = ctx.plan(inp)
+                else:
+                    if hook is not None and level == first:
+                        hook()   # the device is busy with this cycle: the caller's own work (harness: the last cycle's bookkeeping)
+                    out = cur.plan_wait()
+                self._infeasible_count_kinematics = out.n_candidates - out.n_feasible
+                self._infeasible_count_collision = out.n_collision_before_best
+                rc = out.reason_counts
+                for k, name in _REASON_ITEMS:
+                    if name in rd:
+                        rd[name] = int(rc[k])
+                if out.best_index >= 0:
+                    break
+            if single_level:
+                break
+            level += 1
+        if started is not None:
+            self._rp_inflight = started[1]   # collected at the start of the next cycle (waiting for it here would cost this one)
+        if not single_level:
+            self._levels_ahead = level > first   # this cycle needed more than its first level: the next one starts two at once
+        if out is None or out.best_index < 0:
+            return None
+        # output packing: positions, lon / lat samples, shifted orientations, steering angles and yaw rates in one pass in C
+        blk = out.best_states
+        buf = _capi.pack_trajectory(blk, self.dt, self.vehicle_params.wheelbase, self.x_0.orientation)
+        t0, factor, n = self.x_0.time_step, self.config.planning.factor, blk.shape[1]
+        theta, v, acc, kappa = blk[2], blk[3], blk[4], blk[5]
+        pos, sd, th_c, steer, yaw, yaw0 = buf[:, 0:2], buf[:, 2:4], buf[:, 10], buf[:, 11], buf[:, 12], self.x_0.yaw_rate
+        new_state, RS, CS = object.__new__, ReactivePlannerState, CustomState
+
+        def cart_state(i):
+            st = new_state(RS)
+            st.__dict__ = {"time_step": t0 + factor * i, "position": pos[i], "orientation": float(th_c[i]), "velocity": float(v[i]),
+                           "steering_angle": float(steer[i]), "acceleration": float(acc[i]), "yaw_rate": float(yaw[i]) if i else yaw0}
+            return st
+
+        def curv_state(i):
+            sc = new_state(CS)
+            sc.__dict__ = {"time_step": t0 + factor * i, "position": sd[i], "orientation": float(theta[i]), "velocity": float(v[i]),
+                           "acceleration": float(acc[i]), "yaw_rate": float(kappa[i])}
+            return sc
+        return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)),
+                buf[:, 4:7].tolist(), buf[:, 7:10].tolist())
 
     def _compute_standstill_trajectory(self) -> TrajectorySample:
         """reactive_planner.py:667-713 (arrays of length N, not N + 1, as in the reference)."""

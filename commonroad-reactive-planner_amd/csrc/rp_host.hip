@@ -98,6 +98,14 @@ struct rp_ctx {
     size_t cap_lazy_states = 0;
     int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
     int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
+    // a plan whose kernels are on the stream and whose result has not been collected (rp_plan_begin .. rp_plan_wait)
+    struct Pending {
+        bool active = false, cin = false, skip_eval = false, ticket = false, done = false, time_valid = false, mat = false, coeffs = false;
+        unsigned long long seq = 0;
+        int grid = 0;
+        KArgs ka{};
+        std::chrono::steady_clock::time_point tp0, tp1;
+    } pending;
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
@@ -639,7 +647,9 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_ro
 
 // eval -> finalize (-> count for huge batches) (-> winner re-evaluation when nothing was materialised).
 // The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
-int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
+int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states);
+int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, bool want_rows) {
+    double *const best_states = want_rows ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
     const int n = ka.N + 1;
     int rc;
     if ((rc = ensure_result(c, n)) != RP_OK) return rc;
@@ -824,8 +834,26 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         else launch_eval(c, kw, 1, true, cin, std::getenv("RP_AMD_WINNER_G_AS_BATCH") ? G : 64);
     }
     HIP_TRY(c, hipGetLastError());
-    const auto tp1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-    bool done = lazy_done;
+    rp_ctx::Pending &pd = c->pending;
+    pd.active = true; pd.cin = cin; pd.skip_eval = skip_eval; pd.ticket = ticket; pd.done = lazy_done; pd.time_valid = time_valid;
+    pd.seq = seq; pd.grid = grid; pd.ka = ka; pd.tp0 = tp0;
+    pd.tp1 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+    return RP_OK;
+}
+
+// Second half: wait for the completion ticket of the plan whose kernels pipeline_begin put on the stream, unpack the result.
+int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
+    rp_ctx::Pending &pd = c->pending;
+    if (!pd.active) return fail(c, RP_ESTATE, "no plan in flight on this context");
+    pd.active = false;
+    const KArgs &ka = pd.ka;
+    const bool cin = pd.cin, skip_eval = pd.skip_eval, ticket = pd.ticket, time_valid = pd.time_valid;
+    const unsigned long long seq = pd.seq;
+    const int n = ka.N + 1, grid = pd.grid;
+    (void)grid;
+    ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
+    const auto tp0 = pd.tp0, tp1 = pd.tp1;
+    bool done = pd.done;
     if (ticket && !done) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
         const volatile unsigned long long *flag = &hrb_host->seq;
         const auto t_start = std::chrono::steady_clock::now();
@@ -912,6 +940,11 @@ int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_re
         result->kernel_ms = ms;
     }
     return RP_OK;
+}
+
+int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
+    const int rc = pipeline_begin(c, ka, mat, cin, skip_eval, best_states != nullptr);
+    return rc != RP_OK ? rc : pipeline_wait(c, result, best_states);
 }
 
 }  // namespace
@@ -1260,8 +1293,30 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
 
 int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
             rp_result *result, double *best_states) {
+    if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
+    const int rc = rp_plan_begin(c, p, cost, g, cand_begin, cand_end, best_states != nullptr ? 1 : 0);
+    return rc != RP_OK ? rc : rp_plan_wait(c, result, best_states);
+}
+
+int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
+    if (!c) return RP_EINVAL;
+    if (!result) return fail(c, RP_EINVAL, "rp_plan_wait: null result");
+    if (!c->pending.active) return fail(c, RP_ESTATE, "rp_plan_wait: no plan in flight on this context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = pipeline_wait(c, result, best_states);
+    if (rc != RP_OK) return rc;
+    c->last = c->pending.ka; c->have_last = true; c->last_mat = c->pending.mat; c->last_coeffs = c->pending.coeffs;
+    return RP_OK;
+}
+
+int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
+                  int32_t want_best_states) {
+    rp_result dummy_result;
+    rp_result *const result = &dummy_result;   // (validate only checks it for null)
+    double *const best_states = want_best_states ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_begin: a plan is already in flight on this context (rp_plan_wait first)");
     c->have_last = false;   // (before anything of the last plan -- inline grids, staging area -- is overwritten: an early return leaves no half-valid plan behind)
     if (c->timing) c->t_entry = std::chrono::steady_clock::now();
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
@@ -1332,9 +1387,9 @@ int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *
     if (c->obs.n_dyn <= 0 && c->obs.n_clus == 0) ka.use_near_mask = 0;
     table_window(c, p, g, ka);
     c->have_last = false;
-    rc = run_pipeline(c, ka, mat, false, false, result, best_states);
+    rc = pipeline_begin(c, ka, mat, false, false, best_states != nullptr);
     if (rc != RP_OK) return rc;
-    c->last = ka; c->have_last = true; c->last_mat = mat; c->last_coeffs = false;
+    c->pending.mat = mat; c->pending.coeffs = false;
     return RP_OK;
 }
 
@@ -1646,6 +1701,30 @@ int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double 
 // Reference-path front end (host only; rp_frontend.h)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out) {
+    if (n < 1 || !states || !out || !(dt > 0.0)) return RP_EINVAL;
+    const double *x = states + (size_t)RP_X * n, *y = states + (size_t)RP_Y * n, *th = states + (size_t)RP_THETA * n;
+    const double *kappa = states + (size_t)RP_KAPPA * n, *s_ = states + (size_t)RP_S * n, *d_ = states + (size_t)RP_D * n;
+    const double *sd = states + (size_t)RP_S_DOT * n, *sdd = states + (size_t)RP_S_DDOT * n;
+    const double *dd = states + (size_t)RP_D_DOT * n, *ddd = states + (size_t)RP_D_DDOT * n;
+    const double lo = x0_orientation - M_PI, hi = x0_orientation + M_PI;
+    for (int i = 0; i < n; ++i) {
+        double *o = out + (size_t)i * 13;
+        o[0] = x[i]; o[1] = y[i]; o[2] = s_[i]; o[3] = d_[i];
+        o[4] = s_[i]; o[5] = sd[i]; o[6] = sdd[i];
+        o[7] = d_[i]; o[8] = dd[i]; o[9] = ddd[i];
+        double t = th[i];   // shift_orientation (utility/general.py:49-55): into [x_0.orientation - pi, x_0.orientation + pi]
+        if (t == t && std::fabs(t) < 1e300) {
+            while (t < lo) t += 2.0 * M_PI;
+            while (t > hi) t -= 2.0 * M_PI;
+        }
+        o[10] = t;
+        o[11] = std::atan2(wheelbase * kappa[i], 1.0);                 // reactive_planner.py:539
+        o[12] = i > 0 ? (th[i] - th[i - 1]) / dt : 0.0;               // :535 (state 0 carries x_0.yaw_rate: the caller's)
+    }
+    return RP_OK;
+}
 
 int rp_build_reference(int32_t n_in, const double *xy_in, int32_t smooth, double resample_step, int32_t cap, int32_t *n_out,
                        double *xy_out, double *ref_pos, double *ref_theta, double *ref_curv, double *ref_curv_d) {

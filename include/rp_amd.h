@@ -187,6 +187,17 @@ int rp_set_obstacles(rp_ctx *ctx, int32_t n_sobb, const double *sobb, int32_t n_
 int rp_plan(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids,
             int64_t cand_begin, int64_t cand_end, rp_result *result, double *best_states);
 
+/* The same call in two halves.  rp_plan_begin validates, stages and puts the kernels of the plan on the context's stream and
+ * returns; rp_plan_wait waits for the completion ticket the last kernel writes into pinned host memory and unpacks the result
+ * (rp_plan = begin + wait).  Between the two the host is free -- the replanning loop packs the previous cycle's output, a
+ * planner starts the next sampling level on a second context (plan() visits its levels one after the other,
+ * reactive_planner.py:616-636: a level without a winner costs a whole round trip before the next can start).
+ * One plan in flight per context; the calls that read "the last plan" refer to the last COLLECTED one.  Plans whose chain needs
+ * decisions of the host in between (the cost-ordered collision stage of large batches) run them inside rp_plan_begin. */
+int rp_plan_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids, int64_t cand_begin,
+                  int64_t cand_end, int32_t want_best_states);
+int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *best_states);
+
 /* Generic entry for foreign SamplingSpace plug-ins (sampling.py:165-175): the polynomials come
  * from the plug-in's TrajectorySample objects.  lon_coeffs/lat_coeffs: [C][6]; lon_T/lat_T: [C]
  * delta_tau of each polynomial; traj_len: [C].  Candidate index = list index. */
@@ -240,6 +251,14 @@ int rp_cost_range(rp_ctx *ctx, double *min_cost, double *max_cost, int64_t *n);
  * half width of every segment's rectangle.  Uses the obstacle tables of rp_set_obstacles. */
 int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const double *x, const double *y,
                    const double *theta, int32_t *first_hit, double *boxes);
+
+/* ---- output packing (host only; no GPU involved) ---------------------------------------------------
+   What ReactivePlanner._compute_trajectory_pair makes of the optimal trajectory's arrays (commonroad_rp/reactive_planner.py:
+   514-568), in one pass over the winner's state block [RP_N_ARRAYS][n]: out[n][13] = position x, y | curvilinear position s, d |
+   lon sample s, s', s'' | lat sample d, d', d'' | orientation shifted into [x0_orientation - pi, x0_orientation + pi]
+   (shift_orientation, utility/general.py:49-55) | steering angle atan2(wheelbase * kappa, 1) (:539) | yaw rate
+   (theta[i] - theta[i-1]) / dt (:535; entry 0 is 0: state 0 carries x_0.yaw_rate). */
+int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out);
 
 /* ---- reference-path front end (host only; no GPU involved) ---------------------------------------
    rp_build_reference: what CoordinateSystem.__init__ makes of a route centre line

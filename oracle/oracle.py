@@ -106,15 +106,25 @@ class OracleRun:
 
 
 def plan(inp: PlanInputs, tables: OracleTables, cand_begin: int = 0, cand_end: int = -1, want_states: bool = True,
-         nthreads: int = 1) -> OracleRun:
+         nthreads: int = 1, scratch: dict = None) -> OracleRun:
+    """``scratch``: a dict that keeps the output arrays between calls of the same size (timing loops: fresh arrays of hundreds
+    of MB are page-faulted in by every call; rows the oracle does not write then keep what an earlier call left)."""
     total = inp.n_candidates
     end = total if cand_end < 0 else cand_end
     cnt = end - cand_begin
     n = inp.params.N + 1
-    status = np.zeros(cnt, dtype=np.uint32)
-    cost = np.full(cnt, np.nan)
-    coeffs = np.zeros((cnt, 13))
-    states = np.zeros((cnt, N_ARRAYS, n)) if want_states else None
+    key = (cnt, n, bool(want_states))
+    if scratch is not None and scratch.get("key") == key:
+        status, cost, coeffs, states = scratch["arrays"]
+        status[:] = 0
+        cost[:] = np.nan
+    else:
+        status = np.zeros(cnt, dtype=np.uint32)
+        cost = np.full(cnt, np.nan)
+        coeffs = np.zeros((cnt, 13))
+        states = np.zeros((cnt, N_ARRAYS, n)) if want_states else None
+        if scratch is not None:
+            scratch["key"], scratch["arrays"] = key, (status, cost, coeffs, states)
     best = np.zeros((N_ARRAYS, n))
     res = RpResult()
     tb = tables.c_struct()

@@ -43,6 +43,17 @@ class OracleContext:
         self._inp, self._range, self._N = inp, (cand_begin, end), inp.params.N
         return self._run.out
 
+    def plan_begin(self, inp, cand_begin=0, cand_end=-1, want_best_states=True):
+        self._pending = (inp, cand_begin, cand_end)
+
+    def plan_wait(self):
+        inp, lo, hi = self._pending
+        self._pending = None
+        return self.plan(inp, lo, hi)
+
+    def last_path(self):
+        return 0
+
     def plan_coeffs(self, params, cost, lon_coeffs, lat_coeffs, lon_T, traj_len, want_best_states=True):
         self._run = oracle.plan_coeffs(params, cost, self._tables(), lon_coeffs, lat_coeffs, traj_len)
         self._range, self._N = (0, len(traj_len)), params.N

@@ -100,3 +100,77 @@ def test_state_list_is_a_list_and_keeps_yaw_rate_none():
     again = pickle.loads(pickle.dumps(sl))
     assert type(again) is list and len(again) == n and again[3].velocity == sl[3].velocity
     assert [s.time_step for s in sl] == [rp.x_0.time_step + i for i in range(n)]
+
+
+def _plan_summary(res, rp):
+    head = (rp.infeasible_count_kinematics, rp.infeasible_count_collision, dict(rp.infeasible_reason_dict))
+    if res is None:
+        return head, None
+    cart, cvln, lon, lat = res
+    c = np.array([[st.time_step, st.position[0], st.position[1], st.orientation, st.velocity, st.acceleration, st.steering_angle]
+                  + ([] if st.yaw_rate is None else [st.yaw_rate]) for st in cart.state_list], dtype=float)
+    v = np.array([[st.time_step, st.position[0], st.position[1], st.orientation, st.velocity, st.acceleration, st.yaw_rate]
+                  for st in cvln.state_list], dtype=float)
+    return head, (c, v, np.array(lon), np.array(lat))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fast_cycle_equals_general_cycle(name):
+    """``plan()`` of the stand-alone planner takes a cycle without bundle / sample / container objects when nothing needs them
+    (``_plan_fast``: level loop on the arrays, output packing in ``rp_pack_trajectory``).  Same result as the general loop:
+    counters and reasons exact, positions / lon / lat samples exact (copies of the same block), angles to 1e-13 (libm's atan2
+    against NumPy's)."""
+    from _oracle_ctx import OracleContext
+    fast, _ = build_planner_from_plan_golden(name, OracleContext)
+    slow, _ = build_planner_from_plan_golden(name, OracleContext)
+    slow._get_optimal_trajectory = slow._get_optimal_trajectory        # (an instance attribute: the general loop)
+    assert not slow._fast_path_ok()
+    a, b = _plan_summary(fast.plan(), fast), _plan_summary(slow.plan(), slow)
+    assert a[0] == b[0]
+    assert (a[1] is None) == (b[1] is None)
+    if a[1] is not None:
+        for x, y in zip(a[1], b[1]):
+            np.testing.assert_allclose(x, y, rtol=0, atol=1e-13)
+        np.testing.assert_array_equal(a[1][2], b[1][2])
+        np.testing.assert_array_equal(a[1][3], b[1][3])
+
+
+def test_next_level_starts_while_the_current_one_is_on_the_device():
+    """A cycle whose first level has no winner costs a whole device round trip before the second can start
+    (reactive_planner.py:616-636).  After such a cycle the planner puts level i + 1 on a second context right behind level i:
+    both are on the device before the first result is waited for; results as before."""
+    from _oracle_ctx import OracleContext
+    log = []
+
+    class Logged(OracleContext):
+        def plan_begin(self, inp, *a, **k):
+            log.append(("begin", inp.n_candidates))
+            return super().plan_begin(inp, *a, **k)
+
+        def plan_wait(self):
+            log.append(("wait",))
+            self._in_wait = True
+            try:
+                return super().plan_wait()
+            finally:
+                self._in_wait = False
+
+        def plan(self, inp, *a, **k):
+            if not getattr(self, "_in_wait", False):
+                log.append(("plan", inp.n_candidates))
+            return super().plan(inp, *a, **k)
+
+    name = "plan_all_collide"          # (no level has a winner: plan() visits all three)
+    ref, z = build_planner_from_plan_golden(name, OracleContext)
+    want = _plan_summary(ref.plan(), ref)
+    rp, _ = build_planner_from_plan_golden(name, Logged)
+    assert rp._fast_path_ok()
+    first = _plan_summary(rp.plan(), rp)
+    assert [e[0] for e in log] == ["plan", "plan", "plan"] and rp._levels_ahead      # level by level, and it took more than one
+    del log[:]
+    second = _plan_summary(rp.plan(), rp)
+    # two levels on the device before the first wait; the third starts (on the context level 1 has left) before the second is waited for
+    assert [e[0] for e in log] == ["begin", "begin", "wait", "begin", "wait", "wait"]
+    for got in (first, second):
+        assert got == want
+    rp.close()
