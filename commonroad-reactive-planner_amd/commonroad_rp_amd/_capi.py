@@ -229,6 +229,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_select": (C.c_int, [ctx, dp, C.c_int64, C.POINTER(RpResult), dp]),
         "rp_cost_range": (C.c_int, [ctx, dp, dp, C.POINTER(C.c_int64)]),
         "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
+        "rp_pyset_order": (C.c_int, [C.c_int32, dp, C.c_int32, dp, ip]),
+        "rp_corridor_coeffs": (C.c_int, [C.c_int32, dp, ip, dp, dp, ip, dp, C.c_int32, dp, dp, C.c_int64, C.POINTER(C.c_int64), dp, dp, dp, ip, dp, dp]),
         "rp_build_reference": (C.c_int, [C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, ip, dp, dp, dp, dp, dp]),
         "rp_project": (C.c_int, [C.c_int32, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "rp_initial_state": (C.c_int, [C.c_int32, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -258,11 +260,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory")
+_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+                          "rp_corridor_coeffs")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_cost_range", "rp_check_swept", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
+                    "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
 
 
@@ -281,6 +284,43 @@ def pack_trajectory(states: np.ndarray, dt: float, wheelbase: float, x0_orientat
     if rc != 0:
         raise RpError(f"rp_pack_trajectory -> {rc}")
     return out
+
+
+def pyset_order(values, union_zero: bool = False) -> np.ndarray:
+    """``rp_pyset_order``: the values of ``set(values)`` (``set(values).union({0})``) in the iteration order of a CPython set, as
+    the library restates it."""
+    v = f64(values)
+    out = np.empty(len(v) + 1)
+    n = C.c_int32(0)
+    rc = load_library().rp_pyset_order(len(v), dptr(v), int(bool(union_zero)), dptr(out), C.byref(n))
+    if rc != 0:
+        raise RpError(f"rp_pyset_order -> {rc}")
+    return out[:n.value].copy()
+
+
+def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0_lon, x0_lat, cap: int = 32768):
+    """``rp_corridor_coeffs``: (lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])."""
+    lib = load_library()
+    T, v_low, v_up, boxes = f64(T), f64(v_low), f64(v_up), f64(boxes)
+    traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
+    box_off = np.ascontiguousarray(box_off, dtype=np.int32)
+    x0_lon, x0_lat = f64(x0_lon), f64(x0_lat)
+    ipt = C.POINTER(C.c_int32)
+    for _ in range(2):
+        lon, lat = np.empty((cap, 6)), np.empty((cap, 6))
+        lt, le, de = np.empty(cap), np.empty(cap), np.empty(cap)
+        tl = np.empty(cap, dtype=np.int32)
+        cnt = C.c_int64(0)
+        rc = lib.rp_corridor_coeffs(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
+                                    dptr(boxes), int(n_samples), dptr(x0_lon), dptr(x0_lat), cap, C.byref(cnt), dptr(lon), dptr(lat),
+                                    dptr(lt), tl.ctypes.data_as(ipt), dptr(le), dptr(de))
+        k = int(cnt.value)
+        if rc == 0:
+            return lon[:k], lat[:k], lt[:k], tl[:k], le[:k], de[:k]
+        if rc != -4:
+            raise RpError(f"rp_corridor_coeffs -> {rc}")
+        cap = k
+    raise RpError("rp_corridor_coeffs: output size changed between calls")
 
 
 # ---- reference-path front end (host-only entry points: no context, no GPU) -------------------------

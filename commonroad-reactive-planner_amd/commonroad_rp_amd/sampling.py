@@ -203,6 +203,7 @@ class CorridorSampling(SamplingSpace):
         self.horizon = config.planning.dt * config.planning.time_steps_computation
         self.samples_t = TimeSampling(config.sampling.t_min, self.horizon, config.sampling.num_sampling_levels, self.dt)   # :289
         self._corridor = None
+        self._nodes_are_boxes = False
         self._velocity_constraints: Dict[int, list] = dict()
         self._dict_level_to_num_samples: Dict[int, int] = dict()
         self.set_dict_number_of_samples()
@@ -215,6 +216,9 @@ class CorridorSampling(SamplingSpace):
     def driving_corridor(self, corridor):
         self._corridor = corridor
         self._velocity_constraints = {k: list(self._ops.lon_velocity_interval_connected_set(nodes)) for k, nodes in corridor.items()}   # :311-315
+        from . import corridor as _corridor
+        self._nodes_are_boxes = all(type(b) is _corridor.ReachBox for nodes in corridor.values() for b in nodes)
+        self.__dict__.pop("_native_cache", None)
 
     # (the planner assigns samples_d / samples_v in set_*_sampling_parameters; this space only keeps the bounds, :317-325)
     samples_d = property(lambda self: None, lambda self, ps: self.__dict__.update(_d_min=getattr(ps, "low", None), _d_max=getattr(ps, "up", None)))
@@ -273,7 +277,70 @@ class CorridorSampling(SamplingSpace):
 
     def coeffs_at_level(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str, low_vel_mode: bool):
         """Batch view: ``(lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])`` of the
-        candidates ``generate_trajectories_at_level`` would return, in the same order, without one Python object per
+        candidates ``generate_trajectories_at_level`` would return, in the same order.  With this module's own corridor
+        operations (``corridor.ReachBox`` nodes) the list is produced by the library (``rp_corridor_coeffs``, host C++: the
+        corridor's boxes per time sample go in, the coefficient arrays come out; the set-iteration order the reference's
+        candidate order rests on is restated there and checked against this interpreter's sets on first use); with foreign
+        reach operations, or should that check ever fail, by ``_coeffs_at_level_py``."""
+        if self._corridor is None:
+            raise AttributeError("<CorridorSampling>: Please set a driving corridor.")
+        if self._native_ok():
+            n = self._dict_level_to_num_samples[level_sampling]
+            first_step = min(self._corridor.keys())
+            t_set = self.samples_t.samples_at_level(level_sampling)
+            key = (id(t_set), len(t_set), id(self._corridor))
+            hit = self.__dict__.get("_native_cache")
+            if hit is None or hit[0] != key or hit[1] is not t_set or hit[2] is not self._corridor:
+                T = np.array([float(t) for t in t_set], dtype=np.float64)
+                tl = np.array([len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in T], dtype=np.int32)   # reactive_planner.py:733,748
+                steps = [round(t / self.dt) + first_step for t in t_set]                                             # :359
+                low = np.array([self._velocity_constraints[k][0] for k in steps], dtype=np.float64)
+                up = np.array([self._velocity_constraints[k][1] for k in steps], dtype=np.float64)
+                off = np.zeros(len(steps) + 1, dtype=np.int32)
+                rows = []
+                for j, k in enumerate(steps):
+                    nodes = self._corridor[k]
+                    rows.extend((b.p_lon_min, b.p_lon_max, b.p_lat_min, b.p_lat_max, b.v_lon_min, b.v_lon_max) for b in nodes)
+                    off[j + 1] = len(rows)
+                boxes = np.array(rows, dtype=np.float64).reshape(-1, 6)
+                hit = self._native_cache = (key, t_set, self._corridor, (T, tl, low, up, off, boxes))
+            T, tl, low, up, off, boxes = hit[3]
+            from . import _capi
+            return _capi.corridor_coeffs(T, tl, low, up, off, boxes, n, x_0_lon, x_0_lat)
+        return self._coeffs_at_level_py(level_sampling, x_0_lon, x_0_lat, longitudinal_mode, low_vel_mode)
+
+    _native_state = None   # None: not checked yet; True / False: the library's set order agrees with this interpreter's
+
+    def _native_ok(self) -> bool:
+        """The library's batch view applies: this module's own reach operations on ReachBox nodes, and the library's restatement
+        of CPython's set iteration order reproduces this interpreter's on a set of probes (a different CPython could order its
+        sets differently: the reference's candidate order is whatever the interpreter it runs on does)."""
+        from . import corridor as _corridor
+        if self._ops is not _corridor:
+            return False
+        cls = CorridorSampling
+        if cls._native_state is None:
+            try:
+                from . import _capi
+                ok = True
+                rng = np.random.default_rng(12345)
+                for n in (3, 5, 9, 17, 21, 33, 65):
+                    for _ in range(6):
+                        lo = float(rng.uniform(-20.0, 20.0))
+                        hi = lo + float(rng.uniform(0.0, 30.0))
+                        v = np.linspace(lo, hi, n)
+                        ok = ok and np.array_equal(_capi.pyset_order(v), np.array(list(set(v)), dtype=float))
+                        w = np.linspace(-abs(lo) - 0.5, abs(hi) + 0.5, n)
+                        ok = ok and np.array_equal(_capi.pyset_order(w, True), np.array([float(x) for x in set(w).union({0})]))
+                cls._native_state = bool(ok)
+            except Exception:
+                cls._native_state = False
+        if not cls._native_state:
+            return False
+        return self._nodes_are_boxes
+
+    def _coeffs_at_level_py(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str, low_vel_mode: bool):
+        """The batch view in NumPy, without one Python object per
         candidate or per longitudinal sample: per time sample the quartics of all velocity samples are solved in one
         ``np.linalg.solve`` call (the same LAPACK routine per system as polynomial_trajectory.py:341-360, so the end positions
         that decide which part of the corridor a sample falls into come out bit for bit), the lateral samples of a set of

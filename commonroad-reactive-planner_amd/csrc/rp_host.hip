@@ -23,6 +23,7 @@
 
 #include "rp_kernels.h"
 #include "rp_frontend.h"
+#include "rp_corridor.h"
 
 namespace {
 
@@ -1722,6 +1723,39 @@ int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelb
         o[10] = t;
         o[11] = std::atan2(wheelbase * kappa[i], 1.0);                 // reactive_planner.py:539
         o[12] = i > 0 ? (th[i] - th[i - 1]) / dt : 0.0;               // :535 (state 0 carries x_0.yaw_rate: the caller's)
+    }
+    return RP_OK;
+}
+
+int rp_pyset_order(int32_t n, const double *values, int32_t union_zero, double *out, int32_t *n_out) {
+    if (n < 0 || (n && !values) || !out || !n_out) return RP_EINVAL;
+    const rpco::PySetF64 base = rpco::PySetF64::from_values(values, n);
+    std::vector<double> v;
+    const double zero = 0.0;
+    if (union_zero) base.union_with(&zero, 1).values(v);
+    else base.values(v);
+    *n_out = (int32_t)v.size();
+    std::memcpy(out, v.data(), v.size() * sizeof(double));   // (at most n + 1 values: the caller's room)
+    return RP_OK;
+}
+
+int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up, const int32_t *box_off,
+                       const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat, int64_t cap, int64_t *count,
+                       double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out, double *lon_end, double *lat_end) {
+    if (nT < 0 || n_samples < 1 || !count || !x0_lon || !x0_lat || (nT && (!T || !traj_len || !v_low || !v_up || !box_off))) return RP_EINVAL;
+    if (nT && box_off[nT] > 0 && !boxes) return RP_EINVAL;
+    rpco::Candidates c;
+    rpco::corridor_candidates(nT, T, traj_len, v_low, v_up, box_off, reinterpret_cast<const rpco::Box *>(boxes), n_samples, x0_lon, x0_lat, c);
+    const int64_t C = (int64_t)c.T.size();
+    *count = C;
+    if (C > cap || (C && (!lon_coeffs || !lat_coeffs || !lon_T || !traj_len_out || !lon_end || !lat_end))) return RP_ENOMEM;   // *count: room needed
+    if (C) {
+        std::memcpy(lon_coeffs, c.lon.data(), sizeof(double) * 6 * (size_t)C);
+        std::memcpy(lat_coeffs, c.lat.data(), sizeof(double) * 6 * (size_t)C);
+        std::memcpy(lon_T, c.T.data(), sizeof(double) * (size_t)C);
+        std::memcpy(traj_len_out, c.traj_len.data(), sizeof(int32_t) * (size_t)C);
+        std::memcpy(lon_end, c.v_end.data(), sizeof(double) * (size_t)C);
+        std::memcpy(lat_end, c.d_end.data(), sizeof(double) * (size_t)C);
     }
     return RP_OK;
 }

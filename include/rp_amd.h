@@ -260,6 +260,22 @@ int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const 
    (theta[i] - theta[i-1]) / dt (:535; entry 0 is 0: state 0 carries x_0.yaw_rate). */
 int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out);
 
+/* ---- adaptive sampling space (host only; no GPU involved) -----------------------------------------
+   rp_corridor_coeffs: the candidates CorridorSampling.generate_trajectories_at_level returns (commonroad_rp/sampling.py:
+   345-397), as the coefficient arrays rp_plan_coeffs takes.  Per time sample k (in the iteration order of the level's time
+   set): duration T[k], traj_len[k], the corridor's velocity interval [v_low[k], v_up[k]] at that time step (:363-364) and its reach
+   nodes boxes[box_off[k] .. box_off[k+1])[6] = p_lon_min, p_lon_max, p_lat_min, p_lat_max, v_lon_min, v_lon_max.  For every
+   velocity of set(np.linspace(v_low, v_up, n_samples)) (:367): quartic to (v, 0) (:368), its end position (:369), the nodes that
+   contain it (:374-375), their connected parts (lateral intervals that overlap or touch, :378), per part the lateral samples
+   set(np.linspace(lo, hi, n_samples)), with the reference path added where the interval straddles it (:382-386), per lateral sample
+   a quintic to (d, 0, 0) over T (:390-392).  Order = the reference's: iteration order of CPython sets of floats (restated,
+   csrc/rp_corridor.h; rp_pyset_order exposes it: the values of set(values), or of set(values).union({0}), in iteration order).
+   Output rows 0 .. *count - 1; with RP_ENOMEM *count is the room needed (cap too small). */
+int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up, const int32_t *box_off,
+                       const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat, int64_t cap, int64_t *count,
+                       double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out, double *lon_end, double *lat_end);
+int rp_pyset_order(int32_t n, const double *values, int32_t union_zero, double *out /* [n + 1] */, int32_t *n_out);
+
 /* ---- reference-path front end (host only; no GPU involved) ---------------------------------------
    rp_build_reference: what CoordinateSystem.__init__ makes of a route centre line
    (commonroad_rp/utility/utils_coordinate_system.py:88-118): duplicate vertices removed (:95-96), with `smooth`

@@ -167,3 +167,55 @@ def test_corridor_candidates_on_every_launch_path(name):
                     have = ((orun.status & 3) == 1) | ((orun.status & 3) == 3) | bool(int(z["draw"]))
                     np.testing.assert_allclose(ctx.fetch_states()[have], orun.states[have], rtol=0, atol=1e-6)
             ctx.close()
+
+
+def test_library_restates_the_interpreters_set_order():
+    """The reference's candidate order is the iteration order of Python sets of floats (sampling.py:367,384-386); the library's
+    batch view restates CPython's set (csrc/rp_corridor.h).  Against this interpreter's own sets: plain sets of np.linspace values
+    of every size the levels use, with duplicates (a degenerate interval), and ``.union({0})`` -- a copy (different table size!)
+    plus the reference path."""
+    from commonroad_rp_amd import _capi
+    rng = np.random.default_rng(7)
+    for trial in range(1500):
+        n = int(rng.choice([3, 5, 9, 17, 21, 33, 65, 129, 257]))
+        lo = float(rng.uniform(-50.0, 50.0))
+        hi = lo if trial % 40 == 0 else lo + float(rng.uniform(0.0, 60.0))
+        v = np.linspace(lo, hi, n)
+        np.testing.assert_array_equal(_capi.pyset_order(v), np.array(list(set(v)), dtype=float))
+        w = np.linspace(-abs(lo) - 0.25, abs(hi) + 0.25, n)
+        np.testing.assert_array_equal(_capi.pyset_order(w, True), np.array([float(x) for x in set(w).union({0})]))
+    assert CorridorSampling._native_state in (None, True)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_library_batch_view_equals_the_numpy_one(name):
+    """rp_corridor_coeffs against the NumPy batch view: same candidates in the same order (T, end velocity, end offset bit for
+    bit), coefficients to 1e-12 (closed-form quartic against the LAPACK solve the reference uses)."""
+    z = _load(name)
+    sp = _space(z)
+    lvl = int(z["level"])
+    assert sp._native_ok()
+    a = sp.coeffs_at_level(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    b = sp._coeffs_at_level_py(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    for k in (2, 3, 4, 5):
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-12)
+    # a larger synthetic corridor (three lanes that merge and split over time), several levels of sample counts
+    s0, v0 = float(z["x0_lon"][0]), max(float(z["x0_lon"][1]), 1.0)
+    cor = {}
+    for q in range(int(z["N"]) + 2):
+        t = q * float(z["dt"])
+        cor[int(z["time_step0"]) + q] = [ReachBox(s0 - 1.0, s0 + 1.6 * v0 * t + 4.0, -2.8, -0.3, 0.5 * v0, 1.3 * v0 + 1.0),
+                                        ReachBox(s0 + 0.3 * v0 * t, s0 + 1.8 * v0 * t + 6.0, -0.5, 1.4, 0.6 * v0, 1.4 * v0 + 1.0),
+                                        ReachBox(s0 + 0.8 * v0 * t + 2.0, s0 + 2.0 * v0 * t + 8.0, 2.0, 3.0, 0.9 * v0, 1.5 * v0 + 1.0)]
+    sp.driving_corridor = cor
+    for n_samples in (3, 9, 21):
+        sp._dict_level_to_num_samples = {k: n_samples for k in range(sp.num_sampling_levels)}
+        a = sp.coeffs_at_level(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+        b = sp._coeffs_at_level_py(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+        assert len(a[2]) == len(b[2]) > 0
+        for k in (2, 3, 4, 5):
+            np.testing.assert_array_equal(a[k], b[k])
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-12)
