@@ -51,7 +51,9 @@ def run_closed_loop(planner, max_steps: int, replanning_frequency: Optional[int]
         current_count = len(planner.record_state_list) - 1
         temp = current_count % freq
         if temp == 0:
-            if desired_velocity is not None:
+            if callable(desired_velocity):   # a schedule: desired velocity of this replanning cycle (e.g. hold, then pull away)
+                planner.set_desired_velocity(desired_velocity=desired_velocity(current_count), current_speed=planner.x_0.velocity)
+            elif desired_velocity is not None:
                 planner.set_desired_velocity(desired_velocity=desired_velocity, current_speed=planner.x_0.velocity)
             else:
                 planner.set_desired_velocity(current_speed=planner.x_0.velocity)

@@ -120,6 +120,18 @@ def cfg1(level: int = 3, flags: int = 0, road_boundary: bool = False) -> Workloa
                               description=f"ZAM_Over-1_1, sampling level {level}, N=20" + (", road boundary" if road_boundary else ""))
 
 
+def ramp(level: int = 1, flags: int = 0, road_boundary: bool = False) -> Workload:
+    """ZAM-Ramp-1_1-T-1 at its initial state: standstill on the middle lane (v = 0: standstill branch and low-velocity mode), the
+    reference's sampling levels (N = 20, t_min 0.4), three dynamic obstacles on the neighbouring lanes.  The whole scenario in
+    closed loop: tests/test_ramp_loop.py."""
+    dt, N, t_min = 0.1, 20, 0.4
+    step = int((1 / (level + 1)) / dt)
+    T = sorted(set(np.arange(t_min, round(N * dt + dt, 2), step * dt)) - {round(N * dt + dt, 2)})
+    n = 2 ** (level + 1) + 1
+    return _scenario_workload("ramp", "ZAM-Ramp-1_1-T-1", N, T, n, n, low_vel_threshold=4.0, flags=flags, road_boundary=road_boundary,
+                              desired_speed=8.0, description=f"ZAM-Ramp-1_1-T-1 at standstill, sampling level {level}, N=20")
+
+
 def cfg2(flags: int = 0, road_boundary: bool = False) -> Workload:
     """ZAM_Tjunction-1_42_T-1, 15 x 15 x 31 grid, N = 30, 5 dynamic obstacles."""
     dt, N = 0.1, 30
@@ -289,4 +301,4 @@ def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_fa
     return recorded[:n_states]
 
 
-WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg3f": cfg3f, "cfg4": cfg4, "cfg5": cfg5}
+WORKLOADS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": cfg3, "cfg3f": cfg3f, "cfg4": cfg4, "cfg5": cfg5, "ramp": ramp}

@@ -649,6 +649,53 @@ def run_corridor_case(case):
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# Closed loops over a whole scenario, driven by the reference planner itself through the loop of run_planner.py:61-107
+# (commonroad_rp_amd.harness.run_closed_loop uses only the reference's public methods).
+# ----------------------------------------------------------------------------------------------
+RAMP_HOLD_CYCLES, RAMP_SPEED = 3, 8.0
+
+
+def ramp_schedule(cycle):
+    """desired velocity of replanning cycle `cycle`: hold at standstill, then pull away"""
+    return 0.0 if cycle < RAMP_HOLD_CYCLES else RAMP_SPEED
+
+
+def loop_cases():
+    """ZAM-Ramp-1_1-T-1 (example_scenarios/, no YAML shipped): the ego starts at standstill on the middle lane.  Three cycles at
+    desired velocity 0 (standstill branch of plan(), reactive_planner.py:638-653,667-713), then it pulls away: low-velocity mode
+    (lateral motion over arc length, :594) until the speed crosses low_vel_mode_threshold, time-based sampling after."""
+    sc = np.load(os.path.join(HERE, "scenario_ZAM-Ramp-1_1-T-1.npz"))
+    x, y, th, v = (float(q) for q in sc["init"])
+    xr, yr = x - VEH["wb_rear_axle"] * np.cos(th), y - VEH["wb_rear_axle"] * np.sin(th)   # the planner state sits on the rear axle
+    centre = sc["centre"]
+    # straight route: s = distance from the first vertex along it, d = signed offset
+    e = (centre[-1] - centre[0]) / np.linalg.norm(centre[-1] - centre[0])
+    s0 = float((np.array([xr, yr]) - centre[0]) @ e)
+    d0 = float(-(xr - centre[0][0]) * e[1] + (yr - centre[0][1]) * e[0])
+    tables = ObstacleTables(dyn_obb=sc["dyn_obb"], dyn_t0=int(sc["dyn_t0"]))
+    return [dict(name="loop_zam_ramp", dt=float(sc["dt"]), N=20, t_min=0.4, ref_path=centre, level=1, x0_lon=[s0, v, 0.0],
+                 x0_lat=[d0, 0.0, 0.0], x0_orientation=th, x0_velocity=v, desired_speed=0.0, time_step0=int(sc["init_time_step"]),
+                 obstacles=tables, low_vel_mode_threshold=4.0, steps=45)]
+
+
+def run_loop_case(case):
+    from commonroad_rp_amd.harness import run_closed_loop
+    rp = make_planner(case)
+    rp.record_state_and_input = lambda state: rp._record_state_list.append(state)   # (InputState is a stand-in here)
+    inputs = case_inputs(rp, case)
+    flags = []
+
+    def on_step(k, planner, optimal):
+        flags.append((int(planner._low_vel_mode), int(len(optimal[0].state_list) == planner.N),          # standstill trajectories hold N states
+                      planner._infeasible_count_kinematics, planner._infeasible_count_collision))
+    res = run_closed_loop(rp, max_steps=case["steps"], replanning_frequency=1, desired_velocity=ramp_schedule, on_step=on_step)
+    trace = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration or 0.0, s.steering_angle or 0.0]
+                      for s in res.states], dtype=float)
+    return dict(inputs, completed=int(res.completed), n_replans=res.n_replans, trace=trace, flags=np.array(flags, dtype=np.int64),
+                hold_cycles=RAMP_HOLD_CYCLES, pull_away_speed=RAMP_SPEED, steps=case["steps"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--list", action="store_true")
@@ -665,6 +712,17 @@ def main():
         lab = out["label"]
         print(f"{case['name']:34s} C={len(lab):5d} feasible={int((lab == 1).sum()):5d} kin={int((lab == 2).sum()):4d} coll={int((lab == 3).sum()):4d} "
               f"none={int((lab == 0).sum()):4d} winner={out['winner']} ncol={out['n_infeasible_collision']}")
+    for case in loop_cases():
+        if args.list:
+            print(case["name"])
+            continue
+        if args.only and case["name"] != args.only:
+            continue
+        out = run_loop_case(case)
+        np.savez_compressed(os.path.join(HERE, case["name"] + ".npz"), **out)
+        fl = out["flags"]
+        print(f"{case['name']:34s} completed={out['completed']} replans={out['n_replans']} standstill cycles={int(fl[:, 1].sum())} "
+              f"low-velocity cycles={int(fl[:, 0].sum())} final speed={out['trace'][-1, 4]:.3f} m/s at x={out['trace'][-1, 1]:.2f}")
     for case in plan_cases():
         if args.list:
             print(case["name"])

@@ -20,7 +20,13 @@ ROUTES = {
     "ZAM_Tjunction-1_42_T-1": ["50195", "50209", "50203"],   # left turn at the junction
     "DEU_Test-1_1_T-1": ["1", "3"],
     "ZAM_Over-1_1": ["1000"],
+    # the acceleration lane scenario: initial state at standstill on the middle lane (lanelet 5), goal 50 m ahead
+    "ZAM-Ramp-1_1-T-1": ["5", "6", "7", "8"],
 }
+# metres of straight lead-in put in front of a route's centre line.  The ramp scenario starts with the vehicle's CENTRE on the
+# first vertex of its lanelet, i.e. the rear axle -- the planner's reference point (state.py:52-55) -- 1.4 m in front of the
+# polyline: pycrccosy extends a reference path at both ends, this build's polyline transform does not
+LEAD_IN = {"ZAM-Ramp-1_1-T-1": 5.0}
 
 
 def pts(node):
@@ -52,6 +58,9 @@ def main():
             c = 0.5 * (left + right)
             centre.append(c if not centre else c[1:])
         centre = np.concatenate(centre, axis=0)
+        if name in LEAD_IN:
+            d = (centre[1] - centre[0]) / np.linalg.norm(centre[1] - centre[0])
+            centre = np.concatenate(([centre[0] - LEAD_IN[name] * d], centre), axis=0)
         left_b = np.concatenate([pts(lanelets[l].find("leftBound")) for l in route])
         right_b = np.concatenate([pts(lanelets[l].find("rightBound")) for l in route])
         dyn_nodes = root.findall("dynamicObstacle")

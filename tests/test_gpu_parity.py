@@ -381,7 +381,8 @@ def test_horizon_lengths_around_lane_group_boundaries(ctx, N):
                                                    ("cfg3", 58000, 2543, False), ("cfg4", 250000, 3000, False),
                                                    ("cfg5obs", 500000, 3000, False), ("cfg3", 12000, 3000, True),
                                                    ("cfg2rb", 0, 7440, False), ("cfg3rb", 20000, 3000, False),
-                                                   ("cfg4rb", 100000, 3000, False), ("cfg2rb", 0, 7440, True)])
+                                                   ("cfg4rb", 100000, 3000, False), ("cfg2rb", 0, 7440, True),
+                                                   ("ramp", 0, 120, False), ("ramprb", 0, 120, False)])
 def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
     """The benchmark workloads (many dynamic obstacles, extended horizons, curved routes): labels -- in particular
     INFEASIBLE_COLLISION -- exact against the oracle's brute-force query, in production and in draw mode.  This is

@@ -1,0 +1,54 @@
+"""ZAM-Ramp-1_1-T-1 in closed loop (reference: example_scenarios/ZAM-Ramp-1_1-T-1.xml; the loop of run_planner.py:61-107): the
+ego starts at standstill, holds for three cycles (standstill branch of plan(), reactive_planner.py:638-653,667-713), then pulls
+away -- low-velocity mode (lateral motion over arc length, :594) until the speed crosses low_vel_mode_threshold, time-based
+sampling after.  45 replanning cycles; the fixture tests/golden/loop_zam_ramp.npz holds the state sequence the REFERENCE planner
+traced (tests/golden/make_golden.py::run_loop_case; scenario data: tests/golden/make_scenarios.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from _golden import GOLDEN_DIR, build_planner_from_plan_golden
+from commonroad_rp_amd.harness import run_closed_loop
+
+
+def _run(backend):
+    z = dict(np.load(os.path.join(GOLDEN_DIR, "loop_zam_ramp.npz")))
+    hold, speed = int(z["hold_cycles"]), float(z["pull_away_speed"])
+    np.savez(os.path.join(GOLDEN_DIR, "_tmp_loop_plan.npz"), **dict(z, continuous=0, via_scenario=0, planned=1))
+    try:
+        rp, _ = build_planner_from_plan_golden("_tmp_loop_plan", backend)
+    finally:
+        os.remove(os.path.join(GOLDEN_DIR, "_tmp_loop_plan.npz"))
+    flags = []
+
+    def on_step(k, planner, optimal):
+        flags.append((int(planner._low_vel_mode), int(len(optimal[0].state_list) == planner.N),
+                      planner.infeasible_count_kinematics, planner.infeasible_count_collision))
+    res = run_closed_loop(rp, max_steps=int(z["steps"]), replanning_frequency=1,
+                          desired_velocity=lambda c: 0.0 if c < hold else speed, on_step=on_step)
+    trace = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration or 0.0, s.steering_angle or 0.0]
+                      for s in res.states], dtype=float)
+    if hasattr(rp, "close"):
+        rp.close()
+    return z, res, trace, np.array(flags, dtype=np.int64)
+
+
+def _check(z, res, trace, flags, atol):
+    assert res.completed and res.n_replans == int(z["n_replans"]) == 45
+    np.testing.assert_array_equal(flags[:, :2], z["flags"][:, :2])          # which cycles ran in low-velocity mode / ended at standstill
+    np.testing.assert_array_equal(flags[:, 2:], z["flags"][:, 2:])          # rejected candidates (kinematics, collisions) per cycle
+    assert flags[:, 1].sum() == 3 and 0 < flags[:, 0].sum() < len(flags)    # standstill, low-velocity and time-based cycles all occur
+    np.testing.assert_allclose(trace, z["trace"], rtol=0, atol=atol)
+    assert trace[-1, 4] > 7.0                                               # it did pull away
+
+
+def test_ramp_closed_loop_cpu_glue():
+    from _oracle_ctx import OracleContext
+    _check(*_run(OracleContext), atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_ramp_closed_loop_gpu():
+    from commonroad_rp_amd._capi import RpContext
+    _check(*_run(RpContext), atol=1e-6)
