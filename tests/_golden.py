@@ -13,7 +13,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def case_names():
-    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("scenario_", "plan_", "frontend_", "corridor_")))
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("scenario_", "plan_", "frontend_", "corridor_", "loop_")))
 
 
 class Golden:
