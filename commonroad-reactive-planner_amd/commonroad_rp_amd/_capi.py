@@ -220,6 +220,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_plan_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64, C.c_int32]),
         "rp_plan_wait": (C.c_int, [ctx, C.POINTER(RpResult), dp]),
         "rp_pack_trajectory": (C.c_int, [C.c_int32, dp, C.c_double, C.c_double, C.c_double, dp]),
+        "rp_fast_buffer": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+        "rp_plan_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.c_int32, C.c_int32, C.POINTER(RpResult), C.c_void_p]),
         "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
                                      C.POINTER(RpResult), dp]),
         "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
@@ -261,9 +263,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 _OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
-                          "rp_corridor_coeffs")
+                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_plan_coeffs", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -298,18 +300,23 @@ def pyset_order(values, union_zero: bool = False) -> np.ndarray:
     return out[:n.value].copy()
 
 
-def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0_lon, x0_lat, cap: int = 32768):
-    """``rp_corridor_coeffs``: (lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C])."""
+def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0_lon, x0_lat, buffers: Optional[dict] = None):
+    """``rp_corridor_coeffs``: (lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C]).
+    ``buffers``: a dict that keeps the output arrays between calls (the result then consists of views into them, valid until the
+    next call with the same dict: tens of thousands of candidates are a few MB, whose page faults cost more than the call)."""
     lib = load_library()
     T, v_low, v_up, boxes = f64(T), f64(v_low), f64(v_up), f64(boxes)
     traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
     box_off = np.ascontiguousarray(box_off, dtype=np.int32)
     x0_lon, x0_lat = f64(x0_lon), f64(x0_lat)
     ipt = C.POINTER(C.c_int32)
+    keep = buffers if buffers is not None else {}
+    cap = keep.get("cap", 16384)
     for _ in range(2):
-        lon, lat = np.empty((cap, 6)), np.empty((cap, 6))
-        lt, le, de = np.empty(cap), np.empty(cap), np.empty(cap)
-        tl = np.empty(cap, dtype=np.int32)
+        if keep.get("cap") != cap or "arrays" not in keep:
+            keep["cap"] = cap
+            keep["arrays"] = (np.empty((cap, 6)), np.empty((cap, 6)), np.empty(cap), np.empty(cap, dtype=np.int32), np.empty(cap), np.empty(cap))
+        lon, lat, lt, tl, le, de = keep["arrays"]
         cnt = C.c_int64(0)
         rc = lib.rp_corridor_coeffs(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
                                     dptr(boxes), int(n_samples), dptr(x0_lon), dptr(x0_lat), cap, C.byref(cnt), dptr(lon), dptr(lat),
@@ -319,7 +326,7 @@ def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0
             return lon[:k], lat[:k], lt[:k], tl[:k], le[:k], de[:k]
         if rc != -4:
             raise RpError(f"rp_corridor_coeffs -> {rc}")
-        cap = k
+        cap = max(k, 2 * cap)
     raise RpError("rp_corridor_coeffs: output size changed between calls")
 
 
@@ -463,6 +470,39 @@ class RpContext:
         self._N = inp.params.N
         self._last_count = res.n_candidates
         return self._output(res, best)
+
+    def plan_packed(self, params: RpParams, cost: RpCost, T, traj_len, L, D):
+        """``rp_plan_packed``: one sampling level -> (the context's ``RpResult`` struct, state block [14, N + 1], packed output
+        [N + 1, 13]) -- the last two ``None`` without a winner.  The grids go through the context's own buffer (four slice
+        assignments instead of a struct of four array pointers built per call) and the result comes back as the C struct."""
+        fb = getattr(self, "_fast", None)
+        if fb is None:
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
+            raw = (C.c_char * nbytes.value).from_address(ptr.value)
+            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan_packed)
+        f64v, i32v, call = fb
+        nT, nL, nD = len(T), len(L), len(D)
+        nd = nT + nL + nD
+        if nd * 8 + nT * 4 > f64v.nbytes:
+            raise RpError("plan_packed: grids larger than the context's buffer")
+        f64v[0:nT] = T
+        f64v[nT:nT + nL] = L
+        f64v[nT + nL:nd] = D
+        i32v[2 * nd:2 * nd + nT] = traj_len
+        n = params.N + 1
+        out = np.empty((N_ARRAYS + 13) * n)
+        res = self._res
+        rc = call(self._h, params, cost, nT, nL, nD, res, out.ctypes.data)
+        if rc != 0:
+            self._check(rc, "rp_plan_packed")
+        self._N = params.N
+        self._last_count = res.n_candidates
+        self._serial += 1
+        self._last_best = None
+        if res.best_index < 0:
+            return res, None, None
+        return res, out[:N_ARRAYS * n].reshape(N_ARRAYS, n), out[N_ARRAYS * n:].reshape(n, 13)
 
     def plan_begin(self, inp: PlanInputs, cand_begin: int = 0, cand_end: int = -1, want_best_states: bool = True):
         """First half of ``plan``: the kernels of the plan go onto the context's stream and the call returns; ``plan_wait``

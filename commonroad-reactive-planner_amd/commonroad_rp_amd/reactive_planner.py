@@ -820,6 +820,31 @@ class ReactivePlanner(GpuBackendMixin):
             stale.plan_wait()
             self._rp_inflight = None
         out, started, first = None, None, level   # started: (level, context, inputs) of the plan begun ahead
+        packed_call = getattr(ctx, "plan_packed", None) if (not ahead and hook is None) else None
+        blk = buf = None
+        while packed_call is not None and level < self.sampling_level:
+            # one call per level: grids through the context's own buffer, counters read off the C result, output packed in C
+            T, traj_len, L, D = sp.grids_at_level(level, x_0_lon, x_0_lat, mode)
+            self._reset_statistics()
+            if len(T) * len(L) * len(D):
+                res, blk, buf = packed_call(params, cost, T, traj_len, L, D)
+                self._infeasible_count_kinematics = res.n_candidates - res.n_feasible
+                self._infeasible_count_collision = res.n_collision_before_best
+                rc = res.reason_counts
+                for k, name in _REASON_ITEMS:
+                    if name in rd:
+                        rd[name] = int(rc[k])
+                if blk is not None:
+                    break
+            if single_level:
+                break
+            level += 1
+        if packed_call is not None:
+            if not single_level:
+                self._levels_ahead = level > first
+            if blk is None:
+                return None
+            return self._fast_output(blk, buf)
         while level < self.sampling_level:
             if started is not None and started[0] == level:
                 cur, inp = started[1], started[2]
@@ -867,7 +892,11 @@ class ReactivePlanner(GpuBackendMixin):
             return None
         # output packing: positions, lon / lat samples, shifted orientations, steering angles and yaw rates in one pass in C
         blk = out.best_states
-        buf = _capi.pack_trajectory(blk, self.dt, self.vehicle_params.wheelbase, self.x_0.orientation)
+        return self._fast_output(blk, _capi.pack_trajectory(blk, self.dt, self.vehicle_params.wheelbase, self.x_0.orientation))
+
+    def _fast_output(self, blk, buf):
+        """(Cartesian trajectory, curvilinear trajectory, lon list, lat list) of reactive_planner.py:514-568 from the winner's state
+        block [14, N + 1] and its packed form [N + 1, 13] (``rp_pack_trajectory``); state objects are built on access."""
         t0, factor, n = self.x_0.time_step, self.config.planning.factor, blk.shape[1]
         theta, v, acc, kappa = blk[2], blk[3], blk[4], blk[5]
         pos, sd, th_c, steer, yaw, yaw0 = buf[:, 0:2], buf[:, 2:4], buf[:, 10], buf[:, 11], buf[:, 12], self.x_0.yaw_rate

@@ -306,7 +306,8 @@ class CorridorSampling(SamplingSpace):
                 hit = self._native_cache = (key, t_set, self._corridor, (T, tl, low, up, off, boxes))
             T, tl, low, up, off, boxes = hit[3]
             from . import _capi
-            return _capi.corridor_coeffs(T, tl, low, up, off, boxes, n, x_0_lon, x_0_lat)
+            # (views into arrays this object keeps: valid until the next call -- a level's bundle is done with them by then)
+            return _capi.corridor_coeffs(T, tl, low, up, off, boxes, n, x_0_lon, x_0_lat, self.__dict__.setdefault("_native_buffers", {}))
         return self._coeffs_at_level_py(level_sampling, x_0_lon, x_0_lat, longitudinal_mode, low_vel_mode)
 
     _native_state = None   # None: not checked yet; True / False: the library's set order agrees with this interpreter's

@@ -117,6 +117,7 @@ struct rp_ctx {
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
     std::unordered_map<const void *, hipFunction_t> functions;   // kernel symbol -> function handle (launch_kargs)
+    std::vector<double> fast_buf;   // rp_fast_buffer: grids of rp_plan_packed, written by the caller ([T | L | D | traj_len int32])
     // RP_AMD_TIMING=1: host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
     bool timing = false;
     double t_sum[6] = {0, 0, 0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack | evaluation launch | epilogue launch
@@ -1702,6 +1703,31 @@ int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double 
 // Reference-path front end (host only; rp_frontend.h)
 // ------------------------------------------------------------------------------------------------
 extern "C" {
+
+int rp_fast_buffer(rp_ctx *c, void **ptr, size_t *bytes) {
+    if (!c || !ptr || !bytes) return RP_EINVAL;
+    if (c->fast_buf.empty()) c->fast_buf.assign(4096, 0.0);   // (never resized: the caller keeps views of it for the life of the context)
+    *ptr = c->fast_buf.data();
+    *bytes = c->fast_buf.size() * sizeof(double);
+    return RP_OK;
+}
+
+int rp_plan_packed(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t nT, int32_t nL, int32_t nD, rp_result *result, double *out) {
+    if (!c) return RP_EINVAL;
+    if (!p || !cost || !result || !out) return fail(c, RP_EINVAL, "rp_plan_packed: null argument");
+    if (nT < 0 || nL < 0 || nD < 0 || c->fast_buf.empty() ||
+        ((size_t)nT + nL + nD) * sizeof(double) + (size_t)nT * sizeof(int32_t) > c->fast_buf.size() * sizeof(double))
+        return fail(c, RP_EINVAL, "rp_plan_packed: grids do not fit the buffer of rp_fast_buffer (or it was never asked for)");
+    const double *b = c->fast_buf.data();
+    rp_grids g;
+    g.nT = nT; g.nL = nL; g.nD = nD; g.reserved_ = 0;
+    g.T = b; g.L = b + nT; g.D = b + nT + nL;
+    g.traj_len = reinterpret_cast<const int32_t *>(b + nT + nL + nD);
+    const int rc = rp_plan(c, p, cost, &g, 0, -1, result, out);
+    if (rc != RP_OK || result->best_index < 0) return rc;
+    const int n = p->N + 1;
+    return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
+}
 
 int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out) {
     if (n < 1 || !states || !out || !(dt > 0.0)) return RP_EINVAL;

@@ -259,6 +259,13 @@ int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const 
    (shift_orientation, utility/general.py:49-55) | steering angle atan2(wheelbase * kappa, 1) (:539) | yaw rate
    (theta[i] - theta[i-1]) / dt (:535; entry 0 is 0: state 0 carries x_0.yaw_rate). */
 int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out);
+/* One replanning level in one call, for a binding whose per-argument cost matters (ctypes: ~0.5 us per array argument): the grids
+   come from a buffer of the context the caller has filled -- rp_fast_buffer hands it out once, 32 KB, valid for the life of the
+   context: [T (nT doubles) | L (nL) | D (nD) | traj_len (nT int32)] -- and the result leaves as rp_plan's plus, behind the winner's
+   state block in `out` ([RP_N_ARRAYS][N + 1], then [N + 1][13]), the packed output of rp_pack_trajectory. */
+int rp_fast_buffer(rp_ctx *ctx, void **ptr, size_t *bytes);
+int rp_plan_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t nT, int32_t nL, int32_t nD, rp_result *result,
+                   double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */);
 
 /* ---- adaptive sampling space (host only; no GPU involved) -----------------------------------------
    rp_corridor_coeffs: the candidates CorridorSampling.generate_trajectories_at_level returns (commonroad_rp/sampling.py:

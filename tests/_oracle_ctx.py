@@ -43,6 +43,13 @@ class OracleContext:
         self._inp, self._range, self._N = inp, (cand_begin, end), inp.params.N
         return self._run.out
 
+    def plan_packed(self, params, cost, T, traj_len, L, D):
+        from commonroad_rp_amd._capi import PlanInputs, pack_trajectory
+        out = self.plan(PlanInputs(params, cost, T, traj_len, L, D))
+        if out.best_index < 0:
+            return out, None, None
+        return out, out.best_states, pack_trajectory(np.ascontiguousarray(out.best_states), params.dt, params.wheelbase, params.x0_orientation)
+
     def plan_begin(self, inp, cand_begin=0, cand_end=-1, want_best_states=True):
         self._pending = (inp, cand_begin, cand_end)
 
