@@ -286,6 +286,8 @@ def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_fa
     factory = backend_factory or RpContext
 
     class Recording(factory):
+        plan_packed = None   # (the planner's one-call cycle bypasses plan(): off, so that every level's inputs pass through here)
+
         def plan(self, inp, *a, **k):
             recorded.append(PlanInputs(copy_params(inp.params), inp.cost, inp.T.copy(), inp.traj_len.copy(), inp.L.copy(),
                                        inp.D.copy()))

@@ -16,7 +16,8 @@ def test_generator_is_seeded_and_varied():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("path,first", [("single_launch", 0), ("single_launch", 100), ("two_kernel", 200), ("g32", 300), ("g64", 400)])
+@pytest.mark.parametrize("path,first", [("single_launch", 0), ("single_launch", 100), ("two_kernel", 200), ("g32", 300), ("g64", 400), ("lazy", 500),
+                                        ("lazy", 600)])
 def test_random_scenarios_match_oracle(path, first):
     from _paths import launch_path_env
     from commonroad_rp_amd._capi import RpContext
