@@ -790,12 +790,15 @@ class ReactivePlanner(GpuBackendMixin):
         (subclass or instance attribute): then ``plan()`` may skip the bundle, winner-sample and container objects, none of
         which it reads itself (the standstill branch, which does, is left to the general loop)."""
         cls, d = type(self), self.__dict__
-        return (type(self.sampling_space) is FixedIntervalSampling and not self._draw_traj_set and self.shard_dist is None
+        plain = cls.__dict__.get("_fast_cls_ok")   # (per class: none of the cycle's methods is overridden by it)
+        if plain is None:
+            plain = (cls._get_optimal_trajectory is GpuBackendMixin._get_optimal_trajectory
+                     and cls._create_trajectory_bundle is GpuBackendMixin._create_trajectory_bundle
+                     and cls._compute_trajectory_pair is ReactivePlanner._compute_trajectory_pair
+                     and cls._compute_standstill_trajectory is ReactivePlanner._compute_standstill_trajectory)
+            cls._fast_cls_ok = plain
+        return (plain and type(self.sampling_space) is FixedIntervalSampling and not self._draw_traj_set and self.shard_dist is None
                 and self.x_0.velocity > 0.05 and not self.config.planning.continuous_collision_check
-                and cls._get_optimal_trajectory is GpuBackendMixin._get_optimal_trajectory
-                and cls._create_trajectory_bundle is GpuBackendMixin._create_trajectory_bundle
-                and cls._compute_trajectory_pair is ReactivePlanner._compute_trajectory_pair
-                and cls._compute_standstill_trajectory is ReactivePlanner._compute_standstill_trajectory
                 and "_compute_trajectory_pair" not in d and "_get_optimal_trajectory" not in d and "_create_trajectory_bundle" not in d)
 
     def _plan_fast(self, x_0_lon, x_0_lat, level: int, single_level: bool):

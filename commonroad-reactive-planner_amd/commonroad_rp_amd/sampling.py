@@ -144,7 +144,7 @@ class FixedIntervalSampling(SamplingSpace):
         if hit is None or hit[0] is not sample_set or len(hit[1]) != len(sample_set):
             if len(cache) > 64:
                 cache.clear()
-            hit = cache[id(sample_set)] = (sample_set, np.array([float(v) for v in sample_set], dtype=np.float64))
+            hit = cache[id(sample_set)] = (sample_set, np.fromiter(sample_set, dtype=np.float64, count=len(sample_set)))
         return hit[1]
 
     def _cached_T(self, t_set: set):
