@@ -1,7 +1,7 @@
 #!/bin/bash
 # One measurement pass for a round tag: the default bench line, rocprofv3 kernel stats + trace summary of the SAME command,
 # PMC traffic (WRITE_SIZE / FETCH_SIZE, separate passes) and FP64 instruction counters per workload.
-# usage (GPU box): bash profiles/collect_round.sh r02a [quick]      -> gpurun_out/<tag>/...
+# usage (GPU box): bash profiles/collect_round.sh r03a [quick]      -> gpurun_out/<tag>/...
 set -e
 TAG=${1:-r02x}; QUICK=${2:-}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
@@ -17,7 +17,7 @@ rm -rf $OUT/prof
 echo "trace done"
 cd $ROOT
 [ -n "$QUICK" ] && exit 0
-for wl in cfg2 cfg3 cfg4 cfg5; do
+for wl in cfg2 cfg3 cfg3f cfg4 cfg5; do
   steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8
   bash profiles/collect_pmc.sh $wl $steps draw > $OUT/pmc_${wl}_draw.json 2> $OUT/pmc_${wl}_draw.err
   bash profiles/collect_fp64.sh $wl $steps fused > $OUT/fp64_${wl}.json 2> $OUT/fp64_${wl}.err
@@ -25,7 +25,7 @@ for wl in cfg2 cfg3 cfg4 cfg5; do
   echo "$wl counters done"
 done
 cp profiles/r03_pmc_traffic.json profiles/r03_fp64_flops.json $OUT/
-bash profiles/collect_sq.sh cfg2 20 draw > $OUT/${TAG}_sq_cfg2.json 2> $OUT/sq_cfg2.err
+bash profiles/collect_sq.sh cfg3 20 draw > $OUT/${TAG}_sq_cfg3.json 2> $OUT/sq_cfg3.err
 bash profiles/collect_sq.sh cfg5 6 fused > $OUT/${TAG}_sq_cfg5_fused.json 2> $OUT/sq_cfg5.err
-rm -rf $ROOT/gpurun_out/sq_cfg2_draw $ROOT/gpurun_out/sq_cfg5_fused
+rm -rf $ROOT/gpurun_out/sq_cfg3_draw $ROOT/gpurun_out/sq_cfg5_fused
 echo done; ls $OUT
