@@ -99,6 +99,8 @@ struct rp_ctx {
     size_t cap_lazy_states = 0;
     int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
     int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
+    bool epilogue_dirty = false;           // a plan's chain was cut short (an error between its launches and its result): the scratch words
+                                           // its epilogues keep at zero between launches (arrival tickets, totals, histogram) are cleared first
     // a plan whose kernels are on the stream and whose result has not been collected (rp_plan_begin .. rp_plan_wait)
     struct Pending {
         bool active = false, cin = false, skip_eval = false, ticket = false, done = false, time_valid = false, mat = false, coeffs = false;
@@ -704,6 +706,12 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     bool time_valid = false;
     const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     bool lazy_done = false;   // the cost-ordered collision stage delivered the result (its last round handed the ticket over)
+    if (c->epilogue_dirty) {   // (the last chain on this context did not reach its result: see rp_ctx::epilogue_dirty)
+        HIP_TRY(c, hipMemsetAsync(c->d_sel_scratch, 0, RP_SEL_SCRATCH * sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_lazy_ctl, 0, sizeof(LazyCtl), c->stream));
+    }
+    c->epilogue_dirty = true;
     if (!skip_eval) {
         // grids that did not fit the evaluation kernel's launch block: in rp_lon_kernel's (two-kernel path: its workgroup 0 publishes
         // them to d_stage for the kernels behind it) or by a host-to-device copy (a 5-us blit kernel on the stream)
@@ -869,6 +877,7 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
     const auto tp2 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 
+    c->epilogue_dirty = false;   // the chain ran through: its epilogues have left their scratch words at zero
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
     *result = hrb->r;
     result->n_collision_before_best = (int64_t)hrb->n_before;
@@ -1031,6 +1040,7 @@ int rp_set_profiling(rp_ctx *c, int enable) {
 int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *ref_theta, const double *ref_curv,
                      const double *ref_curv_d, const double *ref_x, const double *ref_y, double proj_domain_d_limit) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_set_reference: a plan is in flight on this context (rp_plan_wait first)");
     if (n < 2 || !ref_pos || !ref_theta || !ref_curv || !ref_curv_d || !ref_x || !ref_y)
         return fail(c, RP_EINVAL, "rp_set_reference: need n >= 2 and six non-null tables");
     for (int i = 0; i + 1 < n; ++i)
@@ -1182,6 +1192,7 @@ int ensure_static_grid(rp_ctx *c, double ego_r) {
 int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tri, const double *tri, int32_t n_circ,
                      const double *circ, int32_t n_dyn, int32_t n_steps, int32_t dyn_t0, const double *dyn) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_set_obstacles: a plan is in flight on this context (rp_plan_wait first)");
     if (n_sobb < 0 || n_tri < 0 || n_circ < 0 || n_dyn < 0 || n_steps < 0 || (n_sobb && !sobb) || (n_tri && !tri) ||
         (n_circ && !circ) || (n_dyn && n_steps && !dyn))
         return fail(c, RP_EINVAL, "rp_set_obstacles: negative count or null table");
@@ -1400,6 +1411,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
                    double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_coeffs: a plan is in flight on this context (rp_plan_wait first)");
     c->have_last = false;
     (void)lon_T;
     if (C < 0 || (C > 0 && (!lon_coeffs || !lat_coeffs || !traj_len))) return fail(c, RP_EINVAL, "rp_plan_coeffs: bad arrays");
@@ -1441,6 +1453,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
 
 int rp_fetch_status(rp_ctx *c, int64_t first, int64_t count, uint32_t *status, double *cost) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_fetch_status: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last) return fail(c, RP_ESTATE, "rp_fetch_status: no plan on this context");
     if (first < 0 || count < 0 || first + count > c->last.count) return fail(c, RP_EINVAL, "rp_fetch_status: range");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1452,6 +1465,7 @@ int rp_fetch_status(rp_ctx *c, int64_t first, int64_t count, uint32_t *status, d
 
 int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_fetch_states: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last || !c->last_mat) return fail(c, RP_ESTATE, "rp_fetch_states: last plan did not materialise states");
     if (first < 0 || count < 0 || first + count > c->last.count || (count && !states))
         return fail(c, RP_EINVAL, "rp_fetch_states: range");
@@ -1485,6 +1499,7 @@ int rp_fetch_states(rp_ctx *c, int64_t first, int64_t count, double *states) {
 
 int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, double *cost) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_eval_one: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last) return fail(c, RP_ESTATE, "rp_eval_one: no plan on this context");
     const KArgs &l = c->last;
     const int64_t total = c->last_coeffs ? l.count : (int64_t)l.nT * l.nL * l.nD;
@@ -1532,6 +1547,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
 
 int rp_count_collisions_before(rp_ctx *c, double cost, int64_t index, int64_t *count) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_count_collisions_before: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last || !count) return fail(c, RP_ESTATE, "rp_count_collisions_before: no plan / null output");
     HIP_TRY(c, hipSetDevice(c->device));
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
@@ -1552,6 +1568,7 @@ int rp_count_collisions_before(rp_ctx *c, double cost, int64_t index, int64_t *c
 
 int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, double *best_states) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_select: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last) return fail(c, RP_ESTATE, "rp_select: no plan on this context");
     if (!result || count != c->last.count || (count && !costs)) return fail(c, RP_EINVAL, "rp_select: count mismatch");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1568,6 +1585,7 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
 
 int rp_result_device(rp_ctx *c, const void **ptr, size_t *bytes, int32_t *rows_valid) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_result_device: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last || !ptr || !bytes) return fail(c, RP_ESTATE, "rp_result_device: no plan / null output");
     // The caller reads the block on ANOTHER stream (the collective's).  rp_plan returns on the host ticket, which says nothing
     // about the device copy as seen from other streams: wait for the context's stream here (its kernels have delivered their
@@ -1626,6 +1644,7 @@ int rp_combine_results(rp_ctx *c, const void *d_msgs, int32_t world, void *strea
 
 int rp_cost_range(rp_ctx *c, double *min_cost, double *max_cost, int64_t *n_out) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_cost_range: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last || !min_cost || !max_cost || !n_out) return fail(c, RP_ESTATE, "rp_cost_range: no plan / null output");
     *min_cost = *max_cost = std::nan("");
     *n_out = 0;
@@ -1660,6 +1679,7 @@ int rp_cost_range(rp_ctx *c, double *min_cost, double *max_cost, int64_t *n_out)
 int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double *x, const double *y, const double *theta,
                    int32_t *first_hit, double *boxes) {
     if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_check_swept: a plan is in flight on this context (rp_plan_wait first)");
     if (!p || !first_hit || n_poses < 0 || (n_poses > 0 && (!x || !y || !theta))) return fail(c, RP_EINVAL, "rp_check_swept: arguments");
     *first_hit = -1;
     if (n_poses < 2) return RP_OK;   // no segment

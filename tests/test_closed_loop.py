@@ -108,6 +108,8 @@ def test_plan_begin_wait_gpu():
         c2.plan_begin(g2.inputs)          # both on the device before either is collected
         with pytest.raises(RpError):
             c1.plan_begin(g1.inputs)      # one plan in flight per context
+        with pytest.raises(RpError):
+            c1.fetch_status()             # "the last plan" is the last COLLECTED one: nothing may read past a plan in flight
         o2, o1 = c2.plan_wait(), c1.plan_wait()
         for o, w in ((o1, want1), (o2, want2)):
             assert (o.best_index, o.best_cost, o.n_feasible, o.n_collision_before_best) == (w.best_index, w.best_cost, w.n_feasible, w.n_collision_before_best)
