@@ -302,7 +302,7 @@ struct ObsTables {
     const double *sobb;     // [n_sobb][8]  cx, cy, ux, uy, hl, hw, r_bound, -
     const double *tri;      // [n_tri][10]  x1,y1,x2,y2,x3,y3, bx, by, r_bound, -
     const double *circ;     // [n_circ][4]  cx, cy, r, -
-    const double *dyn;      // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent)
+    const double *dyn;      // [7][n_dyn][n_steps]  cx, cy, ux, uy, hl, hw, r_bound (cx = NaN: absent); + dyn_xy_offset, dyn_rmax_offset
     // static shapes in table order, grouped into at most 63 clusters of consecutive shapes of one kind (boundary
     // rectangles come as polylines, so consecutive shapes are neighbours): bounding circle + member range
     const double *clus;        // [n_clus][4]  cx, cy, r, -
@@ -320,6 +320,11 @@ struct ObsTables {
     int32_t gnx, gny;
     int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0, n_clus, clus_per;   // clus_per: members per cluster (upper bound)
 };
+// behind the seven planes of `dyn`: [n_dyn][n_steps][2] cx, cy interleaved (16-byte aligned), then [n_dyn] the largest r_bound of
+// each obstacle over the steps where it exists
+__host__ __device__ inline size_t dyn_xy_offset(int n_dyn, int n_steps) { return ((size_t)7 * (size_t)n_dyn * (size_t)n_steps + 1) & ~(size_t)1; }
+__host__ __device__ inline size_t dyn_rmax_offset(int n_dyn, int n_steps) { return dyn_xy_offset(n_dyn, n_steps) + (size_t)2 * (size_t)n_dyn * (size_t)n_steps; }
+__host__ __device__ inline size_t dyn_table_doubles(int n_dyn, int n_steps) { return dyn_rmax_offset(n_dyn, n_steps) + (size_t)n_dyn; }
 typedef const int32_t __attribute__((address_space(4))) *gcint;
 
 typedef const double __attribute__((address_space(4))) *gcdouble;   // the tables are read-only for the kernels: constant address

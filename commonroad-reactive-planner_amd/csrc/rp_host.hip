@@ -904,6 +904,14 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
             std::fprintf(stderr, "\nstatic walk of that wavefront (accumulated over the launches so far): clusters %llu, queries %llu, exact member tests %llu", wc[0], wc[1], wc[2]);
         }
 #endif
+#ifndef RP_TIMELINE
+        {   // rp_lon_kernel, one wavefront: kernarg lines | table copy issued | tables arrived | pair inputs | lon_step | masks | rows stored | header
+            unsigned long long ls[9];
+            HIP_TRY(c, hipMemcpy(ls, c->d_debug + 32, sizeof(ls), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "\nprofile kernel (rp_lon_kernel) stamps, cycles since its start:");
+            for (int k = 1; k < 9; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(ls[k] - ls[0]));
+        }
+#endif
         std::fprintf(stderr, "\nfinalize stamps (cycles since its start):");
         for (int k = 25; k < 31; ++k) std::fprintf(stderr, " [%d]%lld", k, (long long)(st[k] - st[24]));
         std::fprintf(stderr, "\n");
@@ -1199,7 +1207,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<double> a((size_t)n_sobb * OB_ROW), b((size_t)n_tri * 10), d((size_t)n_circ * 4),
-        e((size_t)7 * (size_t)n_dyn * (size_t)n_steps);
+        e(dyn_table_doubles(n_dyn, n_steps));
     for (int j = 0; j < n_sobb; ++j) {
         const double *o = sobb + 5 * j;
         double *r = &a[(size_t)j * OB_ROW];
@@ -1229,6 +1237,20 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
             e[4 * plane + at] = o[3]; e[5 * plane + at] = o[4];
             e[6 * plane + at] = std::sqrt(o[3] * o[3] + o[4] * o[4]);
         }
+    // the broad phase of rp_lon_kernel reads a circle per (obstacle, step): centre as one 16-byte pair, radius as the obstacle's
+    // largest over its steps, a scalar -- one vector load per test instead of three (rp_kernels.h: near_mask_step)
+    {
+        double *xy = &e[dyn_xy_offset(n_dyn, n_steps)], *rmax = &e[dyn_rmax_offset(n_dyn, n_steps)];
+        for (int j = 0; j < n_dyn; ++j) {
+            double r = 0.0;
+            for (int k = 0; k < n_steps; ++k) {
+                const size_t at = (size_t)j * n_steps + k;
+                xy[2 * at] = e[at]; xy[2 * at + 1] = e[plane + at];
+                if (e[at] == e[at] && e[6 * plane + at] > r) r = e[6 * plane + at];   // (steps where the obstacle is absent do not count)
+            }
+            rmax[j] = r;
+        }
+    }
     // clusters of consecutive static shapes of one kind (at most 63: one bit each in the (pair, step) masks)
     std::vector<double> cl;
     std::vector<int32_t> ci;

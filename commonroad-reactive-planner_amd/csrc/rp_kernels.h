@@ -272,6 +272,20 @@ struct DevResult {
 #define RP_TL(slot) do { } while (0)
 #endif
 
+// stamps of rp_lon_kernel (diagnostic build -DRP_STAMPS without -DRP_TIMELINE: slots 32 .. of the debug buffer; one wavefront)
+#if defined(RP_STAMPS) && !defined(RP_TIMELINE)
+#define RP_LSTAMP(k)                                                                             \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        unsigned long long t_;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (a.debug && !a.single_index && blockIdx.x == RP_STAMP_BLOCK && threadIdx.x == RP_STAMP_THREAD) a.debug[32 + (k)] = t_;  \
+    } while (0)
+#else
+#define RP_LSTAMP(k) do { } while (0)
+#endif
+
 // The kernarg segment (528 bytes of KArgs + the hidden launch arguments) is written by the host right before
 // the launch and is cold in every cache.  The compiler fetches its fields in many small scalar loads spread
 // over the prologue, each first touch of a 64-byte line a full memory round trip in series with the others.
@@ -1311,15 +1325,31 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
         uint64_t m = ~0ull;
         if (bounded) {
             const gcdouble dyn = (gcdouble)ob.dyn;
-            const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
             m = 0;
-            // (eight obstacles' circles requested before the first is tested: the loop is a chain of memory round trips otherwise --
-            //  51 obstacles of cfg3: 28 us for a kernel that has 2 us of arithmetic)
-#pragma unroll 8
-            for (int j = 0; j < ob.n_dyn; ++j) {
-                const gcdouble o = dyn + (size_t)j * ob.n_steps + k;
-                const double dx = o[0] - cx, dy = o[plane] - cy, rr = R + o[6 * plane];   // NaN centre: absent, no bit
-                if (dx * dx + dy * dy <= rr * rr * 1.000001) m |= 1ull << (j < 63 ? j : 63);
+            // One 16-byte load per obstacle (its centre at this step; dyn_xy_offset) and its radius as a scalar (the obstacle's largest
+            // over the steps, dyn_rmax_offset: a superset of the per-step test), eight obstacles requested before the first is tested.
+            // Round 2 read cx, cy and r_bound from three planes under a `#pragma unroll 8`, for which the compiler emitted load,
+            // load, load, wait per obstacle; with the loads batched the phase stayed at ~150 cycles per load instruction -- the
+            // 153 vector loads per wavefront (8 wavefronts per CU) are what it costs, not their latency (in-kernel stamps on cfg3:
+            // 37 k cycles of the kernel's 48 k, then 22 k batched)
+            typedef double dbl2 __attribute__((ext_vector_type(2)));
+            typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
+            const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
+            const gcdouble rmax = dyn + dyn_rmax_offset(ob.n_dyn, ob.n_steps);
+            constexpr int kB = 8;
+            for (int j0 = 0; j0 < ob.n_dyn; j0 += kB) {
+                dbl2 oc[kB];
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {   // (a batch's tail repeats the last obstacle: same circle, same bit)
+                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
+                    oc[u] = xy[(size_t)j * ob.n_steps + k];
+                }
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
+                    const double dx = oc[u].x - cx, dy = oc[u].y - cy, rr = R + rmax[j];   // NaN centre: absent, no bit
+                    m |= (uint64_t)(dx * dx + dy * dy <= rr * rr * 1.000001) << (j < 63 ? j : 63);
+                }
             }
         }
         f[PF_NEAR] = mask_as_double(m);
@@ -1333,7 +1363,9 @@ template <int G, bool COEFFS_IN, bool LDS_TABLES>
 __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
     const KArgs &a = ag.k;
     extern __shared__ double lds[];
+    RP_LSTAMP(0);
     touch_kernargs<10>();
+    RP_LSTAMP(1);
     const int tid = threadIdx.x;
     const int n_ref = a.n_ref;
     if (a.publish_grids && blockIdx.x == 0) {   // the grids of this launch's kernarg segment -> device memory, for the kernels behind
@@ -1350,7 +1382,9 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
 #pragma unroll 4
         for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
         tab = lds;
+        RP_LSTAMP(2);
         __syncthreads();
+        RP_LSTAMP(3);
     } else {
         tab = a.tables;
     }
@@ -1369,6 +1403,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
         // which is fine here: the body uses only group-level ballots on lanes that are all still active.
         const LonPair lp = lon_pair<COEFFS_IN>(a, a.pair_begin + slot, n);
         const int L = lp.L;
+        RP_LSTAMP(4);
         double *const prow = a.profile + ((size_t)slot * PF_FIELDS) * (size_t)n;
         bool bad_a = false, bad_v = false;
         // fields of the last valid step L - 1 that the bound of the EXTENDED steps needs (pair_step_bound): handed on by the lane
@@ -1382,6 +1417,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
             const int i = c * G + gl;
             double f[PF_FIELDS];
             lon_step(a, rt, lp.lon, i, f);
+            RP_LSTAMP(5);
             if (masks && L - 1 >= c * G && L - 1 < c * G + G) {   // (group-uniform: all lanes of a group share the pair)
                 const int src = L - 1 - c * G;
                 last[PF_SD] = group_bcast<G>(f[PF_SD], src); last[PF_SDD] = group_bcast<G>(f[PF_SDD], src);
@@ -1392,6 +1428,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
             }
             if (i <= N) near_mask_step<COEFFS_IN>(a, rt, lp, i, f, (masks && L >= 1) ? last : nullptr);
             else f[PF_NEAR] = f[PF_NEAR_S] = 0.0;
+            RP_LSTAMP(6);
             bad_a |= (i < L) && (fabs(f[PF_SDD]) > a.a_max);   // pre-filter, :798
             bad_v |= (i < L) && (f[PF_SD] < -RP_EPS);          // pre-filter, :802
             if (i <= N) {
@@ -1399,6 +1436,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
 #pragma unroll
                 for (int k = 0; k < PF_FIELDS; ++k) o[(size_t)k * n] = f[k];
             }
+            RP_LSTAMP(7);
         }
         const bool any_a = group_ballot<G>(bad_a, gbase) != 0, any_v = group_ballot<G>(bad_v, gbase) != 0;
         if (gl == 0) {
@@ -1409,6 +1447,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
             h.L = L;
             a.pair_hdr[slot] = h;
         }
+        RP_LSTAMP(8);
     }
 }
 
