@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="default: cfg3 at N = 1 (the largest configuration BASELINE.json tags 1 x MI355X), cfg4 (strong scaling) at N > 1")
     ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
+    ap.add_argument("--caller", default="c", choices=["c", "python"],
+                    help="who calls rp_plan inside the timed regions: a compiled host loop over the C ABI, or the ctypes binding")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: which record is the headline")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measured record (regions of K steps are repeated)")
     ap.add_argument("--sequence", type=int, default=32, help="replanning cycles in the input sequence")
@@ -130,22 +132,31 @@ def with_mode(seq, mode):
     return out
 
 
-def measure(step, n_inputs, steps, warmup, min_seconds, sync, barrier=None, max_regions=4000):
+def measure(step, n_inputs, steps, warmup, min_seconds, sync, barrier=None, max_regions=4000, region=None):
     """Timed regions of exactly ``steps`` steps (barrier + device sync on both sides), repeated until ``min_seconds`` of
-    timed work; step(k) runs cycle k of the input sequence.  Returns the per-region step times (ms)."""
+    timed work; step(k) runs cycle k of the input sequence -- or region(k0, steps) runs ``steps`` of them in one call (the
+    compiled host loop, _capi.HostLoop).  Returns the per-region step times (ms)."""
     k = 0
-    for _ in range(warmup):
-        step(k % n_inputs)
-        k += 1
+    if region is not None and warmup > 0:
+        region(0, warmup)
+        k = warmup
+    else:
+        for _ in range(warmup):
+            step(k % n_inputs)
+            k += 1
     regions, total = [], 0.0
     while (total < min_seconds and len(regions) < max_regions) or not regions:
         if barrier:
             barrier()
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step(k % n_inputs)
-            k += 1
+        if region is not None:
+            region(k, steps)
+            k += steps
+        else:
+            for _ in range(steps):
+                step(k % n_inputs)
+                k += 1
         sync()
         if barrier:
             barrier()
@@ -213,8 +224,10 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
             "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, **extra}
 
 
-def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=8):
-    """One measured record on one GPU: the sequence in one mode."""
+def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=8, caller="c"):
+    """One measured record on one GPU: the sequence in one mode.  ``caller``: who calls rp_plan inside the timed regions --
+    "c": a compiled host loop over the C ABI (csrc/rp_hostloop.c), "python": the ctypes binding, one ``ctx.plan`` per step."""
+    from commonroad_rp_amd._capi import HostLoop
     inputs = with_mode(seq, mode)
     kms, feas, paths = [], [], [0, 0, 0]
     ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 8th step (a bracket costs ~8 us of stream time)
@@ -225,14 +238,28 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
             kms.append(out.kernel_ms)
         feas.append(out.n_feasible)
         paths[ctx.last_path()] += 1
-    regions = measure(step, len(inputs), steps, warmup, min_seconds, sync)
+    region = None
+    if caller == "c":
+        loop = HostLoop(ctx, inputs)
+        tot = {"kms": 0.0, "kn": 0, "feas": 0, "n": 0}
+
+        def region(k0, n):
+            st = loop.run(k0, n)
+            tot["kms"] += st.kernel_ms_sum; tot["kn"] += st.kernel_ms_n; tot["feas"] += st.feasible_sum; tot["n"] += n
+            for i in range(3):
+                paths[i] += st.paths[i]
+    regions = measure(step, len(inputs), steps, warmup, min_seconds, sync, region=region)
     ctx.set_profiling(0)
     sp = spread(regions)
     cand = float(np.mean([q.n_candidates for q in inputs]))
+    if region is not None:
+        kms = [tot["kms"] / tot["kn"]] if tot["kn"] else []
+        feas = [tot["feas"] / max(tot["n"], 1)]
     kernel_ms = float(np.mean(kms)) if kms else float("nan")
     n1 = inputs[0].params.N + 1
     rec = {"mode": mode, "candidates_per_step": cand, "ms_per_step": sp["median"], "value": cand / (sp["median"] * 1e-3),
            "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms, "sequence": len(inputs),
+           "caller": "compiled host loop over the C ABI (rp_hostloop.c)" if region is not None else "Python binding (ctypes), one call per step",
            # how the steps answered the collision query: eager (every pose of every candidate), cost-ordered stage, stage + eager fallback
            "collision_path_steps": {"eager": paths[0], "cost_ordered": paths[1], "cost_ordered_then_eager": paths[2]},
            "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms)}
@@ -291,7 +318,7 @@ def run_single(args, torch, device):
     sync = torch.cuda.synchronize
     seq = W.replan_sequence(base, args.sequence, device=device)
     base.setup(ctx)
-    head = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, args.min_seconds, sync)
+    head = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, args.min_seconds, sync, caller=args.caller)
     N = base.inputs.params.N
     result = {
         "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
@@ -303,10 +330,14 @@ def run_single(args, torch, device):
                    "horizon_steps": N, "n_obstacles": int(base.obstacles.dyn_obb.shape[0] + len(base.obstacles.static_obb)),
                    "inputs": f"replanning sequence of {len(seq)} consecutive cycles (closed loop over the scenario; cfg5: seeded initial states)",
                    "parallelism": "one GPU", "exchange": "none"},
-        "timing": dict(head["spread_ms"], what="K-step regions bracketed by device syncs, repeated until min-seconds; ms_per_step = median region"),
+        "timing": dict(head["spread_ms"], what="K-step regions bracketed by device syncs, repeated until min-seconds; ms_per_step = median region",
+                       caller=head["caller"]),
         "roofline": head["roofline"],
     }
     if not args.main_only:
+        if args.caller == "c":   # the same regions with the Python binding making the calls (what round 1 and 2 reported)
+            py = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, min(args.min_seconds, 0.5), sync, caller="python")
+            result["python_binding"] = {k: py[k] for k in ("ms_per_step", "value", "unit", "caller", "kernel_ms")}
         if args.mode != "fused":
             result["fused_mode"] = run_record(ctx, base, seq, "fused", args.steps, args.warmup, args.min_seconds, sync)
         ctx.close()
@@ -526,7 +557,7 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     # rank 0 alone on the whole grid: the N = 1 point of the same workload, measured in the same run
     alone = None
     if rank == 0:
-        alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync)
+        alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync, caller="python")   # (same caller as the sharded steps)
     dist.barrier()
     # ---- weak scaling: cfg2-sized shard per rank (longitudinal grid densified N times)
     ww = W.cfg2()

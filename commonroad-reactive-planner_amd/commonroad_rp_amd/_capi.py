@@ -619,3 +619,58 @@ class RpContext:
         best = np.empty((N_ARRAYS, self._N + 1)) if want_best_states else None
         self._check(self._lib.rp_select(self._h, dptr(costs), len(costs), C.byref(res), dptr(best)), "rp_select")
         return self._output(res, best)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+HOSTLOOP_PATH = os.path.join(os.path.dirname(LIB_PATH), "librp_hostloop.so")
+
+
+class RpHostLoopStats(C.Structure):
+    _fields_ = [("feasible_sum", C.c_int64), ("winners", C.c_int64), ("paths", C.c_int64 * 4), ("kernel_ms_sum", C.c_double),
+                ("kernel_ms_n", C.c_int64)]
+
+
+class HostLoop:
+    """A compiled caller's plan loop (csrc/rp_hostloop.c): ``rp_plan`` on a cycle of prepared inputs, ``steps`` calls per
+    ``run`` with no Python between them.  Timing harnesses use it; the planner does not."""
+
+    def __init__(self, ctx: "RpContext", inputs, ranges=None):
+        if not os.path.exists(HOSTLOOP_PATH):
+            raise RpError(f"{HOSTLOOP_PATH} is missing: build it (python -c 'import __graft_entry__ as g; g.build()')")
+        self._loop = C.CDLL(HOSTLOOP_PATH)
+        self._loop.rp_hostloop_run.restype = C.c_int
+        self._ctx, self._inputs = ctx, list(inputs)     # (the inputs own the arrays the structs point into)
+        n = self.n = len(self._inputs)
+        self._grids = [q.grids() for q in self._inputs]
+        self._params = (C.c_void_p * n)(*[C.addressof(q.params) for q in self._inputs])
+        self._cost = (C.c_void_p * n)(*[C.addressof(q.cost) for q in self._inputs])
+        self._g = (C.c_void_p * n)(*[C.addressof(g) for g in self._grids])
+        self._lo = self._hi = None
+        if ranges is not None:
+            self._lo = (C.c_int64 * n)(*[int(r[0]) for r in ranges])
+            self._hi = (C.c_int64 * n)(*[int(r[1]) for r in ranges])
+        n_max = max(q.params.N for q in self._inputs) + 1
+        self._best = np.empty((N_ARRAYS, n_max))
+        self._plan = C.cast(ctx._lib.rp_plan, C.c_void_p)
+        lp = getattr(ctx._lib, "rp_last_path", None)
+        self._last_path = C.cast(lp, C.c_void_p) if lp is not None else None
+
+    def run(self, k0: int, steps: int) -> RpHostLoopStats:
+        st = RpHostLoopStats()
+        ctx = self._ctx
+        rc = self._loop.rp_hostloop_run(self._plan, self._last_path, ctx._h, C.c_int32(self.n), self._params, self._cost, self._g,
+                                        self._lo, self._hi, C.c_int64(k0), C.c_int64(steps), C.byref(ctx._res),
+                                        self._best.ctypes.data_as(_DP), C.byref(st))
+        if rc != 0:
+            ctx._check(rc, "rp_plan")
+        last = self._inputs[(k0 + steps - 1) % self.n]
+        self._last_n = last.params.N + 1
+        ctx._N = last.params.N
+        ctx._last_count = ctx._res.n_candidates
+        ctx._serial += 1
+        return st
+
+    def best_states(self) -> np.ndarray:
+        """state rows [14, N + 1] of the last step's winner (meaningful only if it had one)"""
+        n = self._last_n
+        return self._best.ravel()[:N_ARRAYS * n].reshape(N_ARRAYS, n)
