@@ -550,23 +550,37 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     const bool k_ok = want && k >= 0 && k < ob.n_steps;
     const int kc = k_ok ? k : 0;
     const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+    uint64_t m = k_ok ? near : 0;
     if (!MASKED) {
+        // no (pair, step) mask came with the pose (explicit-polynomial plans, the swept check): it is built here, from the table
+        // the profile kernel builds its masks from -- one 16-byte centre load per obstacle and a scalar radius (the obstacle's
+        // largest over its steps: a superset of the exact circle test below), eight obstacles requested before the first is
+        // tested -- and the walk below then visits the few obstacles that are near.  Round 2 walked every obstacle here with
+        // seven loads each, waited for one obstacle at a time (357 vector loads per wavefront and step block at 51 obstacles).
+        m = 0;
         if (__any(k_ok)) {
-#pragma unroll 4
-            for (int j = 0; j < ob.n_dyn; ++j) {
-                const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
-                const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane], hw = o[5 * plane],
-                             rr = ego_r + o[6 * plane];
-                const double dx = cx - ego.cx, dy = cy - ego.cy;
-                if (k_ok && dx * dx + dy * dy <= rr * rr * 1.000001) {   // false for NaN
-                    Obb b = {cx, cy, ux, uy, hl, hw};
-                    hit |= obb_obb(ego, b);
+            typedef double dbl2 __attribute__((ext_vector_type(2)));
+            typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
+            const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
+            const gcdouble rmax = dyn + dyn_rmax_offset(ob.n_dyn, ob.n_steps);
+            constexpr int kB = 8;
+            for (int j0 = 0; j0 < ob.n_dyn; j0 += kB) {
+                dbl2 oc[kB];
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {   // (a batch's tail repeats the last obstacle: same circle, same bit)
+                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
+                    oc[u] = xy[(size_t)j * ob.n_steps + kc];
+                }
+#pragma unroll
+                for (int u = 0; u < kB; ++u) {
+                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
+                    const double dx = oc[u].x - ego.cx, dy = oc[u].y - ego.cy, rr = ego_r + rmax[j];   // NaN centre: absent, no bit
+                    m |= (uint64_t)(dx * dx + dy * dy <= rr * rr * 1.000001) << (j < 63 ? j : 63);
                 }
             }
         }
-        return hit;
+        if (!k_ok) m = 0;
     }
-    uint64_t m = k_ok ? near : 0;
     RP_WSTAMP(10);
     const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
     m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
