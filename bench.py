@@ -444,6 +444,9 @@ def corridor_sampling_cost(base, device, reps=15):
     mode = rp.config.sampling.longitudinal_mode
     t_obj, t_batch, t_dev, t_level, C = [], [], [], [], 0
     ctx = rp._gpu_ctx()
+    # (as the planner sets it up in _create_trajectory_bundle: the batch view writes into the context's pinned arena, rp_coeffs_arena)
+    sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+    sp.__dict__["_arena_owner"] = rp
     for _ in range(reps):
         t0 = time.perf_counter()
         trajs = sp.generate_trajectories_at_level(1, x0_lon, x0_lat, mode, False)

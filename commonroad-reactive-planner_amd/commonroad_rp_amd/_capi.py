@@ -224,6 +224,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_plan_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.c_int32, C.c_int32, C.POINTER(RpResult), C.c_void_p]),
         "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
                                      C.POINTER(RpResult), dp]),
+        "rp_coeffs_arena": (C.c_int, [ctx, C.c_int64, C.POINTER(dp), C.POINTER(dp), C.POINTER(ip)]),
         "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
         "rp_fetch_states": (C.c_int, [ctx, C.c_int64, C.c_int64, dp]),
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
@@ -263,9 +264,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 _OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
-                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed")
+                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -303,7 +304,8 @@ def pyset_order(values, union_zero: bool = False) -> np.ndarray:
 def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0_lon, x0_lat, buffers: Optional[dict] = None):
     """``rp_corridor_coeffs``: (lon_coeffs [C, 6], lat_coeffs [C, 6], lon_T [C], traj_len [C], lon_end [C], lat_end [C]).
     ``buffers``: a dict that keeps the output arrays between calls (the result then consists of views into them, valid until the
-    next call with the same dict: tens of thousands of candidates are a few MB, whose page faults cost more than the call)."""
+    next call with the same dict: tens of thousands of candidates are a few MB, whose page faults cost more than the call);
+    ``buffers["alloc"]``, if set: cap -> (lon [cap, 6], lat [cap, 6], traj_len [cap]) to write into instead of fresh arrays."""
     lib = load_library()
     T, v_low, v_up, boxes = f64(T), f64(v_low), f64(v_up), f64(boxes)
     traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
@@ -315,7 +317,9 @@ def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0
     for _ in range(2):
         if keep.get("cap") != cap or "arrays" not in keep:
             keep["cap"] = cap
-            keep["arrays"] = (np.empty((cap, 6)), np.empty((cap, 6)), np.empty(cap), np.empty(cap, dtype=np.int32), np.empty(cap), np.empty(cap))
+            alloc = keep.get("alloc")     # (a planner lets the candidates be written into its context's pinned arena: RpContext.coeffs_arena)
+            lon_lat_tl = alloc(cap) if alloc is not None else (np.empty((cap, 6)), np.empty((cap, 6)), np.empty(cap, dtype=np.int32))
+            keep["arrays"] = (lon_lat_tl[0], lon_lat_tl[1], np.empty(cap), lon_lat_tl[2], np.empty(cap), np.empty(cap))
         lon, lat, lt, tl, le, de = keep["arrays"]
         cnt = C.c_int64(0)
         rc = lib.rp_corridor_coeffs(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
@@ -533,6 +537,23 @@ class RpContext:
         out = PlanOutput.from_c(res, best)
         out.serial = self._serial
         return out
+
+    def coeffs_arena(self, cap: int):
+        """``rp_coeffs_arena``: (lon_coeffs [cap, 6], lat_coeffs [cap, 6], traj_len [cap]) as NumPy views of pinned host memory the
+        context owns.  Candidates written into them (leading rows) and passed to ``plan_coeffs`` as they are go to the device
+        without the copy into the staging buffer.  Views handed out earlier die with a call that asks for more room."""
+        fn = getattr(self._lib, "rp_coeffs_arena", None)
+        if fn is None:
+            raise RpError("this library build has no rp_coeffs_arena")
+        have = getattr(self, "_arena", None)
+        if have is not None and have[0] >= cap:
+            return have[1]
+        lon, lat, tl = _DP(), _DP(), C.POINTER(C.c_int32)()
+        self._check(fn(self._h, int(cap), C.byref(lon), C.byref(lat), C.byref(tl)), "rp_coeffs_arena")
+        arrays = (np.ctypeslib.as_array(lon, shape=(cap, 6)), np.ctypeslib.as_array(lat, shape=(cap, 6)),
+                  np.ctypeslib.as_array(tl, shape=(cap,)))
+        self._arena = (int(cap), arrays)
+        return arrays
 
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,
                     want_best_states: bool = True) -> PlanOutput:

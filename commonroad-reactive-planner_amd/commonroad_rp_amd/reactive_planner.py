@@ -391,6 +391,13 @@ class GpuBackendMixin:
             grids = sp.grids_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, grids=grids)
         elif hasattr(sp, "coeffs_at_level"):   # data-dependent candidates (CorridorSampling), batch view: coefficient arrays
+            if sp.__dict__.get("_arena_owner") is not self:
+                # the library writes the candidates straight into pinned arrays of this planner's context (rp_coeffs_arena): rp_plan_coeffs
+                # then skips its copy into the staging buffer -- a quarter of a millisecond at 25 000 candidates
+                ctx = self._gpu_ctx()
+                if hasattr(ctx, "coeffs_arena"):
+                    sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+                sp.__dict__["_arena_owner"] = self
             coeffs = sp.coeffs_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode, self._low_vel_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, coeffs=coeffs)
         else:   # foreign sampling space: its own objects, polynomials handed to the device explicitly

@@ -99,6 +99,16 @@ struct rp_ctx {
     size_t cap_lazy_states = 0;
     int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
     int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
+    // Which of the two ways to answer the collision query is the faster one depends on the scene (how deep into the cost order
+    // the first free candidate lies) and on the batch (what a collision round costs against the eager kernel's extra work): the
+    // context times its own plans -- whole calls, rp_plan / rp_plan_packed / rp_plan_coeffs -- per path and uses the faster one,
+    // measuring the other again every 64th plan.  Results are the same either way (rp_amd.h: rp_last_path).
+    double path_us[2] = {0.0, 0.0};        // running mean of the call time, [0] eager [1] cost-ordered (where the stage found the winner)
+    int path_n[2] = {0, 0};
+    int path_since_probe = 0, path_regime = -1;   // regime: explicit polynomials or grids, log2 of the candidate count
+    bool path_adaptive = false;            // the plan in flight chose its path by this rule (not forced, not a small batch)
+    bool time_whole = false;               // the plan in flight is a whole call: its duration counts
+    std::chrono::steady_clock::time_point plan_t0;
     bool epilogue_dirty = false;           // a plan's chain was cut short (an error between its launches and its result): the scratch words
                                            // its epilogues keep at zero between launches (arrival tickets, totals, histogram) are cleared first
     // a plan whose kernels are on the stream and whose result has not been collected (rp_plan_begin .. rp_plan_wait)
@@ -134,7 +144,10 @@ struct rp_ctx {
     KArgsGL kargs_gl{};          // launch block of rp_lon_kernel: KArgs + room for larger grids (it publishes them to d_stage for the kernels behind it)
     bool grids_pending = false;  // the grids of the last rp_plan (c->staged, h_stage) are neither in kargs_g nor in d_stage yet: run_pipeline
                                  // hands them to rp_lon_kernel's kernarg segment (two-kernel path) or copies them
-    std::vector<double> last_lon, last_lat;   // host copy of explicit polynomials (rp_plan_coeffs)
+    char *h_arena = nullptr, *d_arena = nullptr;   // rp_coeffs_arena: pinned [lon 6 cap | lat 6 cap | traj_len cap] + its device mirror
+    int64_t arena_cap = 0;
+    const double *cin_lon = nullptr, *cin_lat = nullptr;   // host arrays the last rp_plan_coeffs read (pinned stage or arena)
+    int64_t cin_count = -1;   // rp_plan_coeffs: the explicit polynomials of the last such plan are the first 12 * cin_count doubles of h_stage (lon | lat)
 };
 
 namespace {
@@ -514,8 +527,10 @@ void host_winner_coeffs(const rp_ctx *c, const KArgs &ka, bool cin, rp_result *r
     const int64_t w = r->best_index;
     if (w < 0) return;
     if (cin) {
-        if ((size_t)(6 * w + 6) > c->last_lon.size()) return;
-        for (int k = 0; k < 6; ++k) { r->best_lon_coeffs[k] = c->last_lon[6 * w + k]; r->best_lat_coeffs[k] = c->last_lat[6 * w + k]; }
+        // (the pinned staging buffer still holds them: every plan rewrites it, and with it what this context calls its last plan)
+        if (w >= c->cin_count || !c->cin_lon) return;
+        const double *lon = c->cin_lon, *lat = c->cin_lat;
+        for (int k = 0; k < 6; ++k) { r->best_lon_coeffs[k] = lon[6 * w + k]; r->best_lat_coeffs[k] = lat[6 * w + k]; }
         return;
     }
     const size_t need = sizeof(double) * ((size_t)ka.nT + ka.nL + ka.nD);
@@ -653,6 +668,8 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_ro
 // The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
 int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states);
 int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, bool want_rows) {
+    if (c->time_whole) c->plan_t0 = std::chrono::steady_clock::now();
+    c->path_adaptive = false;
     double *const best_states = want_rows ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
     const int n = ka.N + 1;
     int rc;
@@ -770,6 +787,21 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         lazy_possible = lazy_possible && lazy_env != 0;
         bool lazy_try = lazy_possible && (lazy_env == 1 || (!small && c->lazy_skip == 0));
         if (lazy_possible && !lazy_try && lazy_env != 1 && !small && c->lazy_skip > 0) --c->lazy_skip;
+        c->path_adaptive = lazy_possible && lazy_env == -1 && !small;
+        if (c->path_adaptive) {
+            int lg = 0;
+            while ((count >> (lg + 1)) != 0) ++lg;
+            const int regime = 2 * lg + (cin ? 1 : 0);
+            if (regime != c->path_regime) { c->path_regime = regime; c->path_n[0] = c->path_n[1] = 0; c->path_since_probe = 0; }
+            if (lazy_try) {   // (not while the back-off after an exhausted stage holds the plans eager anyway)
+                if (c->path_n[1] == 0) lazy_try = true;                 // first plans of a regime: the cost-ordered stage
+                else if (c->path_n[0] == 0) lazy_try = c->path_n[1] < 4;   // then the eager kernel once
+                else {
+                    lazy_try = c->path_us[1] <= c->path_us[0];
+                    if (++c->path_since_probe >= 64) { lazy_try = !lazy_try; c->path_since_probe = 0; }
+                }
+            }
+        }
         c->last_lazy = 0;
         if (lazy_try) {
             if ((rc = run_lazy(c, ka, cin, G, grid, best_states != nullptr, launch_main_eval, &lazy_done)) != RP_OK) return rc;
@@ -961,9 +993,25 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     return RP_OK;
 }
 
+// a whole call's duration -> the running mean of the path it took (see rp_ctx::path_us)
+void note_path_time(rp_ctx *c) {
+    if (!c->time_whole) return;
+    c->time_whole = false;
+    if (!c->path_adaptive) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c->plan_t0).count();
+    if (c->last_lazy == 2) return;   // (an exhausted stage is the back-off's business -- lazy_skip --, not a sample of what the stage costs when it works)
+    const int k = c->last_lazy;
+    c->path_us[k] = c->path_n[k] == 0 ? us : c->path_us[k] + 0.25 * (us - c->path_us[k]);
+    if (c->path_n[k] < (1 << 30)) ++c->path_n[k];
+}
+
 int run_pipeline(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, rp_result *result, double *best_states) {
-    const int rc = pipeline_begin(c, ka, mat, cin, skip_eval, best_states != nullptr);
-    return rc != RP_OK ? rc : pipeline_wait(c, result, best_states);
+    c->time_whole = true;
+    int rc = pipeline_begin(c, ka, mat, cin, skip_eval, best_states != nullptr);
+    if (rc == RP_OK) rc = pipeline_wait(c, result, best_states);
+    if (rc == RP_OK) note_path_time(c);
+    c->time_whole = false;
+    return rc;
 }
 
 }  // namespace
@@ -1027,6 +1075,8 @@ void rp_destroy(rp_ctx *c) {
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_arena) (void)hipHostFree(c->h_arena);
+    if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1329,8 +1379,11 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
 int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
             rp_result *result, double *best_states) {
     if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
-    const int rc = rp_plan_begin(c, p, cost, g, cand_begin, cand_end, best_states != nullptr ? 1 : 0);
-    return rc != RP_OK ? rc : rp_plan_wait(c, result, best_states);
+    if (c) c->time_whole = true;
+    int rc = rp_plan_begin(c, p, cost, g, cand_begin, cand_end, best_states != nullptr ? 1 : 0);
+    if (rc == RP_OK) rc = rp_plan_wait(c, result, best_states);
+    if (c) { if (rc == RP_OK) note_path_time(c); c->time_whole = false; }
+    return rc;
 }
 
 int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
@@ -1376,6 +1429,7 @@ int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_g
     const size_t nd = (size_t)g->nT + g->nL + g->nD;
     const size_t sbytes = nd * sizeof(double) + (size_t)g->nT * sizeof(int32_t);
     if ((rc = ensure_stage(c, sbytes)) != RP_OK) return rc;
+    c->cin_count = -1;
     double *hs = reinterpret_cast<double *>(c->h_stage);
     std::memcpy(hs, g->T, sizeof(double) * g->nT);
     std::memcpy(hs + g->nT, g->L, sizeof(double) * g->nL);
@@ -1428,6 +1482,29 @@ int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_g
     return RP_OK;
 }
 
+int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len) {
+    if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_coeffs_arena: a plan is in flight on this context (rp_plan_wait first)");
+    if (cap <= 0 || !lon_coeffs || !lat_coeffs || !traj_len) return fail(c, RP_EINVAL, "rp_coeffs_arena: bad arguments");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (cap > c->arena_cap) {
+        if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_arena) HIP_TRY(c, hipHostFree(c->h_arena));
+        if (c->d_arena) HIP_TRY(c, hipFree(c->d_arena));
+        c->h_arena = c->d_arena = nullptr; c->arena_cap = 0;
+        c->have_last = false;   // (the last plan's polynomials may have lived in the old arena)
+        c->cin_lon = c->cin_lat = nullptr; c->cin_count = -1;
+        const size_t bytes = (size_t)cap * (12 * sizeof(double) + sizeof(int32_t));
+        if (hipHostMalloc((void **)&c->h_arena, bytes, hipHostMallocDefault) != hipSuccess) { c->h_arena = nullptr; return fail(c, RP_ENOMEM, "rp_coeffs_arena: pinned host memory"); }
+        if (hipMalloc((void **)&c->d_arena, bytes) != hipSuccess) { (void)hipHostFree(c->h_arena); c->h_arena = c->d_arena = nullptr; return fail(c, RP_ENOMEM, "rp_coeffs_arena: device memory"); }
+        c->arena_cap = cap;
+    }
+    double *base = reinterpret_cast<double *>(c->h_arena);
+    *lon_coeffs = base; *lat_coeffs = base + 6 * c->arena_cap;
+    *traj_len = reinterpret_cast<int32_t *>(base + 12 * c->arena_cap);
+    return RP_OK;
+}
+
 int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
                    const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, rp_result *result,
                    double *best_states) {
@@ -1440,17 +1517,39 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     const int n = p->N + 1;
     const bool mat = (p->flags & RP_FLAG_MATERIALIZE_ALL) != 0 || cost->kind == RP_COST_EXTERNAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t sbytes = (size_t)C * (12 * sizeof(double) + sizeof(int32_t));
-    if ((rc = ensure_stage(c, sbytes)) != RP_OK) return rc;
-    double *hs = reinterpret_cast<double *>(c->h_stage);
-    std::memcpy(hs, lon_coeffs, sizeof(double) * 6 * C);
-    std::memcpy(hs + 6 * C, lat_coeffs, sizeof(double) * 6 * C);
-    std::memcpy(hs + 12 * C, traj_len, sizeof(int32_t) * C);
-    if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+    // the candidates' arrays -> device.  Arrays handed out by rp_coeffs_arena are pinned already and go as they are; anything
+    // else is copied into the pinned staging buffer first (2.4 MB at 25 536 candidates: a quarter of a millisecond of memcpy)
+    const double *d_lon = nullptr, *d_lat = nullptr;
+    const int32_t *d_tl = nullptr;
+    const bool in_arena = c->h_arena && C <= c->arena_cap && lon_coeffs == reinterpret_cast<const double *>(c->h_arena) &&
+                          lat_coeffs == reinterpret_cast<const double *>(c->h_arena) + 6 * c->arena_cap &&
+                          traj_len == reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena) + 12 * c->arena_cap);
+    if (in_arena) {
+        const size_t o_lat = sizeof(double) * 6 * (size_t)c->arena_cap, o_tl = 2 * o_lat;
+        if (C) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_arena, c->h_arena, sizeof(double) * 6 * C, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_arena + o_lat, c->h_arena + o_lat, sizeof(double) * 6 * C, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_arena + o_tl, c->h_arena + o_tl, sizeof(int32_t) * C, hipMemcpyHostToDevice, c->stream));
+        }
+        d_lon = reinterpret_cast<const double *>(c->d_arena);
+        d_lat = reinterpret_cast<const double *>(c->d_arena + o_lat);
+        d_tl = reinterpret_cast<const int32_t *>(c->d_arena + o_tl);
+        c->cin_lon = lon_coeffs; c->cin_lat = lat_coeffs;
+    } else {
+        const size_t sbytes = (size_t)C * (12 * sizeof(double) + sizeof(int32_t));
+        if ((rc = ensure_stage(c, sbytes)) != RP_OK) return rc;
+        double *hs = reinterpret_cast<double *>(c->h_stage);
+        std::memcpy(hs, lon_coeffs, sizeof(double) * 6 * C);
+        std::memcpy(hs + 6 * C, lat_coeffs, sizeof(double) * 6 * C);
+        std::memcpy(hs + 12 * C, traj_len, sizeof(int32_t) * C);
+        if (sbytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, c->h_stage, sbytes, hipMemcpyHostToDevice, c->stream));
+        const double *ds = reinterpret_cast<const double *>(c->d_stage);
+        d_lon = ds; d_lat = ds + 6 * C; d_tl = reinterpret_cast<const int32_t *>(ds + 12 * C);
+        c->cin_lon = hs; c->cin_lat = hs + 6 * C;
+    }
     c->staged.clear();
     c->staged_on_device = false;
-    c->last_lon.assign(lon_coeffs, lon_coeffs + 6 * C);
-    c->last_lat.assign(lat_coeffs, lat_coeffs + 6 * C);
+    c->cin_count = C;
     if ((rc = grow(c, c->d_status, c->cap_status, (size_t)C)) != RP_OK) return rc;
     if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)C)) != RP_OK) return rc;
     if (mat && (rc = grow(c, c->d_states, c->cap_states, (size_t)C * RP_N_ARRAYS * (size_t)((n + 15) & ~15))) != RP_OK) return rc;
@@ -1460,9 +1559,8 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
         if (grc != RP_OK) return grc;
     }
     fill_common(c, p, cost, ka);
-    const double *ds = reinterpret_cast<const double *>(c->d_stage);
-    ka.lon_coeffs = ds; ka.lat_coeffs = ds + 6 * C;
-    ka.traj_len_c = reinterpret_cast<const int32_t *>(ds + 12 * C);
+    ka.lon_coeffs = d_lon; ka.lat_coeffs = d_lat;
+    ka.traj_len_c = d_tl;
     ka.cand_begin = 0; ka.count = C;
     ka.status = c->d_status; ka.cost = c->d_cost;
     ka.states = mat ? c->d_states : nullptr;

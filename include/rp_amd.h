@@ -204,6 +204,14 @@ int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *best_states);
 int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C,
                    const double *lon_coeffs, const double *lat_coeffs, const double *lon_T,
                    const int32_t *traj_len, rp_result *result, double *best_states);
+/* Pinned host arrays for the explicit polynomials of up to `cap` candidates, owned by the context: lon_coeffs [cap][6],
+ * lat_coeffs [cap][6], traj_len [cap].  A sampling space that writes its candidates straight into them (rp_corridor_coeffs
+ * with these as its outputs; CorridorSampling.generate_trajectories_at_level, sampling.py:340-397, builds one object per
+ * candidate instead) and hands the very same pointers to rp_plan_coeffs saves it the copy into its own staging buffer -- at
+ * 25 536 candidates 2.4 MB, a quarter of a millisecond, as much as the device needs for the whole plan.  The arrays stay
+ * valid until rp_coeffs_arena is called with a larger cap (which frees them and hands out new ones) or rp_destroy; a call with
+ * cap <= the current capacity returns the same arrays. */
+int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len);
 
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
 /* How the last plan answered the collision query (reactive_planner.py:1019-1063):

@@ -169,6 +169,50 @@ def test_corridor_candidates_on_every_launch_path(name):
             ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES[:2])
+def test_candidates_written_into_the_contexts_arena(name):
+    """rp_coeffs_arena: the library's batch view writes into pinned arrays of the context, rp_plan_coeffs takes them as they are --
+    same result as with ordinary arrays, also after the arena had to grow and on a second plan that reuses it"""
+    from commonroad_rp_amd._capi import RpContext
+    z = _load(name)
+    sp = _space(z)
+    level, args = int(z["level"]), (z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    lon, lat, T, tl, _, _ = (np.array(a) for a in sp.coeffs_at_level(level, *args))
+    tabs = _tables(z)
+    ctx = RpContext(0)
+    ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
+    ctx.set_obstacles(tabs)
+    p, cost = _params(z, FLAG_MATERIALIZE_ALL)
+    want = ctx.plan_coeffs(p, cost, lon, lat, T, tl)
+    want_status, want_cost = ctx.fetch_status()
+    sp2 = _space(z)
+    if not sp2._native_ok():
+        pytest.skip("this interpreter's set order is not the library's: no native batch view")
+    calls = []
+
+    def alloc(cap):
+        calls.append(cap)
+        return ctx.coeffs_arena(cap)
+    sp2.__dict__["_native_buffers"] = {"alloc": alloc, "cap": 64}    # (too small on purpose: the first call has to grow)
+    for rep in range(2):
+        alon, alat, aT, atl, _, _ = sp2.coeffs_at_level(level, *args)
+        base = ctx.coeffs_arena(calls[-1])
+        assert alon.ctypes.data == base[0].ctypes.data and alat.ctypes.data == base[1].ctypes.data and atl.ctypes.data == base[2].ctypes.data
+        np.testing.assert_array_equal(alon, lon)
+        out = ctx.plan_coeffs(p, cost, alon, alat, aT, atl)
+        status, c = ctx.fetch_status()
+        assert out.best_index == want.best_index and out.n_feasible == want.n_feasible
+        np.testing.assert_array_equal(status, want_status)
+        np.testing.assert_array_equal(c, want_cost)
+        if want.best_index >= 0:
+            np.testing.assert_array_equal(out.best_states, want.best_states)
+            np.testing.assert_array_equal(out.best_lon_coeffs, lon[want.best_index])
+            np.testing.assert_array_equal(out.best_lat_coeffs, lat[want.best_index])
+    assert len(calls) >= 2 and calls[-1] >= len(T)
+    ctx.close()
+
+
 def test_library_restates_the_interpreters_set_order():
     """The reference's candidate order is the iteration order of Python sets of floats (sampling.py:367,384-386); the library's
     batch view restates CPython's set (csrc/rp_corridor.h).  Against this interpreter's own sets: plain sets of np.linspace values
