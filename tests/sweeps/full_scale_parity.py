@@ -7,7 +7,7 @@ from commonroad_rp_amd import workloads as W
 from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL
 from oracle import oracle
 ctx = RpContext(0)
-cases = [("cfg2", {}), ("cfg2", {"road_boundary": True}), ("cfg3", {}), ("cfg3", {"road_boundary": True}), ("cfg4", {}),
+cases = [("cfg2", {}), ("cfg2", {"road_boundary": True}), ("cfg3", {}), ("cfg3", {"road_boundary": True}), ("cfg3f", {}), ("cfg4", {}),
          ("cfg4", {"road_boundary": True}), ("cfg5", {"obstacles": 50})]
 bad = 0
 for name, kw in cases:
@@ -20,16 +20,34 @@ for name, kw in cases:
         t0 = time.time()
         o = oracle.plan(inp, tb, want_states=False, nthreads=16)
         t1 = time.time()
-        out = ctx.plan(inp)
-        st, cost = ctx.fetch_status()
-        lab_ok = np.array_equal(st & 3, o.status & 3) and np.array_equal((st >> 4) & 7, (o.status >> 4) & 7)
-        has = ~np.isnan(o.cost)
-        cost_ok = np.all(np.isnan(cost[~has])) and np.allclose(cost[has], o.cost[has], rtol=1e-9, atol=0)
-        win_ok = out.best_index == o.out.best_index and out.n_collision == o.out.n_collision and \
-            out.n_collision_before_best == o.out.n_collision_before_best and out.n_feasible == o.out.n_feasible
-        ok = lab_ok and cost_ok and win_ok
-        bad += not ok
-        print(f"{name} {kw} draw={bool(extra)}: {inp.n_candidates} candidates, colliding {out.n_collision}, winner {out.best_index}: "
-              f"{'OK' if ok else 'MISMATCH'} (labels {lab_ok}, costs {cost_ok}, winner/counters {win_ok}; oracle {t1 - t0:.1f} s)", flush=True)
+        # both ways of answering the collision query (production-mode plans of large batches; rp_amd.h: rp_last_path): the eager
+        # kernel labels every colliding candidate; the cost-ordered stage only the ones it looked at -- the others keep FEASIBLE,
+        # n_collision counts the collisions found (>= the ones before the winner), everything else is the same
+        for lazy in ("0", "1"):
+            os.environ["RP_AMD_LAZY"] = lazy
+            out = ctx.plan(inp)
+            path = ctx.last_path()
+            st, cost = ctx.fetch_status()
+            lab, olab = st & 3, o.status & 3
+            if path == 1:
+                diff = lab != olab
+                lab_ok = bool(np.all((olab[diff] == 3) & (lab[diff] == 1)))
+                coll_ok = o.out.n_collision_before_best <= out.n_collision <= o.out.n_collision and out.n_collision == int(np.sum(lab == 3))
+            else:
+                lab_ok = np.array_equal(lab, olab)
+                coll_ok = out.n_collision == o.out.n_collision
+            lab_ok = lab_ok and np.array_equal((st >> 4) & 7, (o.status >> 4) & 7)
+            has = ~np.isnan(o.cost)
+            cost_ok = np.all(np.isnan(cost[~has])) and np.allclose(cost[has], o.cost[has], rtol=1e-9, atol=0)
+            win_ok = out.best_index == o.out.best_index and coll_ok and \
+                out.n_collision_before_best == o.out.n_collision_before_best and out.n_feasible == o.out.n_feasible
+            ok = lab_ok and cost_ok and win_ok
+            bad += not ok
+            print(f"{name} {kw} draw={bool(extra)} path={('eager', 'cost-ordered', 'cost-ordered, then eager')[path]}: {inp.n_candidates} candidates, "
+                  f"colliding {o.out.n_collision} (found {out.n_collision}), winner {out.best_index}: "
+                  f"{'OK' if ok else 'MISMATCH'} (labels {lab_ok}, costs {cost_ok}, winner/counters {win_ok}; oracle {t1 - t0:.1f} s)", flush=True)
+            if extra or path == 0 and lazy == "0" and inp.n_candidates <= 16384:
+                break   # (draw-mode plans and small batches have one path only)
+os.environ.pop("RP_AMD_LAZY", None)
 print("all full-scale checks passed" if not bad else f"{bad} MISMATCHES")
 sys.exit(1 if bad else 0)
