@@ -1357,6 +1357,27 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
     // (static shapes: no (pair, step) mask -- every pose looks its own cell of the grid over them up, rp_device.h: static_grid_mask)
 }
 
+// `n16` 16-byte pieces from global memory into the workgroup's LDS, four per thread requested before the first is stored, the
+// stores through an explicit LDS pointer.  Written as `dst[k] = src[k]` under `#pragma unroll 4` with dst a plain pointer, the
+// compiler emitted load, wait, flat_store per piece: a generic store may alias the next load, so the four round trips of a
+// thread came one after the other -- and flat stores count on the vector-memory counter besides.
+// (Measured on cfg2 / cfg2 + road boundary: no change of the kernel's duration -- the other wavefronts of the workgroup cover
+// these round trips; kept because it is what the source says it does.)
+template <int NTHREADS = RP_BLOCK, int BATCH = 4>
+__device__ __forceinline__ void copy16_to_lds(const double *src, double *dst_lds, int n16, int tid) {
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef dbl2 __attribute__((address_space(3))) *lds_dbl2;
+    const dbl2 *s = reinterpret_cast<const dbl2 *>(src);
+    const lds_dbl2 d = (lds_dbl2) reinterpret_cast<dbl2 *>(dst_lds);
+    for (int k0 = tid; k0 < n16; k0 += BATCH * NTHREADS) {
+        dbl2 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) { const int k = k0 + u * NTHREADS; v[u] = s[k < n16 ? k : n16 - 1]; }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) { const int k = k0 + u * NTHREADS; if (k < n16) d[k] = v[u]; }
+    }
+}
+
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
 // and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
@@ -1376,11 +1397,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
     }
     const double *tab;
     if (LDS_TABLES) {   // 16-byte loads, four in flight per lane
-        const double2 *src = reinterpret_cast<const double2 *>(a.tables);
-        double2 *dst = reinterpret_cast<double2 *>(lds);
-        const int nw2 = a.table_words >> 1;   // table_words is even
-#pragma unroll 4
-        for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+        copy16_to_lds(a.tables, lds, a.table_words >> 1, tid);   // table_words is even
         tab = lds;
         RP_LSTAMP(2);
         __syncthreads();
@@ -1671,19 +1688,26 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             // the vertices [win_k0, win_k0 + win_n) of every row and the bucket entries that point into them, at the places
             // they have in the whole block (8-byte pieces: rows start at multiples of n_ref doubles)
             const int wn = a.win_n, total = TB_ROWS * wn;
-            for (int idx = tid; idx < total; idx += RP_BLOCK) {
-                const int at = (idx >> a.win_shift) * a.n_ref + a.win_k0 + (idx & (wn - 1));
-                lds_tab[at] = a.tables[at];
+            typedef double __attribute__((address_space(3))) *lds_double;
+            const lds_double ltab = (lds_double)lds_tab;
+            for (int i0 = tid; i0 < total; i0 += 4 * RP_BLOCK) {   // (four pieces per thread requested before the first is stored: copy16_to_lds)
+                double v[4];
+                int at[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * RP_BLOCK < total ? i0 + u * RP_BLOCK : total - 1;
+                    at[u] = (idx >> a.win_shift) * a.n_ref + a.win_k0 + (idx & (wn - 1));
+                    v[u] = a.tables[at[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * RP_BLOCK < total) ltab[at[u]] = v[u];
             }
             const int *bsrc = reinterpret_cast<const int *>(a.tables + TB_ROWS * a.n_ref) + a.win_b0;
             int *bdst = reinterpret_cast<int *>(lds_tab + TB_ROWS * a.n_ref) + a.win_b0;
             for (int idx = tid; idx < a.win_nb; idx += RP_BLOCK) bdst[idx] = bsrc[idx];
         } else {
-            const double2 *src = reinterpret_cast<const double2 *>(a.tables);
-            double2 *dst = reinterpret_cast<double2 *>(lds_tab);
-            const int nw2 = a.table_words >> 1;
-#pragma unroll 4
-            for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+            copy16_to_lds(a.tables, lds_tab, a.table_words >> 1, tid);
         }
         if (!COEFFS_IN) {
             if (tid < P) { sh_gT[tid] = g_T; sh_gL[tid] = g_L; sh_gtl[tid] = g_tl; }
@@ -1718,10 +1742,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         for (int pass = 0; pass < 2; ++pass) {
             if (pass == 1) {   // (workgroup-uniform) some item left the window: the whole block, then everything again
                 if (!windowed || !sh_miss) break;
-                const double2 *src = reinterpret_cast<const double2 *>(a.tables);
-                double2 *dst = reinterpret_cast<double2 *>(lds_tab);
-                const int nw2 = a.table_words >> 1;
-                for (int k = tid; k < nw2; k += RP_BLOCK) dst[k] = src[k];
+                copy16_to_lds(a.tables, lds_tab, a.table_words >> 1, tid);
                 if (tid < P) lds_flags[tid] = 0;
                 __syncthreads();
                 j = lane;
@@ -1735,11 +1756,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
             if (COLL == 2 && pass == 0 && wave_in_block == RP_BLOCK / 64 - 1) {
                 // the wavefront that only clears mask words below brings the slot table of the static clusters into LDS
                 // while the others work out the profile rows (one round trip, requests back to back)
-                const double2 *src = reinterpret_cast<const double2 *>(a.obs.slot);
-                double2 *dst = reinterpret_cast<double2 *>(lds_slot);
-                const int n2 = n_slots * (RP_SLOT_ROW / 2);
-#pragma unroll 4
-                for (int k = lane; k < n2; k += 64) dst[k] = src[k];
+                copy16_to_lds<64, 8>(a.obs.slot, lds_slot, n_slots * (RP_SLOT_ROW / 2), lane);
             }
             while (j < items) {
                 const int p = (int)((uint32_t)j / (uint32_t)n0), i = j - p * n0;
