@@ -221,7 +221,10 @@ int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_
  *                          until the first free one -- production-mode plans of large batches with obstacles;
  *   RP_PATH_LAZY_FALLBACK  the cost-ordered stage ran out of candidates (a scene where nearly everything collides) and the
  *                          eager kernel decided; results as RP_PATH_EAGER.
- * Winner, cost, infeasible_count_collision and the kinematic counters are the same on every path. */
+ * Winner, cost, infeasible_count_collision and the kinematic counters are the same on every path.
+ * Where both apply, a context picks by its own clock: it times its whole-call plans (rp_plan, rp_plan_packed, rp_plan_coeffs)
+ * per path, takes the faster one and measures the other again every 64th plan; a stage that ran out of candidates keeps the
+ * next 1, 2, 4 .. 64 plans eager.  RP_AMD_LAZY=0 / 1 in the environment pins the choice (tests, measurements). */
 #define RP_PATH_EAGER 0
 #define RP_PATH_LAZY 1
 #define RP_PATH_LAZY_FALLBACK 2

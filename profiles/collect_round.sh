@@ -7,6 +7,18 @@ TAG=${1:-r02x}; QUICK=${2:-}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
+# counters first: the bench line below then carries `traffic` and the FP64 fraction of this very code (bench.py reports the
+# numbers of profiles/r03_*.json only when their source hash is the library's)
+if [ -z "$QUICK" ]; then
+for wl in cfg2 cfg3 cfg3f cfg4 cfg5; do
+  steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8
+  bash profiles/collect_pmc.sh $wl $steps draw > $OUT/pmc_${wl}_draw.json 2> $OUT/pmc_${wl}_draw.err
+  bash profiles/collect_fp64.sh $wl $steps fused > $OUT/fp64_${wl}.json 2> $OUT/fp64_${wl}.err
+  rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
+  echo "$wl counters done"
+done
+cp profiles/r03_pmc_traffic.json profiles/r03_fp64_flops.json $OUT/
+fi
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
@@ -17,14 +29,6 @@ rm -rf $OUT/prof
 echo "trace done"
 cd $ROOT
 [ -n "$QUICK" ] && exit 0
-for wl in cfg2 cfg3 cfg3f cfg4 cfg5; do
-  steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8
-  bash profiles/collect_pmc.sh $wl $steps draw > $OUT/pmc_${wl}_draw.json 2> $OUT/pmc_${wl}_draw.err
-  bash profiles/collect_fp64.sh $wl $steps fused > $OUT/fp64_${wl}.json 2> $OUT/fp64_${wl}.err
-  rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
-  echo "$wl counters done"
-done
-cp profiles/r03_pmc_traffic.json profiles/r03_fp64_flops.json $OUT/
 bash profiles/collect_sq.sh cfg3 20 draw > $OUT/${TAG}_sq_cfg3.json 2> $OUT/sq_cfg3.err
 bash profiles/collect_sq.sh cfg5 6 fused > $OUT/${TAG}_sq_cfg5_fused.json 2> $OUT/sq_cfg5.err
 rm -rf $ROOT/gpurun_out/sq_cfg3_draw $ROOT/gpurun_out/sq_cfg5_fused
