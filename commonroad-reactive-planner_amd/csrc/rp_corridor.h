@@ -151,7 +151,8 @@ struct Candidates {
     std::vector<int32_t> traj_len;
 };
 
-inline void corridor_candidates(int nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up,
+// candidates of the time samples [k_first, k_last), appended to `out` in the reference's order
+inline void corridor_candidates(int k_first, int k_last, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up,
                                 const int32_t *box_off, const Box *boxes, int n, const double *x0_lon, const double *x0_lat,
                                 Candidates &out) {
     std::vector<double> lin, vs, ds, lateral;
@@ -159,7 +160,7 @@ inline void corridor_candidates(int nT, const double *T, const int32_t *traj_len
     const double s0 = x0_lon[0], sv0 = x0_lon[1], sa0 = x0_lon[2];
     const double p0 = x0_lat[0], v0 = x0_lat[1], a0 = x0_lat[2];
     const double zero = 0.0;
-    for (int k = 0; k < nT; ++k) {
+    for (int k = k_first; k < k_last; ++k) {
         const double t = T[k];
         linspace(v_low[k], v_up[k], n, lin);
         vs.clear();
