@@ -20,10 +20,12 @@ in the same JSON line --
   ``cpu_baseline``     the C port of the reference algorithm (oracle/) on the host cores, bounded sample
 N > 1: one process per GPU (the driver's ``python -m torch.distributed.run ... bench.py --gpus N``; started without a
   launcher, this script starts the N ranks itself as child processes BEFORE anything touches the GPU and relays rank
-  0's line).  Headline = BASELINE.json configs[3], cfg4, STRONG scaling: every rank evaluates its contiguous range of
-  the same 512 064-candidate grid and the ranks exchange one {cost, index, counters, winner block} message per step
-  (commonroad_rp_amd/distributed.py).  Beside it: the same region with the other exchange transport, the exchange time
-  per step of both, rank 0 alone on the whole grid, and a weak-scaling record (cfg2-sized shard per rank).
+  0's line).  Headline = WEAK scaling of the N = 1 workload: the grid's longitudinal samples densified N times, every rank
+  evaluates its contiguous range of the candidate index -- a shard the size of the N = 1 grid, the same per-GPU work as
+  `--gpus 1` -- and the ranks exchange one {cost, index, counters, winner block} message per step
+  (commonroad_rp_amd/distributed.py; no data-path collective).  Beside it (`strong`): BASELINE.json configs[3], cfg4's
+  512 064-candidate grid cut into N ranges, the same regions with the other exchange transport, the exchange time per step
+  of both, rank 0 alone on the whole grid.  `--scaling strong` makes that record the headline.
 
 Prints ONE JSON line (rank 0).  Modes:
   draw        every candidate fully evaluated (no pre-filter / early exit, the reference's draw_traj_set semantics)
@@ -59,11 +61,13 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=None, help="default: cfg3 at N = 1 (the largest configuration BASELINE.json tags 1 x MI355X), cfg4 (strong scaling) at N > 1")
+    ap.add_argument("--workload", default=None, help="default: cfg3 (the largest configuration BASELINE.json tags 1 x MI355X); at N > 1 the shard every rank gets")
     ap.add_argument("--mode", default="draw", choices=["draw", "materialize", "fused"])
     ap.add_argument("--caller", default="c", choices=["c", "python"],
                     help="who calls rp_plan inside the timed regions: a compiled host loop over the C ABI, or the ctypes binding")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: which record is the headline")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N > 1: which record is the headline -- weak: every rank a shard the size of the N = 1 workload (its longitudinal "
+                         "grid densified N times), the same per-GPU work as `--gpus 1`; strong: cfg4's grid cut into N ranges")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed work per measured record (regions of K steps are repeated)")
     ap.add_argument("--sequence", type=int, default=32, help="replanning cycles in the input sequence")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
@@ -545,7 +549,7 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
         return [PlanInputs(RpParams.from_buffer_copy(a), RpCost.from_buffer_copy(b), T, tl, L, D) for a, b, T, tl, L, D in seq]
 
     # ---- strong scaling: BASELINE.json configs[3], the same grid whatever N
-    sname = args.workload or "cfg4"
+    sname = "cfg4"
     ws = W.WORKLOADS[sname]()
     seq_s = sequence(ws, min(args.sequence, 16))
     ws.setup(ctx)
@@ -562,9 +566,10 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     if rank == 0:
         alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync, caller="python")   # (same caller as the sharded steps)
     dist.barrier()
-    # ---- weak scaling: cfg2-sized shard per rank (longitudinal grid densified N times)
-    ww = W.cfg2()
-    seq_w = sequence(ww, args.sequence, nL=len(ww.inputs.L) * world)
+    # ---- weak scaling: every rank a shard the size of the N = 1 headline workload (its longitudinal grid densified N times):
+    #      per-GPU work as in `bench.py --gpus 1`, so that the per-N values of a scaling run refer to the same unit of work
+    ww = W.WORKLOADS[args.workload or "cfg3"]()
+    seq_w = sequence(ww, min(args.sequence, 16), nL=len(ww.inputs.L) * world)
     ww.setup(ctx)
     weak = sharded(ww, seq_w, args.mode, args.steps, default_transport)
     try:
