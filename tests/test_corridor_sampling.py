@@ -263,3 +263,33 @@ def test_library_batch_view_equals_the_numpy_one(name):
             np.testing.assert_array_equal(a[k], b[k])
         np.testing.assert_allclose(a[0], b[0], rtol=1e-12, atol=1e-12)
         np.testing.assert_allclose(a[1], b[1], rtol=1e-12, atol=1e-12)
+
+
+def test_library_batch_view_from_concurrent_callers():
+    """rp_corridor_coeffs runs its time samples on the library's pool of host threads (csrc/rp_pool.h), one job at a time: calls
+    from several Python threads at once (ctypes releases the GIL) must each get the complete list in the reference's order"""
+    import threading
+    z = _load(CASES[0])
+    sp0 = _space(z)
+    if not sp0._native_ok():
+        pytest.skip("this interpreter's set order is not the library's: no native batch view")
+    lvl = int(z["level"])
+    want = [np.array(a) for a in sp0._coeffs_at_level_py(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)]
+    errors = []
+
+    def caller():
+        try:
+            sp = _space(z)     # (its own output buffers)
+            for _ in range(40):
+                got = sp.coeffs_at_level(lvl, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+                for k in (2, 3, 4, 5):
+                    np.testing.assert_array_equal(got[k], want[k])
+                np.testing.assert_allclose(got[0], want[0], rtol=1e-12, atol=1e-12)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=caller) for _ in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]
