@@ -490,10 +490,19 @@ class RpContext:
         nd = nT + nL + nD
         if nd * 8 + nT * 4 > f64v.nbytes:
             raise RpError("plan_packed: grids larger than the context's buffer")
-        f64v[0:nT] = T
-        f64v[nT:nT + nL] = L
-        f64v[nT + nL:nd] = D
-        i32v[2 * nd:2 * nd + nT] = traj_len
+        # (the sampling space hands out the same array objects while its sets are unchanged: what the buffer already holds at the
+        #  same place is not written again -- in a replanning loop only the velocity samples change from cycle to cycle)
+        last = getattr(self, "_fast_last", None)
+        same = last is not None and last[0] == (nT, nL, nD)
+        #  (read-only arrays only: an array its owner may write into says nothing by being the same object)
+        if not (same and last[1] is T and last[4] is traj_len and not T.flags.writeable and not traj_len.flags.writeable):
+            f64v[0:nT] = T
+            i32v[2 * nd:2 * nd + nT] = traj_len
+        if not (same and last[2] is L and not L.flags.writeable):
+            f64v[nT:nT + nL] = L
+        if not (same and last[3] is D and not D.flags.writeable):
+            f64v[nT + nL:nd] = D
+        self._fast_last = ((nT, nL, nD), T, L, D, traj_len)
         n = params.N + 1
         out = np.empty((N_ARRAYS + 13) * n)
         res = self._res

@@ -923,8 +923,11 @@ class ReactivePlanner(GpuBackendMixin):
             sc.__dict__ = {"time_step": t0 + factor * i, "position": sd[i], "orientation": float(theta[i]), "velocity": float(v[i]),
                            "acceleration": float(acc[i]), "yaw_rate": float(kappa[i])}
             return sc
+        # (the lon / lat lists -- [s, s', s''] and [d, d', d''] per step, reactive_planner.py:552-553 -- are lists whose rows are built
+        #  on access as well: the loop reads one row of each per cycle, run_planner.py:84-85)
+        lon_rows, lat_rows = buf[:, 4:7], buf[:, 7:10]
         return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)),
-                buf[:, 4:7].tolist(), buf[:, 7:10].tolist())
+                LazyStateList(n, lambda i: lon_rows[i].tolist()), LazyStateList(n, lambda i: lat_rows[i].tolist()))
 
     def _compute_standstill_trajectory(self) -> TrajectorySample:
         """reactive_planner.py:667-713 (arrays of length N, not N + 1, as in the reference)."""

@@ -144,7 +144,9 @@ class FixedIntervalSampling(SamplingSpace):
         if hit is None or hit[0] is not sample_set or len(hit[1]) != len(sample_set):
             if len(cache) > 64:
                 cache.clear()
-            hit = cache[id(sample_set)] = (sample_set, np.fromiter(sample_set, dtype=np.float64, count=len(sample_set)))
+            arr = np.fromiter(sample_set, dtype=np.float64, count=len(sample_set))
+            arr.flags.writeable = False   # (handed out again and again: RpContext.plan_packed skips what its buffer already holds)
+            hit = cache[id(sample_set)] = (sample_set, arr)
         return hit[1]
 
     def _cached_T(self, t_set: set):
@@ -155,6 +157,7 @@ class FixedIntervalSampling(SamplingSpace):
                 cache.clear()
             T = np.array([float(t) for t in t_set], dtype=np.float64)
             traj_len = np.array([len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in T], dtype=np.int32)
+            T.flags.writeable = traj_len.flags.writeable = False
             hit = cache[id(t_set)] = (t_set, T, traj_len)
         return hit[1], hit[2]
 
