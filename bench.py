@@ -526,14 +526,30 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
             t0 = time.perf_counter()
             ex(ctx, out)
             t_ex.append(time.perf_counter() - t0)
-        regions = measure(step, len(inputs), steps, args.warmup, args.min_seconds, sync, bar)
+        # the mailbox transport through the compiled loop (rp_hostloop_run_sharded: rp_plan on the rank's range + both messages of
+        # the exchange, no Python between the steps -- as the N = 1 regions); the collectives need torch between the steps
+        region, caller = None, "Python binding (ctypes) + exchange object, per step"
+        if args.caller == "c" and type(ex).__name__ == "MailboxExchange":
+            from commonroad_rp_amd._capi import HostLoop
+            loop = HostLoop(ctx, inputs, ranges=[shard_range(q.n_candidates, rank, world) for q in inputs])
+            tot = {"kms": 0.0, "kn": 0, "tex": 0.0, "n": 0}
+            caller = "compiled host loop over the C ABI (rp_hostloop.c: rp_plan + rp_mailbox_exchange / rp_mailbox_sum)"
+
+            def region(k0, n):
+                st, tex = loop.run_sharded(ex, k0, n)
+                tot["kms"] += st.kernel_ms_sum; tot["kn"] += st.kernel_ms_n; tot["tex"] += tex; tot["n"] += n
+        regions = measure(step, len(inputs), steps, args.warmup, args.min_seconds, sync, bar, region=region)
         ctx.set_profiling(0)
         sp = spread(regions)
         cand = float(np.mean([q.n_candidates for q in inputs]))
         loc = cand / world
+        if region is not None:
+            kms = [tot["kms"] / tot["kn"]] if tot["kn"] else []
+            t_ex = [tot["tex"] / max(tot["n"], 1)]
         kernel_ms = float(np.mean(kms)) if kms else float("nan")
         return {"mode": mode, "candidates_per_step": cand, "candidates_per_gpu": loc, "ms_per_step": sp["median"],
                 "value": cand / (sp["median"] * 1e-3), "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms,
+                "caller": caller,
                 "exchange": type(ex).__name__, "exchange_ms_per_step": float(np.median(t_ex) * 1e3) if t_ex else None,
                 "roofline": roofline_record(w.name, mode, n1, loc, 0.0, kernel_ms, single_gpu=False)}
 
@@ -564,7 +580,7 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     # rank 0 alone on the whole grid: the N = 1 point of the same workload, measured in the same run
     alone = None
     if rank == 0:
-        alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync, caller="python")   # (same caller as the sharded steps)
+        alone = run_record(ctx, ws, seq_s, args.mode, steps_for(1.8, args.steps), 3, args.min_seconds, sync, caller=args.caller)   # (same caller as the sharded steps)
     dist.barrier()
     # ---- weak scaling: every rank a shard the size of the N = 1 headline workload (its longitudinal grid densified N times):
     #      per-GPU work as in `bench.py --gpus 1`, so that the per-N values of a scaling run refer to the same unit of work

@@ -700,6 +700,37 @@ class HostLoop:
         ctx._serial += 1
         return st
 
+    def run_sharded(self, mailbox, k0: int, steps: int):
+        """The same on a rank of a sharded group: every step ``rp_plan`` on this rank's ranges (``ranges`` of the constructor)
+        followed by the winner exchange through ``mailbox`` (a ``distributed.MailboxExchange``; both messages, the rules of
+        ``distributed.local_collisions_before``) -- (stats, seconds spent in the exchanges).  The global result of the last step
+        is left in ``mailbox._glob`` / ``mailbox._states``."""
+        if self._lo is None:
+            raise RpError("HostLoop.run_sharded: constructed without candidate ranges")
+        if mailbox._broken:
+            raise RuntimeError(f"MailboxExchange: unusable after a time-out ({mailbox._broken})")
+        st = RpHostLoopStats()
+        ctx, lib = self._ctx, self._ctx._lib
+        fn = self._loop.rp_hostloop_run_sharded
+        fn.restype = C.c_int
+        seq, t_ex = C.c_uint64(mailbox.seq), C.c_double(0.0)
+        cast = lambda f: C.cast(f, C.c_void_p)   # noqa: E731
+        rc = fn(self._plan, self._last_path, cast(lib.rp_mailbox_exchange), cast(lib.rp_mailbox_sum), cast(lib.rp_count_collisions_before),
+                ctx._h, mailbox._region, C.c_int32(mailbox.world), C.c_int32(mailbox.rank), C.byref(seq), C.c_int32(self.n),
+                self._params, self._cost, self._g, self._lo, self._hi, C.c_int64(k0), C.c_int64(steps), C.byref(ctx._res),
+                self._best.ctypes.data_as(_DP), C.byref(mailbox._glob), mailbox._states.ctypes.data_as(_DP), C.byref(st), C.byref(t_ex))
+        mailbox.seq = int(seq.value)
+        if rc <= -1000:
+            raise mailbox._timeout("rp_hostloop_run_sharded (mailbox)", rc + 1000, "its message")
+        if rc != 0:
+            ctx._check(rc, "rp_plan")
+        last = self._inputs[(k0 + steps - 1) % self.n]
+        self._last_n = last.params.N + 1
+        ctx._N = last.params.N
+        ctx._last_count = ctx._res.n_candidates
+        ctx._serial += 1
+        return st, float(t_ex.value)
+
     def best_states(self) -> np.ndarray:
         """state rows [14, N + 1] of the last step's winner (meaningful only if it had one)"""
         n = self._last_n
