@@ -210,7 +210,9 @@ int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
  * candidate instead) and hands the very same pointers to rp_plan_coeffs saves it the copy into its own staging buffer -- at
  * 25 536 candidates 2.4 MB, a quarter of a millisecond, as much as the device needs for the whole plan.  The arrays stay
  * valid until rp_coeffs_arena is called with a larger cap (which frees them and hands out new ones) or rp_destroy; a call with
- * cap <= the current capacity returns the same arrays. */
+ * cap <= the current capacity returns the same arrays.  A plan that took its candidates from the arena reads the winner's
+ * coefficients back from it (rp_result.best_*_coeffs, also in a later rp_select): leave the rows alone until the plan's results
+ * have been collected -- writing the next level's candidates is what ends a level anyway. */
 int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len);
 
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
@@ -288,7 +290,9 @@ int rp_plan_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
    set(np.linspace(lo, hi, n_samples)), with the reference path added where the interval straddles it (:382-386), per lateral sample
    a quintic to (d, 0, 0) over T (:390-392).  Order = the reference's: iteration order of CPython sets of floats (restated,
    csrc/rp_corridor.h; rp_pyset_order exposes it: the values of set(values), or of set(values).union({0}), in iteration order).
-   Output rows 0 .. *count - 1; with RP_ENOMEM *count is the room needed (cap too small). */
+   Output rows 0 .. *count - 1; with RP_ENOMEM *count is the room needed (cap too small).  The time samples are worked out on a
+   small pool of host threads of the library (csrc/rp_pool.h; RP_AMD_HOST_THREADS, default 8, 1 = the calling thread only) and
+   joined in the reference's order; concurrent callers take turns. */
 int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up, const int32_t *box_off,
                        const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat, int64_t cap, int64_t *count,
                        double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out, double *lon_end, double *lat_end);
