@@ -10,6 +10,7 @@
 // ever disagree (commonroad_rp_amd/sampling.py).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -157,6 +158,14 @@ inline void corridor_candidates(int k_first, int k_last, const double *T, const 
                                 Candidates &out) {
     std::vector<double> lin, vs, ds, lateral;
     std::vector<int> ids, comp;
+    {   // room for the usual case up front (n velocity samples x (n + 1) lateral samples per connected part): the parts of a level are
+        // worked out on several threads at once, and growing six vectors step by step is what they would contend for (the allocator)
+        size_t nodes_max = 0;
+        for (int k = k_first; k < k_last; ++k) nodes_max = std::max(nodes_max, (size_t)(box_off[k + 1] - box_off[k]));
+        const size_t guess = out.T.size() + (size_t)(k_last - k_first) * (size_t)n * (size_t)(n + 1) * std::max<size_t>(nodes_max, 1);
+        out.lon.reserve(6 * guess); out.lat.reserve(6 * guess);
+        out.T.reserve(guess); out.v_end.reserve(guess); out.d_end.reserve(guess); out.traj_len.reserve(guess);
+    }
     const double s0 = x0_lon[0], sv0 = x0_lon[1], sa0 = x0_lon[2];
     const double p0 = x0_lat[0], v0 = x0_lat[1], a0 = x0_lat[2];
     const double zero = 0.0;

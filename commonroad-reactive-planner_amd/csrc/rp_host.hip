@@ -11,11 +11,13 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -1914,27 +1916,39 @@ int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, con
     // one part per time sample, worked out on the library's host threads (rp_pool.h), put together in the reference's order: a level
     // of 25 536 candidates is ~1 ms of set emulation and coefficient solves on one core -- three times the device's share of the level
     const rpco::Box *bx = reinterpret_cast<const rpco::Box *>(boxes);
-    std::vector<rpco::Candidates> parts((size_t)nT);
+    // (the parts keep their room between calls -- a level is ~5 MB of vectors, and memory handed back to the system at the end of
+    //  every call comes back as page faults in the next: 2.0 -> 3.8 ms in the build container -- so concurrent callers take turns)
+    static std::mutex call_mutex;
+    static std::vector<rpco::Candidates> parts;
+    std::lock_guard<std::mutex> turn(call_mutex);
+    if (parts.size() < (size_t)nT) parts.resize((size_t)nT);
     rppool::Pool &pool = rppool::Pool::get();
+    // One pass: a part is worked out, waits for the end offset of the part before it (items are handed out in ascending order, so
+    // that part was started earlier), publishes its own and copies itself into the output -- no second wake-up of the pool for
+    // the copies.  Parts that would not fit are not copied; *count is the room needed.
+    static std::vector<std::atomic<int64_t>> ends;
+    if (ends.size() < (size_t)nT + 1) { std::vector<std::atomic<int64_t>> grown((size_t)nT + 1); ends.swap(grown); }
+    for (int k = 0; k <= nT; ++k) ends[(size_t)k].store(k == 0 ? 0 : -1, std::memory_order_relaxed);
+    const bool have_out = lon_coeffs && lat_coeffs && lon_T && traj_len_out && lon_end && lat_end;
     pool.parallel_for(nT, [&](int k) {
-        rpco::corridor_candidates(k, k + 1, T, traj_len, v_low, v_up, box_off, bx, n_samples, x0_lon, x0_lat, parts[(size_t)k]);
-    });
-    std::vector<int64_t> first((size_t)nT + 1, 0);
-    for (int k = 0; k < nT; ++k) first[(size_t)k + 1] = first[(size_t)k] + (int64_t)parts[(size_t)k].T.size();
-    const int64_t C = first[(size_t)nT];
-    *count = C;
-    if (C > cap || (C && (!lon_coeffs || !lat_coeffs || !lon_T || !traj_len_out || !lon_end || !lat_end))) return RP_ENOMEM;   // *count: room needed
-    pool.parallel_for(nT, [&](int k) {
-        const rpco::Candidates &c = parts[(size_t)k];
-        const size_t at = (size_t)first[(size_t)k], m = c.T.size();
-        if (!m) return;
-        std::memcpy(lon_coeffs + 6 * at, c.lon.data(), sizeof(double) * 6 * m);
-        std::memcpy(lat_coeffs + 6 * at, c.lat.data(), sizeof(double) * 6 * m);
+        rpco::Candidates &c = parts[(size_t)k];
+        c.lon.clear(); c.lat.clear(); c.T.clear(); c.v_end.clear(); c.d_end.clear(); c.traj_len.clear();
+        rpco::corridor_candidates(k, k + 1, T, traj_len, v_low, v_up, box_off, bx, n_samples, x0_lon, x0_lat, c);
+        const size_t m = c.T.size();
+        int64_t at;
+        while ((at = ends[(size_t)k].load(std::memory_order_acquire)) < 0) __builtin_ia32_pause();
+        ends[(size_t)k + 1].store(at + (int64_t)m, std::memory_order_release);
+        if (!m || !have_out || at + (int64_t)m > cap) return;
+        std::memcpy(lon_coeffs + 6 * (size_t)at, c.lon.data(), sizeof(double) * 6 * m);
+        std::memcpy(lat_coeffs + 6 * (size_t)at, c.lat.data(), sizeof(double) * 6 * m);
         std::memcpy(lon_T + at, c.T.data(), sizeof(double) * m);
         std::memcpy(traj_len_out + at, c.traj_len.data(), sizeof(int32_t) * m);
         std::memcpy(lon_end + at, c.v_end.data(), sizeof(double) * m);
         std::memcpy(lat_end + at, c.d_end.data(), sizeof(double) * m);
     });
+    const int64_t C = ends[(size_t)nT].load(std::memory_order_acquire);
+    *count = C;
+    if (C > cap || (C && !have_out)) return RP_ENOMEM;   // *count: room needed
     return RP_OK;
 }
 
