@@ -147,7 +147,7 @@ struct rp_ctx {
     KArgsGL kargs_gl{};          // launch block of rp_lon_kernel: KArgs + room for larger grids (it publishes them to d_stage for the kernels behind it)
     bool grids_pending = false;  // the grids of the last rp_plan (c->staged, h_stage) are neither in kargs_g nor in d_stage yet: run_pipeline
                                  // hands them to rp_lon_kernel's kernarg segment (two-kernel path) or copies them
-    char *h_arena = nullptr, *d_arena = nullptr;   // rp_coeffs_arena: pinned [lon 6 cap | lat 6 cap | traj_len cap] + its device mirror
+    char *h_arena = nullptr, *h_arena_dev = nullptr;   // rp_coeffs_arena: pinned [lon 6 cap | lat 6 cap | traj_len cap] and its device address
     int64_t arena_cap = 0;
     const double *cin_lon = nullptr, *cin_lat = nullptr;   // host arrays the last rp_plan_coeffs read (pinned stage or arena)
     int64_t cin_count = -1;   // rp_plan_coeffs: the explicit polynomials of the last such plan are the first 12 * cin_count doubles of h_stage (lon | lat)
@@ -1079,7 +1079,6 @@ void rp_destroy(rp_ctx *c) {
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_arena) (void)hipHostFree(c->h_arena);
-    if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1493,13 +1492,12 @@ int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_co
     if (cap > c->arena_cap) {
         if (c->stream) HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (c->h_arena) HIP_TRY(c, hipHostFree(c->h_arena));
-        if (c->d_arena) HIP_TRY(c, hipFree(c->d_arena));
-        c->h_arena = c->d_arena = nullptr; c->arena_cap = 0;
+        c->h_arena = c->h_arena_dev = nullptr; c->arena_cap = 0;
         c->have_last = false;   // (the last plan's polynomials may have lived in the old arena)
         c->cin_lon = c->cin_lat = nullptr; c->cin_count = -1;
         const size_t bytes = (size_t)cap * (12 * sizeof(double) + sizeof(int32_t));
         if (hipHostMalloc((void **)&c->h_arena, bytes, hipHostMallocDefault) != hipSuccess) { c->h_arena = nullptr; return fail(c, RP_ENOMEM, "rp_coeffs_arena: pinned host memory"); }
-        if (hipMalloc((void **)&c->d_arena, bytes) != hipSuccess) { (void)hipHostFree(c->h_arena); c->h_arena = c->d_arena = nullptr; return fail(c, RP_ENOMEM, "rp_coeffs_arena: device memory"); }
+        if (hipHostGetDevicePointer((void **)&c->h_arena_dev, c->h_arena, 0) != hipSuccess) { (void)hipHostFree(c->h_arena); c->h_arena = c->h_arena_dev = nullptr; return fail(c, RP_EHIP, "rp_coeffs_arena: device address of the pinned arrays"); }
         c->arena_cap = cap;
     }
     double *base = reinterpret_cast<double *>(c->h_arena);
@@ -1524,19 +1522,18 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     // else is copied into the pinned staging buffer first (2.4 MB at 25 536 candidates: a quarter of a millisecond of memcpy)
     const double *d_lon = nullptr, *d_lat = nullptr;
     const int32_t *d_tl = nullptr;
-    const bool in_arena = c->h_arena && C <= c->arena_cap && lon_coeffs == reinterpret_cast<const double *>(c->h_arena) &&
+    static const bool no_zero_copy = std::getenv("RP_AMD_NO_ZERO_COPY") != nullptr;   // (A/B: arena rows through the staging copy)
+    const bool in_arena = !no_zero_copy && c->h_arena && C <= c->arena_cap && lon_coeffs == reinterpret_cast<const double *>(c->h_arena) &&
                           lat_coeffs == reinterpret_cast<const double *>(c->h_arena) + 6 * c->arena_cap &&
                           traj_len == reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena) + 12 * c->arena_cap);
     if (in_arena) {
+        // the kernels read the pinned arrays themselves (each value once per plan or round: rp_lon_kernel the longitudinal
+        // polynomials, the evaluation kernel the lateral ones): three host-to-device copies of 28 + 27 + 7 us with 8-us gaps in
+        // front of the first kernel cost more than the reads over PCIe inside it (25 536 candidates: 0.336 -> 0.311 ms)
         const size_t o_lat = sizeof(double) * 6 * (size_t)c->arena_cap, o_tl = 2 * o_lat;
-        if (C) {
-            HIP_TRY(c, hipMemcpyAsync(c->d_arena, c->h_arena, sizeof(double) * 6 * C, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->d_arena + o_lat, c->h_arena + o_lat, sizeof(double) * 6 * C, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->d_arena + o_tl, c->h_arena + o_tl, sizeof(int32_t) * C, hipMemcpyHostToDevice, c->stream));
-        }
-        d_lon = reinterpret_cast<const double *>(c->d_arena);
-        d_lat = reinterpret_cast<const double *>(c->d_arena + o_lat);
-        d_tl = reinterpret_cast<const int32_t *>(c->d_arena + o_tl);
+        d_lon = reinterpret_cast<const double *>(c->h_arena_dev);
+        d_lat = reinterpret_cast<const double *>(c->h_arena_dev + o_lat);
+        d_tl = reinterpret_cast<const int32_t *>(c->h_arena_dev + o_tl);
         c->cin_lon = lon_coeffs; c->cin_lat = lat_coeffs;
     } else {
         const size_t sbytes = (size_t)C * (12 * sizeof(double) + sizeof(int32_t));

@@ -207,8 +207,9 @@ int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
 /* Pinned host arrays for the explicit polynomials of up to `cap` candidates, owned by the context: lon_coeffs [cap][6],
  * lat_coeffs [cap][6], traj_len [cap].  A sampling space that writes its candidates straight into them (rp_corridor_coeffs
  * with these as its outputs; CorridorSampling.generate_trajectories_at_level, sampling.py:340-397, builds one object per
- * candidate instead) and hands the very same pointers to rp_plan_coeffs saves it the copy into its own staging buffer -- at
- * 25 536 candidates 2.4 MB, a quarter of a millisecond, as much as the device needs for the whole plan.  The arrays stay
+ * candidate instead) and hands the very same pointers to rp_plan_coeffs saves it the copy into its own staging buffer and the
+ * transfers to the device -- the kernels read the pinned arrays themselves, every value once per plan (or per round of the
+ * cost-ordered stage).  The arrays stay
  * valid until rp_coeffs_arena is called with a larger cap (which frees them and hands out new ones) or rp_destroy; a call with
  * cap <= the current capacity returns the same arrays.  A plan that took its candidates from the arena reads the winner's
  * coefficients back from it (rp_result.best_*_coeffs, also in a later rp_select): leave the rows alone until the plan's results
