@@ -451,7 +451,7 @@ def corridor_sampling_cost(base, device, reps=15):
     # (as the planner sets it up in _create_trajectory_bundle: the batch view writes into the context's pinned arena, rp_coeffs_arena)
     sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
     sp.__dict__["_arena_owner"] = rp
-    for _ in range(reps):
+    for _ in range(3):   # (a third of a second each: kept out of the loop below, where it would leave the GPU idle between the calls)
         t0 = time.perf_counter()
         trajs = sp.generate_trajectories_at_level(1, x0_lon, x0_lat, mode, False)
         lon = np.array([t.trajectory_long.coeffs for t in trajs])
@@ -459,6 +459,7 @@ def corridor_sampling_cost(base, device, reps=15):
         lon_T = np.array([t.trajectory_long.delta_tau for t in trajs], dtype=float)
         tl = np.array([len(np.arange(0, np.round(tt + p.dt, 5), p.dt)) for tt in lon_T], dtype=np.int32)
         t_obj.append(time.perf_counter() - t0)
+    for _ in range(reps + 5):
         t0 = time.perf_counter()
         blon, blat, bT, btl, _, _ = sp.coeffs_at_level(1, x0_lon, x0_lat, mode, False)
         t_batch.append(time.perf_counter() - t0)
@@ -472,6 +473,7 @@ def corridor_sampling_cost(base, device, reps=15):
         rp._get_optimal_trajectory(rp._create_trajectory_bundle(x0_lon, x0_lat, samp_level=1))
         t_level.append(time.perf_counter() - t0)
     rp.close()
+    t_batch, t_dev, t_level = t_batch[5:], t_dev[5:], t_level[5:]   # (warm-up)
     ms = lambda v: float(np.median(v) * 1e3)   # noqa: E731
     return {"candidates": C, "objects_ms": ms(t_obj), "batch_view_ms": ms(t_batch), "rp_plan_coeffs_ms": ms(t_dev),
             "one_sampling_level_ms": ms(t_level), "winner": int(out.best_index), "candidates_per_s_device": C / (ms(t_dev) * 1e-3),

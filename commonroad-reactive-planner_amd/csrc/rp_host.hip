@@ -1511,6 +1511,7 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
                    double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
+    if (c->timing) c->t_entry = std::chrono::steady_clock::now();
     if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_coeffs: a plan is in flight on this context (rp_plan_wait first)");
     c->have_last = false;
     (void)lon_T;
