@@ -467,7 +467,8 @@ def corridor_sampling_cost(base, device, reps=15):
         params = rp._gpu_params(x0_lon, x0_lat, 0)
         cost = rp._gpu_cost()
         t0 = time.perf_counter()
-        out = ctx.plan_coeffs(params, cost, blon, blat, bT, btl)
+        lg = sp.__dict__.get("_last_groups")   # (as the planner does: groups of exactly these arrays)
+        out = ctx.plan_coeffs(params, cost, blon, blat, bT, btl, groups=lg[1] if (lg is not None and lg[0] is bT) else None)
         t_dev.append(time.perf_counter() - t0)
         t0 = time.perf_counter()
         rp._get_optimal_trajectory(rp._create_trajectory_bundle(x0_lon, x0_lat, samp_level=1))

@@ -225,6 +225,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
                                      C.POINTER(RpResult), dp]),
         "rp_coeffs_arena": (C.c_int, [ctx, C.c_int64, C.POINTER(dp), C.POINTER(dp), C.POINTER(ip)]),
+        "rp_coeffs_arena_groups": (C.c_int, [ctx, C.POINTER(ip), C.POINTER(ip)]),
+        "rp_plan_coeffs_grouped": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip, C.c_int64, ip, ip,
+                                             C.POINTER(RpResult), dp]),
         "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
         "rp_fetch_states": (C.c_int, [ctx, C.c_int64, C.c_int64, dp]),
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
@@ -234,6 +237,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_check_swept": (C.c_int, [ctx, C.POINTER(RpParams), C.c_int32, dp, dp, dp, ip, dp]),
         "rp_pyset_order": (C.c_int, [C.c_int32, dp, C.c_int32, dp, ip]),
         "rp_corridor_coeffs": (C.c_int, [C.c_int32, dp, ip, dp, dp, ip, dp, C.c_int32, dp, dp, C.c_int64, C.POINTER(C.c_int64), dp, dp, dp, ip, dp, dp]),
+        "rp_corridor_coeffs_grouped": (C.c_int, [C.c_int32, dp, ip, dp, dp, ip, dp, C.c_int32, dp, dp, C.c_int64, C.POINTER(C.c_int64), dp, dp, dp, ip,
+                                                 dp, dp, ip, ip, C.POINTER(C.c_int64)]),
         "rp_build_reference": (C.c_int, [C.c_int32, dp, C.c_int32, C.c_double, C.c_int32, ip, dp, dp, dp, dp, dp]),
         "rp_project": (C.c_int, [C.c_int32, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp]),
         "rp_initial_state": (C.c_int, [C.c_int32, dp, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
@@ -264,11 +269,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 _OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
-                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena")
+                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
+                          "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
-                    "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
+                    "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
 
 
@@ -320,11 +326,24 @@ def corridor_coeffs(T, traj_len, v_low, v_up, box_off, boxes, n_samples: int, x0
             alloc = keep.get("alloc")     # (a planner lets the candidates be written into its context's pinned arena: RpContext.coeffs_arena)
             lon_lat_tl = alloc(cap) if alloc is not None else (np.empty((cap, 6)), np.empty((cap, 6)), np.empty(cap, dtype=np.int32))
             keep["arrays"] = (lon_lat_tl[0], lon_lat_tl[1], np.empty(cap), lon_lat_tl[2], np.empty(cap), np.empty(cap))
+            # (an arena also has room for the candidates' groups -- lateral samples of one (T, v) sample share their longitudinal
+            #  polynomial: RpContext.coeffs_arena hands them out as items 3 and 4)
+            keep["group_arrays"] = (lon_lat_tl[3], lon_lat_tl[4]) if len(lon_lat_tl) >= 5 else None
         lon, lat, lt, tl, le, de = keep["arrays"]
         cnt = C.c_int64(0)
-        rc = lib.rp_corridor_coeffs(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
-                                    dptr(boxes), int(n_samples), dptr(x0_lon), dptr(x0_lat), cap, C.byref(cnt), dptr(lon), dptr(lat),
-                                    dptr(lt), tl.ctypes.data_as(ipt), dptr(le), dptr(de))
+        ga = keep.get("group_arrays")   # (group [cap], group_first [cap]) of the same arena, or None
+        if ga is not None and getattr(lib, "rp_corridor_coeffs_grouped", None) is not None:
+            ng = C.c_int64(0)
+            rc = lib.rp_corridor_coeffs_grouped(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
+                                                dptr(boxes), int(n_samples), dptr(x0_lon), dptr(x0_lat), cap, C.byref(cnt), dptr(lon), dptr(lat),
+                                                dptr(lt), tl.ctypes.data_as(ipt), dptr(le), dptr(de), ga[0].ctypes.data_as(ipt),
+                                                ga[1].ctypes.data_as(ipt), C.byref(ng))
+            keep["groups"] = (int(ng.value), ga[0][:int(cnt.value)], ga[1][:int(ng.value)]) if rc == 0 else None
+        else:
+            keep["groups"] = None
+            rc = lib.rp_corridor_coeffs(len(T), dptr(T), traj_len.ctypes.data_as(ipt), dptr(v_low), dptr(v_up), box_off.ctypes.data_as(ipt),
+                                        dptr(boxes), int(n_samples), dptr(x0_lon), dptr(x0_lat), cap, C.byref(cnt), dptr(lon), dptr(lat),
+                                        dptr(lt), tl.ctypes.data_as(ipt), dptr(le), dptr(de))
         k = int(cnt.value)
         if rc == 0:
             return lon[:k], lat[:k], lt[:k], tl[:k], le[:k], de[:k]
@@ -561,21 +580,35 @@ class RpContext:
         self._check(fn(self._h, int(cap), C.byref(lon), C.byref(lat), C.byref(tl)), "rp_coeffs_arena")
         arrays = (np.ctypeslib.as_array(lon, shape=(cap, 6)), np.ctypeslib.as_array(lat, shape=(cap, 6)),
                   np.ctypeslib.as_array(tl, shape=(cap,)))
+        gfn = getattr(self._lib, "rp_coeffs_arena_groups", None)
+        if gfn is not None:   # + (group [cap], group_first [cap]) for rp_corridor_coeffs_grouped / plan_coeffs(groups=...)
+            g, gf = C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+            self._check(gfn(self._h, C.byref(g), C.byref(gf)), "rp_coeffs_arena_groups")
+            arrays = arrays + (np.ctypeslib.as_array(g, shape=(cap,)), np.ctypeslib.as_array(gf, shape=(cap,)))
         self._arena = (int(cap), arrays)
         return arrays
 
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,
-                    want_best_states: bool = True) -> PlanOutput:
+                    want_best_states: bool = True, groups=None) -> PlanOutput:
+        """``groups``: (n_groups, group [C], group_first [n_groups]) -- candidates that share their longitudinal polynomial, as
+        ``rp_corridor_coeffs_grouped`` reports them; arena arrays only (``rp_plan_coeffs_grouped``)."""
         lon_coeffs, lat_coeffs, lon_T = f64(lon_coeffs), f64(lat_coeffs), f64(lon_T)
         traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
         cnt = len(traj_len)
         assert lon_coeffs.shape == (cnt, 6) and lat_coeffs.shape == (cnt, 6) and lon_T.shape == (cnt,)
         res = self._res
         best = np.empty((N_ARRAYS, params.N + 1)) if want_best_states else None
-        self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs),
-                                             dptr(lat_coeffs), dptr(lon_T),
-                                             traj_len.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(res), dptr(best)),
-                    "rp_plan_coeffs")
+        ipt = C.POINTER(C.c_int32)
+        if groups is not None and groups[0] > 0 and getattr(self._lib, "rp_plan_coeffs_grouped", None) is not None:
+            self._check(self._lib.rp_plan_coeffs_grouped(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs), dptr(lat_coeffs),
+                                                         dptr(lon_T), traj_len.ctypes.data_as(ipt), int(groups[0]),
+                                                         groups[1].ctypes.data_as(ipt), groups[2].ctypes.data_as(ipt), C.byref(res), dptr(best)),
+                        "rp_plan_coeffs_grouped")
+        else:
+            self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs),
+                                                 dptr(lat_coeffs), dptr(lon_T),
+                                                 traj_len.ctypes.data_as(ipt), C.byref(res), dptr(best)),
+                        "rp_plan_coeffs")
         self._N = params.N
         self._last_count = cnt
         return self._output(res, best)

@@ -400,6 +400,8 @@ class GpuBackendMixin:
                 sp.__dict__["_arena_owner"] = self
             coeffs = sp.coeffs_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode, self._low_vel_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, coeffs=coeffs)
+            lg = sp.__dict__.get("_last_groups")   # (groups of exactly these arrays, if the batch view reported any)
+            bundle.coeff_groups = lg[1] if (lg is not None and lg[0] is coeffs[2]) else None
         else:   # foreign sampling space: its own objects, polynomials handed to the device explicitly
             samples = sp.generate_trajectories_at_level(samp_level, x_0_lon, x_0_lat,
                                                         self.config.sampling.longitudinal_mode, self._low_vel_mode)
@@ -445,7 +447,8 @@ class GpuBackendMixin:
             if len(lon_T) == 0:
                 self._infeasible_count_kinematics = 0
                 return None
-            out = ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl)
+            groups = getattr(bundle, "coeff_groups", None)
+            out = ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl, groups=groups) if groups else ctx.plan_coeffs(params, cost, lon, lat, lon_T, tl)
         else:
             samples = bundle.trajectories
             if not samples:

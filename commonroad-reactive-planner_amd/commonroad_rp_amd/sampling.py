@@ -310,7 +310,12 @@ class CorridorSampling(SamplingSpace):
             T, tl, low, up, off, boxes = hit[3]
             from . import _capi
             # (views into arrays this object keeps: valid until the next call -- a level's bundle is done with them by then)
-            return _capi.corridor_coeffs(T, tl, low, up, off, boxes, n, x_0_lon, x_0_lat, self.__dict__.setdefault("_native_buffers", {}))
+            buffers = self.__dict__.setdefault("_native_buffers", {})
+            out = _capi.corridor_coeffs(T, tl, low, up, off, boxes, n, x_0_lon, x_0_lat, buffers)
+            # (which candidates share their longitudinal polynomial -- the lateral samples of one (T, v) sample --, when the buffers
+            #  are a context's arena: what the planner hands to plan_coeffs next to the arrays)
+            self._last_groups = (out[2], buffers.get("groups"))
+            return out
         return self._coeffs_at_level_py(level_sampling, x_0_lon, x_0_lat, longitudinal_mode, low_vel_mode)
 
     _native_state = None   # None: not checked yet; True / False: the library's set order agrees with this interpreter's

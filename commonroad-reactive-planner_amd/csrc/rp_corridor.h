@@ -150,6 +150,9 @@ struct Box { double p_lon_min, p_lon_max, p_lat_min, p_lat_max, v_lon_min, v_lon
 struct Candidates {
     std::vector<double> lon, lat, T, v_end, d_end;   // [C][6], [C][6], [C], [C], [C]
     std::vector<int32_t> traj_len;
+    // candidates that share a longitudinal polynomial -- the lateral samples of one (T, v) sample -- are adjacent: group[C] numbers
+    // them (0, 1, ... in order of appearance), first[groups] is a group's first candidate
+    std::vector<int32_t> group, first;
 };
 
 // candidates of the time samples [k_first, k_last), appended to `out` in the reference's order
@@ -164,7 +167,7 @@ inline void corridor_candidates(int k_first, int k_last, const double *T, const 
         for (int k = k_first; k < k_last; ++k) nodes_max = std::max(nodes_max, (size_t)(box_off[k + 1] - box_off[k]));
         const size_t guess = out.T.size() + (size_t)(k_last - k_first) * (size_t)n * (size_t)(n + 1) * std::max<size_t>(nodes_max, 1);
         out.lon.reserve(6 * guess); out.lat.reserve(6 * guess);
-        out.T.reserve(guess); out.v_end.reserve(guess); out.d_end.reserve(guess); out.traj_len.reserve(guess);
+        out.T.reserve(guess); out.v_end.reserve(guess); out.d_end.reserve(guess); out.traj_len.reserve(guess); out.group.reserve(guess);
     }
     const double s0 = x0_lon[0], sv0 = x0_lon[1], sa0 = x0_lon[2];
     const double p0 = x0_lat[0], v0 = x0_lat[1], a0 = x0_lat[2];
@@ -214,6 +217,8 @@ inline void corridor_candidates(int k_first, int k_last, const double *T, const 
                 if (lo < 0.0 && 0.0 < hi) base.union_with(&zero, 1).values(lateral);                 // :384-386
                 else base.values(lateral);
             }
+            if (!lateral.empty()) out.first.push_back((int32_t)out.T.size());
+            const int32_t gid = (int32_t)out.first.size() - 1;
             for (double d : lateral) {
                 // QuinticTrajectory to (d, 0, 0) over t (polynomial_trajectory.py:292-320), closed form
                 const double T2 = t * t, T3 = T2 * t;
@@ -225,6 +230,7 @@ inline void corridor_candidates(int k_first, int k_last, const double *T, const 
                 out.lat.insert(out.lat.end(), q, q + 6);
                 out.T.push_back(t); out.v_end.push_back(v); out.d_end.push_back(d);
                 out.traj_len.push_back(traj_len[k]);
+                out.group.push_back(gid);
             }
         }
     }

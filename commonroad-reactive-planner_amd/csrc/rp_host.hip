@@ -150,6 +150,8 @@ struct rp_ctx {
     char *h_arena = nullptr, *h_arena_dev = nullptr;   // rp_coeffs_arena: pinned [lon 6 cap | lat 6 cap | traj_len cap] and its device address
     int64_t arena_cap = 0;
     const double *cin_lon = nullptr, *cin_lat = nullptr;   // host arrays the last rp_plan_coeffs read (pinned stage or arena)
+    int64_t cin_groups = 0;                 // rp_plan_coeffs_grouped: groups of the last such plan (0: one pair per candidate)
+    const int32_t *cin_group_of = nullptr;  //   and the host view of its candidate -> group table (arena)
     int64_t cin_count = -1;   // rp_plan_coeffs: the explicit polynomials of the last such plan are the first 12 * cin_count doubles of h_stage (lon | lat)
 };
 
@@ -691,7 +693,8 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         fused_pairs = ka.lds_pairs;
         if (c->last_G) G = c->last_G;
     } else {
-        if (!std::getenv("RP_AMD_NO_FUSED_LON")) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
+        // (grouped explicit polynomials: the two-kernel path -- the single-launch prologue counts one pair per candidate there)
+        if (!std::getenv("RP_AMD_NO_FUSED_LON") && !(cin && ka.pair_of)) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
     }
     ka.lds_pairs = fused_pairs;
     if (!skip_eval) {
@@ -749,7 +752,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         }
         // longitudinal profiles of every (T, longitudinal sample) pair touched by the candidate range
         if (count > 0 && !fused_lds) {
-            if (cin) { ka.pair_begin = 0; ka.pair_count = count; }
+            if (cin) { ka.pair_begin = 0; ka.pair_count = ka.pair_of ? c->cin_groups : count; }
             else {
                 ka.pair_begin = ka.cand_begin / ka.nD;
                 ka.pair_count = (ka.cand_begin + count - 1) / ka.nD + 1 - ka.pair_begin;
@@ -1495,7 +1498,7 @@ int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_co
         c->h_arena = c->h_arena_dev = nullptr; c->arena_cap = 0;
         c->have_last = false;   // (the last plan's polynomials may have lived in the old arena)
         c->cin_lon = c->cin_lat = nullptr; c->cin_count = -1;
-        const size_t bytes = (size_t)cap * (12 * sizeof(double) + sizeof(int32_t));
+        const size_t bytes = (size_t)cap * (12 * sizeof(double) + 3 * sizeof(int32_t));   // lon | lat | traj_len | group | group_first
         if (hipHostMalloc((void **)&c->h_arena, bytes, hipHostMallocDefault) != hipSuccess) { c->h_arena = nullptr; return fail(c, RP_ENOMEM, "rp_coeffs_arena: pinned host memory"); }
         if (hipHostGetDevicePointer((void **)&c->h_arena_dev, c->h_arena, 0) != hipSuccess) { (void)hipHostFree(c->h_arena); c->h_arena = c->h_arena_dev = nullptr; return fail(c, RP_EHIP, "rp_coeffs_arena: device address of the pinned arrays"); }
         c->arena_cap = cap;
@@ -1509,6 +1512,21 @@ int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_co
 int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
                    const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, rp_result *result,
                    double *best_states) {
+    return rp_plan_coeffs_grouped(c, p, cost, C, lon_coeffs, lat_coeffs, lon_T, traj_len, 0, nullptr, nullptr, result, best_states);
+}
+
+int rp_coeffs_arena_groups(rp_ctx *c, int32_t **group, int32_t **group_first) {
+    if (!c) return RP_EINVAL;
+    if (!c->h_arena || !group || !group_first) return fail(c, RP_ESTATE, "rp_coeffs_arena_groups: no arena (rp_coeffs_arena first) / null output");
+    int32_t *tl = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(c->h_arena) + 12 * c->arena_cap);
+    *group = tl + c->arena_cap;
+    *group_first = tl + 2 * c->arena_cap;
+    return RP_OK;
+}
+
+int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                           const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups, const int32_t *group,
+                           const int32_t *group_first, rp_result *result, double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
     if (c->timing) c->t_entry = std::chrono::steady_clock::now();
@@ -1563,6 +1581,21 @@ int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C
     ka.lon_coeffs = d_lon; ka.lat_coeffs = d_lat;
     ka.traj_len_c = d_tl;
     ka.cand_begin = 0; ka.count = C;
+    // candidates in groups with a common longitudinal polynomial: one profile per group (pair = group).  Out of the arena only -- the
+    // kernels read the group tables where the sampling space wrote them, as they read the polynomials.
+    c->cin_groups = 0; c->cin_group_of = nullptr;
+    static const bool no_groups = std::getenv("RP_AMD_NO_COEFF_GROUPS") != nullptr;   // (A/B: one profile per candidate)
+    if (n_groups > 0 && group && group_first && !no_groups) {
+        int32_t *tl_h = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(c->h_arena) + 12 * c->arena_cap);
+        if (!in_arena || group != tl_h + c->arena_cap || group_first != tl_h + 2 * c->arena_cap || n_groups > C)
+            return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: groups come with candidates out of the context's arena (rp_coeffs_arena, rp_coeffs_arena_groups)");
+        if (C > 0 && (group[0] != 0 || group[C - 1] != (int32_t)(n_groups - 1) || group_first[0] != 0))
+            return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: group numbers must run from 0 to n_groups - 1");
+        const int32_t *tl_d = reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena_dev) + 12 * c->arena_cap);
+        ka.pair_of = tl_d + c->arena_cap;
+        ka.group_first = tl_d + 2 * c->arena_cap;
+        c->cin_groups = n_groups; c->cin_group_of = group;
+    }
     ka.status = c->d_status; ka.cost = c->d_cost;
     ka.states = mat ? c->d_states : nullptr;
     c->have_last = false;
@@ -1644,7 +1677,7 @@ int rp_eval_one(rp_ctx *c, int64_t index, double *states, uint32_t *status, doub
     kw.partials = nullptr;
     // the candidate's pair may lie outside the last plan's shard: give it a one-pair profile of its own
     if ((rc = grow(c, c->d_profile_one, c->cap_profile_one, (size_t)PF_FIELDS * (size_t)n)) != RP_OK) return rc;
-    kw.pair_begin = c->last_coeffs ? index : index / l.nD;
+    kw.pair_begin = c->last_coeffs ? (l.pair_of && c->cin_group_of ? (int64_t)c->cin_group_of[index] : index) : index / l.nD;
     kw.pair_count = 1;
     kw.profile = c->d_profile_one;
     kw.pair_hdr = c->d_pair_hdr_one;
@@ -1909,6 +1942,14 @@ int rp_pyset_order(int32_t n, const double *values, int32_t union_zero, double *
 int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up, const int32_t *box_off,
                        const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat, int64_t cap, int64_t *count,
                        double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out, double *lon_end, double *lat_end) {
+    return rp_corridor_coeffs_grouped(nT, T, traj_len, v_low, v_up, box_off, boxes, n_samples, x0_lon, x0_lat, cap, count, lon_coeffs, lat_coeffs,
+                                      lon_T, traj_len_out, lon_end, lat_end, nullptr, nullptr, nullptr);
+}
+
+int rp_corridor_coeffs_grouped(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up,
+                               const int32_t *box_off, const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat,
+                               int64_t cap, int64_t *count, double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out,
+                               double *lon_end, double *lat_end, int32_t *group, int32_t *group_first, int64_t *n_groups) {
     if (nT < 0 || n_samples < 1 || !count || !x0_lon || !x0_lat || (nT && (!T || !traj_len || !v_low || !v_up || !box_off))) return RP_EINVAL;
     if (nT && box_off[nT] > 0 && !boxes) return RP_EINVAL;
     // one part per time sample, worked out on the library's host threads (rp_pool.h), put together in the reference's order: a level
@@ -1924,19 +1965,26 @@ int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, con
     // One pass: a part is worked out, waits for the end offset of the part before it (items are handed out in ascending order, so
     // that part was started earlier), publishes its own and copies itself into the output -- no second wake-up of the pool for
     // the copies.  Parts that would not fit are not copied; *count is the room needed.
-    static std::vector<std::atomic<int64_t>> ends;
-    if (ends.size() < (size_t)nT + 1) { std::vector<std::atomic<int64_t>> grown((size_t)nT + 1); ends.swap(grown); }
-    for (int k = 0; k <= nT; ++k) ends[(size_t)k].store(k == 0 ? 0 : -1, std::memory_order_relaxed);
+    static std::vector<std::atomic<int64_t>> ends, gends;   // end offsets of the parts: candidates, groups
+    if (ends.size() < (size_t)nT + 1) {
+        std::vector<std::atomic<int64_t>> grown((size_t)nT + 1), ggrown((size_t)nT + 1);
+        ends.swap(grown); gends.swap(ggrown);
+    }
+    for (int k = 0; k <= nT; ++k) { ends[(size_t)k].store(k == 0 ? 0 : -1, std::memory_order_relaxed); gends[(size_t)k].store(0, std::memory_order_relaxed); }
     const bool have_out = lon_coeffs && lat_coeffs && lon_T && traj_len_out && lon_end && lat_end;
     pool.parallel_for(nT, [&](int k) {
         rpco::Candidates &c = parts[(size_t)k];
-        c.lon.clear(); c.lat.clear(); c.T.clear(); c.v_end.clear(); c.d_end.clear(); c.traj_len.clear();
+        c.lon.clear(); c.lat.clear(); c.T.clear(); c.v_end.clear(); c.d_end.clear(); c.traj_len.clear(); c.group.clear(); c.first.clear();
         rpco::corridor_candidates(k, k + 1, T, traj_len, v_low, v_up, box_off, bx, n_samples, x0_lon, x0_lat, c);
-        const size_t m = c.T.size();
+        const size_t m = c.T.size(), mg = c.first.size();
         int64_t at;
         while ((at = ends[(size_t)k].load(std::memory_order_acquire)) < 0) __builtin_ia32_pause();
+        const int64_t gat = gends[(size_t)k].load(std::memory_order_relaxed);   // (written before ends[k], read behind it)
+        gends[(size_t)k + 1].store(gat + (int64_t)mg, std::memory_order_relaxed);
         ends[(size_t)k + 1].store(at + (int64_t)m, std::memory_order_release);
         if (!m || !have_out || at + (int64_t)m > cap) return;
+        if (group) for (size_t i = 0; i < m; ++i) group[(size_t)at + i] = (int32_t)gat + c.group[i];
+        if (group_first) for (size_t g = 0; g < mg; ++g) group_first[(size_t)gat + g] = (int32_t)at + c.first[g];   // (groups <= candidates <= cap)
         std::memcpy(lon_coeffs + 6 * (size_t)at, c.lon.data(), sizeof(double) * 6 * m);
         std::memcpy(lat_coeffs + 6 * (size_t)at, c.lat.data(), sizeof(double) * 6 * m);
         std::memcpy(lon_T + at, c.T.data(), sizeof(double) * m);
@@ -1946,6 +1994,7 @@ int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, con
     });
     const int64_t C = ends[(size_t)nT].load(std::memory_order_acquire);
     *count = C;
+    if (n_groups) *n_groups = gends[(size_t)nT].load(std::memory_order_relaxed);
     if (C > cap || (C && !have_out)) return RP_ENOMEM;   // *count: room needed
     return RP_OK;
 }

@@ -61,6 +61,11 @@ struct KArgs {
     const double *lon_coeffs;  // [C][6]  (COEFFS_IN)
     const double *lat_coeffs;  // [C][6]
     const int32_t *traj_len_c; // [C]
+    // COEFFS_IN, optional: candidates that share their longitudinal polynomial (all lateral samples of one (T, v) sample of a corridor
+    // level) form a group -- one longitudinal profile per group instead of one per candidate.  pair_of[C]: group of a candidate
+    // (ascending, adjacent); group_first[groups]: its first candidate, whose lon_coeffs / traj_len_c rows stand for the group.
+    const int32_t *pair_of;
+    const int32_t *group_first;
     // candidate range: global indices [cand_begin, cand_begin + count)
     int64_t cand_begin, count;
     const int64_t *single_index;  // != nullptr: evaluate exactly this one (global) candidate -> slot 0
@@ -1078,14 +1083,23 @@ struct LonPairIn {
     int L;
 };
 
+// (T, longitudinal sample) pair of a candidate: its index / nD on a grid, itself for explicit polynomials -- or its group, where the
+// caller said which candidates share their longitudinal polynomial (KArgs::pair_of)
+template <bool COEFFS_IN, class KA>
+__device__ __forceinline__ int64_t pair_index(const KA &a, int64_t gidx) {
+    if (COEFFS_IN) return a.pair_of ? (int64_t)a.pair_of[gidx] : gidx;
+    return (int64_t)((uint32_t)gidx / (uint32_t)a.nD);
+}
+
 template <bool COEFFS_IN>
 __device__ __forceinline__ LonPairIn lon_pair_fetch(const KArgs &a, int64_t pair) {
     LonPairIn r;
     if (COEFFS_IN) {
-        const double *pl = a.lon_coeffs + 6 * pair;
+        const int64_t row = a.group_first ? (int64_t)a.group_first[pair] : pair;   // (grouped: the group's first candidate)
+        const double *pl = a.lon_coeffs + 6 * row;
 #pragma unroll
         for (int k = 0; k < 6; ++k) r.c[k] = pl[k];
-        r.L = a.traj_len_c[pair];
+        r.L = a.traj_len_c[row];
     } else {
         const int iT = (int)((uint32_t)pair / (uint32_t)a.nL), iL = (int)((uint32_t)pair - (uint32_t)iT * (uint32_t)a.nL);
         const double *gb = grid_base(a);
@@ -1529,7 +1543,7 @@ __device__ __forceinline__ void fetch_lateral(const KArgs &a, int64_t gidx, Cand
         const double *pt = a.lat_coeffs + 6 * gidx;
 #pragma unroll
         for (int k = 0; k < 6; ++k) ci.v[k] = pt[k];
-        pair = gidx;
+        pair = pair_index<true>(a, gidx);
     } else {
         const uint32_t g32 = (uint32_t)gidx, nd = (uint32_t)a.nD;   // candidate indices fit 32 bits (checked by the host)
         const uint32_t p32 = g32 / nd;
@@ -1884,7 +1898,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const int64_t ls0 = slot0 < count ? slot0 : (wave_first < count ? wave_first : (a.index_list ? (int64_t)blockIdx.x * GPB : 0));
         const int64_t g0 = a.single_index ? *a.single_index : (a.index_list ? (int64_t)a.index_list[ls0] : a.cand_begin + ls0);
         cin = fetch_candidate<COEFFS_IN>(a, g0, hdr_base, pair0);
-        const int32_t ps0 = (int32_t)((COEFFS_IN ? g0 : (int64_t)((uint32_t)g0 / (uint32_t)a.nD)) - pair0);
+        const int32_t ps0 = (int32_t)(pair_index<COEFFS_IN>(a, g0) - pair0);
         const int32_t pw0 = __builtin_amdgcn_readfirstlane(ps0);   // pair of the wavefront's first candidate (wave-uniform)
         const uint32_t n80 = (uint32_t)(a.N + 1) * 8u;
         pf0 = load_profile<PFN, G == 16>(reinterpret_cast<const char *>(prof_base + ((size_t)pw0 * PF_FIELDS) * (size_t)(a.N + 1)),
@@ -1954,7 +1968,7 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
         const double s0 = cin.s0;
         const uint32_t pre_reason = (uint32_t)cin.pre_reason;   // pre-filter verdict of the pair (label stays None)
         // profile rows are addressed arithmetically (no dependence on the header load just issued)
-        const int32_t pair_slot_ = (int32_t)((COEFFS_IN ? gidx : (int64_t)((uint32_t)gidx / (uint32_t)al.nD)) - pair0);
+        const int32_t pair_slot_ = (int32_t)(pair_index<COEFFS_IN>(al, gidx) - pair0);
         const int32_t pair_w = __builtin_amdgcn_readfirstlane(pair_slot_);   // wavefront's first candidate: wave-uniform base
         const uint32_t n8p = (uint32_t)n * 8u;
         const char *const pbase = reinterpret_cast<const char *>(prof_base + ((size_t)pair_w * PF_FIELDS) * (size_t)n);

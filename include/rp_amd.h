@@ -215,6 +215,16 @@ int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
  * coefficients back from it (rp_result.best_*_coeffs, also in a later rp_select): leave the rows alone until the plan's results
  * have been collected -- writing the next level's candidates is what ends a level anyway. */
 int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len);
+/* Two more arrays of the arena handed out last, int32 [cap] each: room for the group of every candidate and the first candidate of
+   every group (rp_corridor_coeffs_grouped writes them, rp_plan_coeffs_grouped reads them). */
+int rp_coeffs_arena_groups(rp_ctx *ctx, int32_t **group, int32_t **group_first);
+/* rp_plan_coeffs for candidates that come in groups with a common longitudinal polynomial (and traj_len): group[C] ascending without
+   gaps from 0, the candidates of a group adjacent; group_first[n_groups].  The rows of a group's first candidate stand for the
+   group.  Arrays out of the context's arena only (rp_coeffs_arena, rp_coeffs_arena_groups); n_groups == 0 or group == NULL: as
+   rp_plan_coeffs.  Results are those of rp_plan_coeffs on the same candidates. */
+int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                           const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups,
+                           const int32_t *group, const int32_t *group_first, rp_result *result, double *best_states);
 
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
 /* How the last plan answered the collision query (reactive_planner.py:1019-1063):
@@ -297,6 +307,14 @@ int rp_plan_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
 int rp_corridor_coeffs(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up, const int32_t *box_off,
                        const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat, int64_t cap, int64_t *count,
                        double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out, double *lon_end, double *lat_end);
+/* The same, and which candidates share their longitudinal polynomial: the lateral samples of one (time, velocity) sample are
+   adjacent rows and form a group.  group[cap]: number of a candidate's group (0, 1, ... in order of appearance); group_first[cap]:
+   first candidate of a group; *n_groups.  What rp_plan_coeffs_grouped takes (one longitudinal profile per group on the device
+   instead of one per candidate: `share work across d`, as the grid plans do).  Any of the three may be NULL. */
+int rp_corridor_coeffs_grouped(int32_t nT, const double *T, const int32_t *traj_len, const double *v_low, const double *v_up,
+                               const int32_t *box_off, const double *boxes, int32_t n_samples, const double *x0_lon, const double *x0_lat,
+                               int64_t cap, int64_t *count, double *lon_coeffs, double *lat_coeffs, double *lon_T, int32_t *traj_len_out,
+                               double *lon_end, double *lat_end, int32_t *group, int32_t *group_first, int64_t *n_groups);
 int rp_pyset_order(int32_t n, const double *values, int32_t union_zero, double *out /* [n + 1] */, int32_t *n_out);
 
 /* ---- reference-path front end (host only; no GPU involved) ---------------------------------------

@@ -29,8 +29,10 @@ x0_lon, x0_lat = rp.x_0_cl
 mode = rp.config.sampling.longitudinal_mode
 blon, blat, bT, btl, _, _ = sp.coeffs_at_level(1, x0_lon, x0_lat, mode, False)
 params, cost = rp._gpu_params(x0_lon, x0_lat, 0), rp._gpu_cost()
+groups = None if os.environ.get("PROBE_NO_GROUPS") else sp._last_groups[1]
+print("groups", groups[0] if groups else None)
 ts = []
 for _ in range(40):
-    t0 = time.perf_counter(); out = ctx.plan_coeffs(params, cost, blon, blat, bT, btl); ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter(); out = ctx.plan_coeffs(params, cost, blon, blat, bT, btl, groups=groups); ts.append(time.perf_counter() - t0)
 print("plan_coeffs p50 us", np.median(ts) * 1e6, "candidates", len(bT), "winner", out.best_index, "path", ctx.last_path())
 rp.close()

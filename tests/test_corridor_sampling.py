@@ -152,10 +152,20 @@ def test_corridor_candidates_on_every_launch_path(name):
             ctx = RpContext(0)
             ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
             ctx.set_obstacles(tabs)
-            for extra in (0, FLAG_MATERIALIZE_ALL):
+            # every case twice: plain arrays (one longitudinal profile per candidate), and written into the context's arena with the
+            # groups the batch view reports (rp_plan_coeffs_grouped: one profile per (T, v) sample) -- where this interpreter's sets
+            # allow the native batch view
+            spa = _space(z)
+            grouped = spa._native_ok()
+            if grouped:
+                spa.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+                alon, alat, aT, atl, _, _ = spa.coeffs_at_level(int(z["level"]), z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+                groups = spa._last_groups[1]
+                assert groups is not None and groups[0] > 0
+            for extra, use_groups in ((0, False), (FLAG_MATERIALIZE_ALL, False)) + (((0, True), (FLAG_MATERIALIZE_ALL, True)) if grouped else ()):
                 p, cost = _params(z, extra)
                 orun = oracle.plan_coeffs(p, cost, tb, lon, lat, tl)
-                out = ctx.plan_coeffs(p, cost, lon, lat, T, tl)
+                out = ctx.plan_coeffs(p, cost, alon, alat, aT, atl, groups=groups) if use_groups else ctx.plan_coeffs(p, cost, lon, lat, T, tl)
                 status, c = ctx.fetch_status()
                 from _lazy import lazy_relaxed
                 _check_against_fixture(status, c, out, z)             # (the reference's own labels are lazy: raw labels against them)
@@ -195,21 +205,40 @@ def test_candidates_written_into_the_contexts_arena(name):
         calls.append(cap)
         return ctx.coeffs_arena(cap)
     sp2.__dict__["_native_buffers"] = {"alloc": alloc, "cap": 64}    # (too small on purpose: the first call has to grow)
-    for rep in range(2):
+    for rep in range(3):
         alon, alat, aT, atl, _, _ = sp2.coeffs_at_level(level, *args)
         base = ctx.coeffs_arena(calls[-1])
+        groups = sp2._last_groups[1]
+        # candidates of a group are adjacent and share their longitudinal polynomial and traj_len; group_first points at their first
+        ng, gof, gfirst = groups
+        assert ng == len(gfirst) and len(gof) == len(aT) and gof[0] == 0 and gof[-1] == ng - 1 and np.all(np.diff(gof) >= 0) and np.all(np.diff(gof) <= 1)
+        np.testing.assert_array_equal(alon, alon[gfirst[gof]])
+        np.testing.assert_array_equal(atl, atl[gfirst[gof]])
+        assert ng < len(aT)
         assert alon.ctypes.data == base[0].ctypes.data and alat.ctypes.data == base[1].ctypes.data and atl.ctypes.data == base[2].ctypes.data
         np.testing.assert_array_equal(alon, lon)
-        out = ctx.plan_coeffs(p, cost, alon, alat, aT, atl)
+        # rep 0 / 2: one longitudinal profile per group (rp_plan_coeffs_grouped); rep 1: one per candidate -- same results
+        out = ctx.plan_coeffs(p, cost, alon, alat, aT, atl, groups=groups if rep != 1 else None)
         status, c = ctx.fetch_status()
         assert out.best_index == want.best_index and out.n_feasible == want.n_feasible
         np.testing.assert_array_equal(status, want_status)
-        np.testing.assert_array_equal(c, want_cost)
+        if rep == 1:   # the same launch path as `want` (a batch this small takes the single-launch kernel): bit for bit
+            np.testing.assert_array_equal(c, want_cost)
+        else:          # grouped plans take the two-kernel path: its sums round differently in the last bit (tolerances of test_gpu_parity)
+            np.testing.assert_allclose(c, want_cost, rtol=1e-12, atol=1e-9)
         if want.best_index >= 0:
-            np.testing.assert_array_equal(out.best_states, want.best_states)
+            if rep == 1:
+                np.testing.assert_array_equal(out.best_states, want.best_states)
+            else:
+                np.testing.assert_allclose(out.best_states, want.best_states, rtol=0, atol=1e-9)
             np.testing.assert_array_equal(out.best_lon_coeffs, lon[want.best_index])
             np.testing.assert_array_equal(out.best_lat_coeffs, lat[want.best_index])
     assert len(calls) >= 2 and calls[-1] >= len(T)
+    # (the last plan was a grouped one) a single candidate re-evaluated on the device: its rows are the batch's
+    states = ctx.fetch_states()
+    have = np.flatnonzero((want_status & 3) == 1)    # (rows of infeasible candidates are not materialised outside draw mode)
+    for idx in (have[0], have[len(have) // 2], have[-1]):
+        np.testing.assert_array_equal(ctx.eval_one(int(idx))[0], states[idx])
     ctx.close()
 
 
@@ -293,3 +322,56 @@ def test_library_batch_view_from_concurrent_callers():
     for t in threads:
         t.join()
     assert not errors, errors[0]
+
+
+@pytest.mark.gpu
+def test_grouped_plan_equals_ungrouped_on_a_large_corridor():
+    """25 536 candidates in 651 (T, v) groups on cfg3's route and obstacles (the level bench.py's corridor record times): one
+    longitudinal profile per group against one per candidate -- labels, costs, counters, winner; production and materialising mode"""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import copy_params
+    base = W.WORKLOADS["cfg3"]()
+    rp = W.make_planner(base, device=0)
+    p = base.inputs.params
+    sp = CorridorSampling(rp.config)
+    sp.samples_t._dict_level_to_sample_set[1] = set(float(t) for t in base.inputs.T)
+    sp._dict_level_to_num_samples = {k: 21 for k in range(rp.config.sampling.num_sampling_levels)}
+    s0, v0 = p.x0_lon[0], max(p.x0_lon[1], 1.0)
+    cor = {}
+    for q in range(p.N + 2):
+        t = q * p.dt
+        cor[p.time_step0 + q] = [ReachBox(s0 - 1.0, s0 + 1.6 * v0 * t + 4.0, -2.8, -0.3, 0.5 * v0, 1.3 * v0 + 1.0),
+                                 ReachBox(s0 + 0.3 * v0 * t, s0 + 1.8 * v0 * t + 6.0, -0.5, 1.4, 0.6 * v0, 1.4 * v0 + 1.0),
+                                 ReachBox(s0 + 0.8 * v0 * t + 2.0, s0 + 2.0 * v0 * t + 8.0, 2.0, 3.0, 0.9 * v0, 1.5 * v0 + 1.0)]
+    sp.driving_corridor = cor
+    if not sp._native_ok():
+        pytest.skip("this interpreter's set order is not the library's: no native batch view")
+    ctx = rp._gpu_ctx()
+    sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+    x0_lon, x0_lat = rp.x_0_cl
+    lon, lat, T, tl, _, _ = sp.coeffs_at_level(1, x0_lon, x0_lat, rp.config.sampling.longitudinal_mode, False)
+    groups = sp._last_groups[1]
+    assert len(T) > 20000 and 0 < groups[0] < len(T) // 10
+    cost = rp._gpu_cost()
+    for flags in (0, FLAG_MATERIALIZE_ALL):
+        prm = copy_params(rp._gpu_params(x0_lon, x0_lat, flags))
+        res = {}
+        for key, g in (("plain", None), ("grouped", groups)):
+            os.environ["RP_AMD_LAZY"] = "0"      # (labels of both runs from the eager query: comparable one by one)
+            try:
+                out = ctx.plan_coeffs(prm, cost, lon, lat, T, tl, groups=g)
+            finally:
+                os.environ.pop("RP_AMD_LAZY", None)
+            status, c = ctx.fetch_status()
+            res[key] = (out, status.copy(), c.copy(), ctx.fetch_states().copy() if flags else None)
+        a, b = res["plain"], res["grouped"]
+        assert a[0].best_index == b[0].best_index >= 0 and a[0].n_feasible == b[0].n_feasible
+        assert a[0].n_collision == b[0].n_collision and a[0].n_collision_before_best == b[0].n_collision_before_best
+        np.testing.assert_array_equal(a[0].reason_counts, b[0].reason_counts)
+        np.testing.assert_array_equal(a[1], b[1])
+        np.testing.assert_array_equal(a[2], b[2])            # (the same launch path, the same profile values: bit for bit)
+        np.testing.assert_array_equal(a[0].best_states, b[0].best_states)
+        if flags:
+            have = (a[1] & 3) == 1
+            np.testing.assert_array_equal(a[3][have], b[3][have])
+    rp.close()
