@@ -375,3 +375,36 @@ def test_grouped_plan_equals_ungrouped_on_a_large_corridor():
             have = (a[1] & 3) == 1
             np.testing.assert_array_equal(a[3][have], b[3][have])
     rp.close()
+
+
+@pytest.mark.gpu
+def test_grouped_plan_refuses_malformed_group_tables():
+    """the kernels index through the group tables: rp_plan_coeffs_grouped looks at every entry before it launches anything"""
+    from commonroad_rp_amd._capi import RpContext, RpError
+    z = _load(CASES[0])
+    sp = _space(z)
+    if not sp._native_ok():
+        pytest.skip("no native batch view with this interpreter's set order")
+    ctx = RpContext(0)
+    ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
+    ctx.set_obstacles(_tables(z))
+    sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+    lon, lat, T, tl, _, _ = sp.coeffs_at_level(int(z["level"]), z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+    ng, gof, gfirst = sp._last_groups[1]
+    p, cost = _params(z, 0)
+    want = ctx.plan_coeffs(p, cost, lon, lat, T, tl, groups=(ng, gof, gfirst)).best_index
+    for spoil in ("gap", "order", "first", "range"):
+        keep_of, keep_first = gof.copy(), gfirst.copy()
+        if spoil == "gap":
+            gof[len(gof) // 2:] += 1
+        elif spoil == "order":
+            gof[1], gof[-1] = gof[-1], gof[1]
+        elif spoil == "first":
+            gfirst[1] += 1
+        else:
+            gof[-1] = ng + 5
+        with pytest.raises(RpError):
+            ctx.plan_coeffs(p, cost, lon, lat, T, tl, groups=(ng, gof, gfirst))
+        gof[:], gfirst[:] = keep_of, keep_first
+    assert ctx.plan_coeffs(p, cost, lon, lat, T, tl, groups=(ng, gof, gfirst)).best_index == want
+    ctx.close()
