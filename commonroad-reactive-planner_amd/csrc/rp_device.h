@@ -584,31 +584,6 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     RP_WSTAMP(10);
     const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
     m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
-#ifdef RP_NARROW_TWO_STAGE
-    typedef double dbl2n __attribute__((ext_vector_type(2)));
-    typedef const dbl2n __attribute__((address_space(4))) *gcdouble2n;
-    const gcdouble2n xyt = (gcdouble2n)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
-    while (__any(m != 0)) {   // wave-uniform trip count = largest number of near obstacles among the lanes
-        const bool act = m != 0;
-        const int j = act ? __ffsll((unsigned long long)m) - 1 : 0;
-        m &= m - 1;           // (0 stays 0)
-        const size_t at = (size_t)j * ob.n_steps + kc;
-        // the (pair, step) mask is exact to ~7 m only: most of its bits fail the pose's own circle test -- two loads (centre as one
-        // 16-byte pair, bounding radius) decide that; the four of the rectangle follow for the wavefronts that have a close pose
-        const dbl2n ctr = xyt[at];
-        const double rr = ego_r + dyn[6 * plane + at];
-        const double dx = ctr.x - ego.cx, dy = ctr.y - ego.cy;
-        const bool close = act && dx * dx + dy * dy <= rr * rr * 1.000001;   // false for NaN
-        if (__any(close)) {
-            const gcdouble o = dyn + at;
-            const double ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane], hw = o[5 * plane];
-            if (close) {
-                Obb b = {ctr.x, ctr.y, ux, uy, hl, hw};
-                hit |= obb_obb(ego, b);
-            }
-        }
-    }
-#else
     while (__any(m != 0)) {   // wave-uniform trip count = largest number of near obstacles among the lanes
         const bool act = m != 0;
         const int j = act ? __ffsll((unsigned long long)m) - 1 : 0;
@@ -623,7 +598,6 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
             hit |= obb_obb(ego, b);
         }
     }
-#endif
     if (__any(overflow)) {    // more than 63 dynamic obstacles: the tail is tested one by one
         for (int j = 63; j < ob.n_dyn; ++j) {
             const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
