@@ -1585,7 +1585,11 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
     // kernels read the group tables where the sampling space wrote them, as they read the polynomials.
     c->cin_groups = 0; c->cin_group_of = nullptr;
     static const bool no_groups = std::getenv("RP_AMD_NO_COEFF_GROUPS") != nullptr;   // (A/B: one profile per candidate)
-    if (n_groups > 0 && group && group_first && !no_groups && !no_zero_copy) {   // (RP_AMD_NO_ZERO_COPY: the A/B path copies the rows, the group tables stay behind)
+    // (a level small enough for the single-launch variant keeps one pair per candidate: one launch less beats the shared profiles there)
+    int fused_pairs_q = 0;
+    const bool single_launch = !std::getenv("RP_AMD_NO_FUSED_LON") &&
+                               fused_lon_lds(c, ka, C, lanes_per_candidate(c, ka.N, C, mat), true, mat, &fused_pairs_q) != 0;
+    if (n_groups > 0 && group && group_first && !no_zero_copy) {   // (RP_AMD_NO_ZERO_COPY: the A/B path copies the rows, the group tables stay behind)
         int32_t *tl_h = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(c->h_arena) + 12 * c->arena_cap);
         if (!in_arena || group != tl_h + c->arena_cap || group_first != tl_h + 2 * c->arena_cap || n_groups > C)
             return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: groups come with candidates out of the context's arena (rp_coeffs_arena, rp_coeffs_arena_groups)");
@@ -1597,10 +1601,12 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
         }
         if (!tables_ok)
             return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: groups must be adjacent and numbered 0 .. n_groups - 1 in order, group_first their first candidates");
-        const int32_t *tl_d = reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena_dev) + 12 * c->arena_cap);
-        ka.pair_of = tl_d + c->arena_cap;
-        ka.group_first = tl_d + 2 * c->arena_cap;
-        c->cin_groups = n_groups; c->cin_group_of = group;
+        if (!no_groups && !single_launch) {   // (tables checked either way: what a call accepts does not depend on the batch size)
+            const int32_t *tl_d = reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena_dev) + 12 * c->arena_cap);
+            ka.pair_of = tl_d + c->arena_cap;
+            ka.group_first = tl_d + 2 * c->arena_cap;
+            c->cin_groups = n_groups; c->cin_group_of = group;
+        }
     }
     ka.status = c->d_status; ka.cost = c->d_cost;
     ka.states = mat ? c->d_states : nullptr;
