@@ -408,3 +408,70 @@ def test_grouped_plan_refuses_malformed_group_tables():
         gof[:], gfirst[:] = keep_of, keep_first
     assert ctx.plan_coeffs(p, cost, lon, lat, T, tl, groups=(ng, gof, gfirst)).best_index == want
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_random_corridors_grouped_against_the_oracle(seed):
+    """random corridors (one to four reach boxes per time step, overlapping or apart; 3 .. 11 samples per
+    interval) on a fixture's route and obstacles: the grouped device plan out of the arena against the oracle on the same candidates --
+    on the two-kernel paths (eager and cost-ordered), where the groups are used whatever the batch size, and on the default one"""
+    from _paths import launch_path_env
+    from commonroad_rp_amd._capi import RpContext
+    from oracle import oracle
+    rng = np.random.default_rng(1000 + seed)
+    z = _load(CASES[seed % len(CASES)])
+    sp = _space(z)
+    if not sp._native_ok():
+        pytest.skip("no native batch view with this interpreter's set order")
+    s0, v0 = float(z["x0_lon"][0]), max(float(z["x0_lon"][1]), 1.0)
+    dt, N, t0 = float(z["dt"]), int(z["N"]), int(z["time_step0"])
+    cor = {}
+    for q in range(N + 2):
+        t = q * dt
+        boxes = []
+        for _ in range(int(rng.integers(1, 5))):
+            lo = s0 + rng.uniform(-1.0, 1.2) * v0 * t + rng.uniform(-2.0, 2.0)
+            dlo = rng.uniform(-3.5, 2.5)
+            vlo = rng.uniform(0.3, 1.0) * v0
+            boxes.append(ReachBox(lo, lo + rng.uniform(0.5, 1.5) * v0 * max(t, 0.5) + 2.0, dlo, dlo + rng.uniform(0.3, 3.0), vlo,
+                                  vlo + rng.uniform(0.2, 1.0) * v0 + 0.5))
+        if boxes:
+            cor[t0 + q] = boxes
+    sp.driving_corridor = cor
+    n_samples = int(rng.choice([3, 5, 9, 11]))
+    sp._dict_level_to_num_samples = {k: n_samples for k in range(sp.num_sampling_levels)}
+    level = int(z["level"])
+    tabs = _tables(z)
+    tb = oracle.OracleTables(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]), tabs)
+    for path in ("single_launch", "two_kernel", "lazy"):
+        with launch_path_env(path):
+            ctx = RpContext(0)
+            ctx.set_reference(z["ref_pos"], z["ref_theta"], z["ref_curv"], z["ref_curv_d"], z["ref_path"], float(z["proj_d_limit"]))
+            ctx.set_obstacles(tabs)
+            sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
+            try:
+                lon, lat, T, tl, _, _ = sp.coeffs_at_level(level, z["x0_lon"], z["x0_lat"], "velocity_keeping", False)
+            except KeyError:      # (a time sample of the level without a corridor entry: the reference raises there as well)
+                ctx.close()
+                pytest.skip("the random corridor misses a time sample of the level")
+            groups = sp._last_groups[1]
+            if len(T) == 0:
+                ctx.close()
+                continue
+            assert groups is not None and 0 < groups[0] <= len(T)
+            for extra in (0, FLAG_MATERIALIZE_ALL):
+                p, cost = _params(z, extra)
+                orun = oracle.plan_coeffs(p, cost, tb, np.array(lon), np.array(lat), np.array(tl))
+                out = ctx.plan_coeffs(p, cost, lon, lat, T, tl, groups=groups)
+                status, c = ctx.fetch_status()
+                from _lazy import lazy_relaxed
+                status, _ = lazy_relaxed(status, c, orun, ctx, out)
+                np.testing.assert_array_equal(status & 0x7F, orun.status & 0x7F)
+                has = ~np.isnan(orun.cost)
+                np.testing.assert_allclose(c[has], orun.cost[has], rtol=1e-9)
+                assert out.best_index == orun.out.best_index and out.n_feasible == orun.out.n_feasible
+                assert out.n_collision_before_best == orun.out.n_collision_before_best
+                if out.best_index >= 0:
+                    np.testing.assert_allclose(out.best_states, orun.out.best_states, rtol=0, atol=1e-6)
+            ctx.close()
