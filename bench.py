@@ -366,7 +366,7 @@ def side_configs(args, torch, device, skip):
     out = {}
     guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.2, "cfg3f": 0.2, "cfg4": 1.4, "cfg5": 2.5}
     # (cfg2rb: the T-junction with its road boundary in the obstacle tables, 85 thin rectangles from the lanelet network)
-    for name in ("cfg2", "cfg2rb", "cfg3", "cfg3f", "cfg4", "cfg5"):
+    for name in ("cfg1", "cfg2", "cfg2rb", "cfg3", "cfg3f", "cfg4", "cfg5"):   # (cfg1: the size of the reference's shipped configurations, N = 20)
         if name == skip:
             continue
         w = W.cfg2(road_boundary=True) if name == "cfg2rb" else W.WORKLOADS[name]()

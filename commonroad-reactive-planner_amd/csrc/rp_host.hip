@@ -378,8 +378,10 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
     if (!mat) return 16;
     // up to 32 steps (the shipped configurations: N = 20): 16 lanes, two step blocks -- except for the smallest batches, where
     // every wavefront has a SIMD to itself either way and one step block of 32 lanes is the shorter chain
-    // (profiles/probe_small_n20.py: 120 candidates 28.8 vs 31.5 us per step, 630: 29.6 vs 32.2, 3 060: equal, 7 440: 41 vs 32)
-    if (N + 1 <= 32) return (N + 1 > 16 && count <= (int64_t)c->num_cus * 4) ? 32 : 16;
+    // (profiles/probe_small_n20.py, end of round 3, 32 vs 16 lanes: 630 candidates at N = 20 31.3 vs 36.0 us per step, 3 060: 34.3 vs 37.3;
+    //  N = 30: 1 041 candidates 27.3 vs 30.0, 2 083: equal, 4 092: 31.1 vs 30.7, 7 440: 38.7 vs 31.1 -- one step block of 32 lanes wins
+    //  up to about three wavefronts per SIMD-quarter of the chip; round 2 had the switch at 1 024 candidates)
+    if (N + 1 <= 32) return (N + 1 > 16 && count <= (int64_t)c->num_cus * 12) ? 32 : 16;
     // longer horizons: one wavefront per candidate for the small batches (at most ~4 wavefronts per SIMD; up to 64 steps that is
     // the single-launch variant with one step block: 400 candidates 36 vs 43 us per step, 2 600: equal), 16 lanes beyond -- 4
     // candidates per wavefront, rows stored straight to memory in 128-byte runs on 128-byte lines (state_row_stride).  Round 1
