@@ -373,6 +373,11 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
         int g = std::atoi(e);
         if (g == 16 || g == 32 || g == 64) return g;
     }
+    // horizons of 33 .. 64 steps (the reference's default N = 60), mid-sized batches: two step blocks of 32 lanes -- half the chain of
+    // four blocks of 16, twice the wavefronts -- win between the one-wavefront-per-candidate range and the batches that fill the chip
+    // anyway (profiles/probe_small_n60.py, end of round 3, 32 vs 16 lanes, production / draw: 6 000 candidates 51.6 vs 57.1 / 52.0 vs
+    // 57.1 us per step, 12 500: 80.0 vs 94.9 / 74.7 vs 81.5; 2 601: as 64 lanes; 22 500: 93.3 vs 83.0 / 87.1 vs 78.0)
+    if (N + 1 > 32 && N + 1 <= 64 && count > (int64_t)c->num_cus * 10 && count <= (int64_t)c->num_cus * 64) return 32;
     // measured on MI355X (profiles/r01_lanes_per_candidate.txt): without state rows 16 lanes per candidate
     // win at every horizon; with state rows long horizons want whole-wavefront rows (512-byte runs)
     if (!mat) return 16;

@@ -6,7 +6,7 @@ sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd")]
 from commonroad_rp_amd import workloads as W
 from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL
 w = W.WORKLOADS["cfg3"]()
-for nT, nL, nD in ((5, 9, 9), (9, 17, 17), (15, 20, 20)):
+for nT, nL, nD in ((5, 9, 9), (9, 17, 17), (15, 20, 20), (20, 25, 25), (25, 30, 30), (31, 36, 36)):
     T = w.inputs.T[:: max(1, len(w.inputs.T) // nT)][:nT]; tl = w.inputs.traj_len[:: max(1, len(w.inputs.T) // nT)][:nT]
     L = np.linspace(w.inputs.L.min(), w.inputs.L.max(), nL); D = np.linspace(-3, 3, nD)
     for mode, fl in (("production", 0), ("draw", FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL)):
