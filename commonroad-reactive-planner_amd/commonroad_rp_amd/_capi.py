@@ -25,6 +25,7 @@ CHECK_BITS = {"velocity": 1, "acceleration": 2, "kappa": 4, "kappa_dot": 8, "yaw
 LON_VELOCITY_KEEPING, LON_STOPPING = 0, 1
 COST_DEFAULT, COST_FAILSAFE, COST_EXTERNAL = 0, 1, 2
 FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, FLAG_SKIP_COLLISION = 1, 2, 4
+COLLISION_AUTO, COLLISION_EAGER, COLLISION_COST_ORDERED, COLLISION_TIMED = 0, 1, 2, 3
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "librp_amd.so")
@@ -212,6 +213,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_last_error": (C.c_char_p, [ctx]),
         "rp_set_profiling": (C.c_int, [ctx, C.c_int]),
         "rp_last_path": (C.c_int, [ctx]),
+        "rp_set_collision_path": (C.c_int, [ctx, C.c_int]),
         "rp_set_reference": (C.c_int, [ctx, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double]),
         "rp_set_obstacles": (C.c_int, [ctx, C.c_int32, dp, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32,
                                        C.c_int32, dp]),
@@ -268,10 +270,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+_OPTIONAL_IN_AB_BUILDS = ("rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
                           "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
                           "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
-EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path",
+EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path", "rp_set_collision_path",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
@@ -436,6 +438,7 @@ class RpContext:
         if getattr(self, "_h", None):
             self._lib.rp_destroy(self._h)
             self._h = None
+        self._arena = self._fast = self._fast_last = None   # (views of memory the context owned)
 
     def __del__(self):
         try:
@@ -456,6 +459,12 @@ class RpContext:
         candidates in ascending cost until the first free one), 2 cost-ordered stage exhausted, eager kernel decided."""
         fn = getattr(self._lib, "rp_last_path", None)
         return int(fn(self._h)) if fn is not None else 0
+
+    def set_collision_path(self, mode: int):
+        """``rp_set_collision_path``: how production-mode plans of large batches answer the collision query -- COLLISION_AUTO
+        (default: cost-ordered with a back-off that depends on the sequence of plans only), COLLISION_EAGER, COLLISION_COST_ORDERED,
+        COLLISION_TIMED (the context's clock picks the faster path)."""
+        self._check(self._lib.rp_set_collision_path(self._h, int(mode)), "rp_set_collision_path")
 
     def set_reference(self, ref_pos, ref_theta, ref_curv, ref_curv_d, ref_xy, proj_domain_d_limit: float = 20.0):
         ref_pos, ref_theta, ref_curv, ref_curv_d = f64(ref_pos), f64(ref_theta), f64(ref_curv), f64(ref_curv_d)

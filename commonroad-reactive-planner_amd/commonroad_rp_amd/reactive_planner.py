@@ -245,7 +245,17 @@ class GpuBackendMixin:
         return world if (world > 1 and n_candidates >= self.shard_min_candidates) else 1
 
     # ---- context and tables -----------------------------------------------------------------------
+    def _collect_inflight(self):
+        """A sampling level started ahead in the last cycle and never needed (``_plan_fast``) is still in flight on its context:
+        collect it before that context is asked for anything else -- ``rp_plan_begin`` / ``rp_set_reference`` / ``rp_set_obstacles``
+        refuse a context with a plan in flight (RP_ESTATE)."""
+        ctx = self.__dict__.get("_rp_inflight")
+        if ctx is not None:
+            self._rp_inflight = None
+            ctx.plan_wait()
+
     def _gpu_ctx(self):
+        self._collect_inflight()
         ctx = getattr(self, "_rp_ctx", None)
         if ctx is None:
             ctx = self._rp_ctx = self.backend_factory(self.gpu_device)
@@ -328,12 +338,21 @@ class GpuBackendMixin:
         self._rp_tables_checker = getattr(self, "_cc", None)   # (drop-in mode: these tables stand for the planner's checker)
 
     def close(self):
+        try:
+            self._collect_inflight()
+        except Exception:   # (a context that cannot deliver any more is destroyed all the same)
+            self._rp_inflight = None
         for name in ("_rp_ctx", "_rp_ctx2"):
             ctx = getattr(self, name, None)
             if ctx is not None:
                 ctx.close()
                 setattr(self, name, None)
-        self._rp_inflight = None
+        # a sampling space that wrote its candidates into pinned arrays of the context just destroyed (rp_coeffs_arena) must not
+        # keep views of them: the next context hands out its own
+        sp = getattr(self, "sampling_space", None)
+        if sp is not None:
+            for key in ("_native_buffers", "_arena_owner", "_last_groups"):
+                sp.__dict__.pop(key, None)
 
     # ---- per-call inputs ---------------------------------------------------------------------------
     def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
@@ -391,13 +410,17 @@ class GpuBackendMixin:
             grids = sp.grids_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, grids=grids)
         elif hasattr(sp, "coeffs_at_level"):   # data-dependent candidates (CorridorSampling), batch view: coefficient arrays
-            if sp.__dict__.get("_arena_owner") is not self:
+            ctx = self._gpu_ctx()
+            if sp.__dict__.get("_arena_owner") is not ctx:
                 # the library writes the candidates straight into pinned arrays of this planner's context (rp_coeffs_arena): rp_plan_coeffs
-                # then skips its copy into the staging buffer -- a quarter of a millisecond at 25 000 candidates
-                ctx = self._gpu_ctx()
+                # then skips its copy into the staging buffer -- a quarter of a millisecond at 25 000 candidates.  The arrays belong
+                # to the CONTEXT (rp_destroy frees them): a planner that was closed and plans again gets the new context's
+                sp.__dict__.pop("_last_groups", None)
                 if hasattr(ctx, "coeffs_arena"):
                     sp.__dict__["_native_buffers"] = {"alloc": ctx.coeffs_arena}
-                sp.__dict__["_arena_owner"] = self
+                else:
+                    sp.__dict__.pop("_native_buffers", None)
+                sp.__dict__["_arena_owner"] = ctx
             coeffs = sp.coeffs_at_level(samp_level, x_0_lon, x_0_lat, self.config.sampling.longitudinal_mode, self._low_vel_mode)
             bundle = GpuTrajectoryBundle(self, samp_level, x_0_lon, x_0_lat, coeffs=coeffs)
             lg = sp.__dict__.get("_last_groups")   # (groups of exactly these arrays, if the batch view reported any)
@@ -765,6 +788,8 @@ class ReactivePlanner(GpuBackendMixin):
         assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
         x_0_lon, x_0_lat = self.x_0_cl
         self._low_vel_mode = bool(self.x_0.velocity < self.config.planning.low_vel_mode_threshold)
+        if self.__dict__.get("_rp_inflight") is not None:   # (whatever path this cycle takes: the context is free first)
+            self._collect_inflight()
 
         optimal, bundle = None, None
         i = 1 if current_sampling_level is None else current_sampling_level
@@ -828,10 +853,6 @@ class ReactivePlanner(GpuBackendMixin):
         # last cycle needed a second level, this one puts level i + 1 on the device -- on a second context -- right behind level i
         # and collects it only if level i fails: one round trip for both.
         ahead = split and self._levels_ahead and not single_level
-        stale = getattr(self, "_rp_inflight", None)
-        if stale is not None:   # a level started ahead in the last cycle and never needed: its context is free once collected
-            stale.plan_wait()
-            self._rp_inflight = None
         out, started, first = None, None, level   # started: (level, context, inputs) of the plan begun ahead
         packed_call = getattr(ctx, "plan_packed", None) if (not ahead and hook is None) else None
         blk = buf = None

@@ -101,7 +101,10 @@ struct rp_ctx {
     double *d_lazy_states = nullptr;
     size_t cap_lazy_states = 0;
     int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
+    int collision_mode = RP_COLLISION_AUTO;   // rp_set_collision_path
     int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
+    double last_best_cost = 0.0;           // winner of the last collected plan (rp_count_collisions_before after a cost-ordered plan)
+    int64_t last_best_index = -1;
     // Which of the two ways to answer the collision query is the faster one depends on the scene (how deep into the cost order
     // the first free candidate lies) and on the batch (what a collision round costs against the eager kernel's extra work): the
     // context times its own plans -- whole calls, rp_plan / rp_plan_packed / rp_plan_coeffs -- per path and uses the faster one,
@@ -597,8 +600,9 @@ int wait_ticket(rp_ctx *c, unsigned long long seq) {
 // The longitudinal profiles are in place (run_pipeline launched rp_lon_kernel).  *done: the result block in pinned host memory is
 // final (winner or "no candidate survives"); otherwise the caller runs the eager kernel over the whole batch.
 template <typename LaunchEval>
-int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_rows, LaunchEval &launch_main_eval, bool *done) {
+int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_rows, LaunchEval &launch_main_eval, bool *done, int *rounds) {
     *done = false;
+    *rounds = 0;
     (void)G;
     const int n = ka.N + 1;
     const int64_t count = ka.count;
@@ -669,6 +673,7 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_ro
         const uint32_t overflow = (uint32_t)(ex[1] >> 32), checked = (uint32_t)ex[2];
         const unsigned long long feasible = ex[3];
         cnt[0] = (uint32_t)ex[0]; cnt[1] = (uint32_t)(ex[0] >> 32); cnt[2] = (uint32_t)ex[1];
+        *rounds = l + 1;
         if (overflow & ((2u << l) - 1u)) return RP_OK;              // this round's list (or an earlier one) was incomplete: not conclusive
         if (hrb_host->r.best_index >= 0) { *done = true; return RP_OK; }
         if ((unsigned long long)checked >= feasible) { *done = true; return RP_OK; }   // every feasible candidate collides: no winner
@@ -797,10 +802,13 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
                              ka.cost_kind != RP_COST_EXTERNAL && !ka.single_index;
         const char *lazy_e = lazy_possible ? std::getenv("RP_AMD_LAZY") : nullptr;   // (read per plan: the tests switch paths)
         const int lazy_env = lazy_e ? std::atoi(lazy_e) : -1;
-        lazy_possible = lazy_possible && lazy_env != 0;
-        bool lazy_try = lazy_possible && (lazy_env == 1 || (!small && c->lazy_skip == 0));
-        if (lazy_possible && !lazy_try && lazy_env != 1 && !small && c->lazy_skip > 0) --c->lazy_skip;
-        c->path_adaptive = lazy_possible && lazy_env == -1 && !small;
+        lazy_possible = lazy_possible && lazy_env != 0 && (c->collision_mode != RP_COLLISION_EAGER || lazy_env == 1);
+        const bool always = lazy_env == 1 || (lazy_env == -1 && c->collision_mode == RP_COLLISION_COST_ORDERED);
+        bool lazy_try = lazy_possible && (always || (!small && c->lazy_skip == 0));
+        if (lazy_possible && !lazy_try && !always && !small && c->lazy_skip > 0) --c->lazy_skip;
+        // RP_COLLISION_TIMED: the context's own clock decides (what a plan labels then depends on earlier timings); the default rule
+        // below depends on the sequence of plans alone
+        c->path_adaptive = lazy_possible && lazy_env == -1 && !small && c->collision_mode == RP_COLLISION_TIMED;
         if (c->path_adaptive) {
             int lg = 0;
             while ((count >> (lg + 1)) != 0) ++lg;
@@ -817,8 +825,21 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         }
         c->last_lazy = 0;
         if (lazy_try) {
-            if ((rc = run_lazy(c, ka, cin, G, grid, best_states != nullptr, launch_main_eval, &lazy_done)) != RP_OK) return rc;
-            if (lazy_done) { c->lazy_penalty = 0; c->last_lazy = 1; c->last_rows_on_device = best_states != nullptr; }
+            int lazy_rounds = 0;
+            if ((rc = run_lazy(c, ka, cin, G, grid, best_states != nullptr, launch_main_eval, &lazy_done, &lazy_rounds)) != RP_OK) return rc;
+            if (lazy_done) {
+                c->last_lazy = 1; c->last_rows_on_device = best_states != nullptr;
+                // A stage that needed its third list to find the winner (three rounds and their epilogues, host decisions in
+                // between) costs more than the eager kernel on batches whose query is cheap: such a scene keeps the next 1, 2, 4 ..
+                // 64 plans eager, like one where the stage ran dry.  A rule over the sequence of plans, not over a clock: the same
+                // calls label the same candidates in every run (RP_COLLISION_TIMED measures instead).
+                if (lazy_rounds >= RP_LAZY_LEVELS && !always && !c->path_adaptive) {
+                    c->lazy_penalty = std::min(64, std::max(1, c->lazy_penalty * 2));
+                    c->lazy_skip = c->lazy_penalty;
+                } else {
+                    c->lazy_penalty = 0;
+                }
+            }
             else {   // the eager kernel decides (profiles are in place); the next plans do not try again for a while
                 c->lazy_penalty = std::min(64, std::max(1, c->lazy_penalty * 2));
                 c->lazy_skip = c->lazy_penalty;
@@ -927,6 +948,7 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     *result = hrb->r;
     result->n_collision_before_best = (int64_t)hrb->n_before;
     host_winner_coeffs(c, ka, cin, result);
+    c->last_best_cost = result->best_cost; c->last_best_index = result->best_index;
     if (result->best_index >= 0 && best_states)
         std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
 #ifdef RP_STAMPS
@@ -1101,6 +1123,14 @@ const char *rp_last_error(const rp_ctx *c) { return c ? c->err.c_str() : "null c
 
 int rp_last_path(const rp_ctx *c) { return c ? c->last_lazy : 0; }
 
+int rp_set_collision_path(rp_ctx *c, int mode) {
+    if (!c) return RP_EINVAL;
+    if (mode < RP_COLLISION_AUTO || mode > RP_COLLISION_TIMED) return fail(c, RP_EINVAL, "rp_set_collision_path: unknown mode");
+    if (mode != c->collision_mode) { c->lazy_skip = c->lazy_penalty = 0; c->path_regime = -1; }
+    c->collision_mode = mode;
+    return RP_OK;
+}
+
 int rp_set_profiling(rp_ctx *c, int enable) {
     if (!c) return RP_EINVAL;
     c->profiling = enable < 0 ? 0 : enable;   // k: every k-th call is timed (1 = every call)
@@ -1180,7 +1210,7 @@ int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *
 // rectangle whose centre lies anywhere in the cell.  Distances: exact for rectangles, through the bounding circle for
 // triangles (an under-estimate: more bits, never fewer).  At most ~2^20 cells (8 MB); the cell grows with the map.
 // Built on first use and again when a plan comes with a larger ego rectangle (a smaller one keeps the grid: still conservative).
-int ensure_static_grid(rp_ctx *c, double ego_r) {
+static int ensure_static_grid(rp_ctx *c, double ego_r) {
     if (c->grid_valid && ego_r <= c->grid_ego_r) return RP_OK;
     const int n_clus = (int)(c->h_clus_info.size() / 4);
     c->obs.grid = nullptr; c->obs.gnx = c->obs.gny = 0;
@@ -1722,6 +1752,11 @@ int rp_count_collisions_before(rp_ctx *c, double cost, int64_t index, int64_t *c
     if (!c) return RP_EINVAL;
     if (c->pending.active) return fail(c, RP_ESTATE, "rp_count_collisions_before: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last || !count) return fail(c, RP_ESTATE, "rp_count_collisions_before: no plan / null output");
+    // after a cost-ordered plan the labels are complete up to the plan's own winner (all of them without one): a key behind it
+    // would count candidates nobody looked at
+    if (c->last_lazy == 1 && c->last_best_index >= 0 && !(cost < c->last_best_cost || (cost == c->last_best_cost && index <= c->last_best_index)))
+        return fail(c, RP_ESTATE, "rp_count_collisions_before: (cost, index) sorts behind the winner of a plan that answered the collision "
+                                  "query in cost order (rp_last_path() == RP_PATH_LAZY)");
     HIP_TRY(c, hipSetDevice(c->device));
     ResultBlock *drb = reinterpret_cast<ResultBlock *>(c->d_result);
     const KArgs &l = c->last;
@@ -1744,6 +1779,11 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
     if (c->pending.active) return fail(c, RP_ESTATE, "rp_select: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last) return fail(c, RP_ESTATE, "rp_select: no plan on this context");
     if (!result || count != c->last.count || (count && !costs)) return fail(c, RP_EINVAL, "rp_select: count mismatch");
+    // a cost-ordered plan (rp_last_path() == RP_PATH_LAZY) answered the collision query for the candidates it had to look at only:
+    // the others keep RP_LABEL_FEASIBLE, and a selection with other costs could crown a colliding one
+    if (c->last_lazy == 1)
+        return fail(c, RP_ESTATE, "rp_select: the last plan answered the collision query in cost order (rp_last_path() == RP_PATH_LAZY); "
+                                  "plan with RP_FLAG_MATERIALIZE_ALL / RP_COST_EXTERNAL, which take the eager query");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc;
     if ((rc = grow(c, c->d_user, c->cap_user, (size_t)count)) != RP_OK) return rc;
@@ -1991,11 +2031,18 @@ int rp_corridor_coeffs_grouped(int32_t nT, const double *T, const int32_t *traj_
     }
     for (int k = 0; k <= nT; ++k) { ends[(size_t)k].store(k == 0 ? 0 : -1, std::memory_order_relaxed); gends[(size_t)k].store(0, std::memory_order_relaxed); }
     const bool have_out = lon_coeffs && lat_coeffs && lon_T && traj_len_out && lon_end && lat_end;
-    pool.parallel_for(nT, [&](int k) {
+    std::atomic<bool> part_failed{false};
+    const bool items_ok = pool.parallel_for(nT, [&](int k) {
         rpco::Candidates &c = parts[(size_t)k];
-        c.lon.clear(); c.lat.clear(); c.T.clear(); c.v_end.clear(); c.d_end.clear(); c.traj_len.clear(); c.group.clear(); c.first.clear();
-        rpco::corridor_candidates(k, k + 1, T, traj_len, v_low, v_up, box_off, bx, n_samples, x0_lon, x0_lat, c);
-        const size_t m = c.T.size(), mg = c.first.size();
+        bool ok = true;
+        try {   // (the vectors grow: std::bad_alloc must neither leave a worker thread nor the chain of end offsets unpublished)
+            c.lon.clear(); c.lat.clear(); c.T.clear(); c.v_end.clear(); c.d_end.clear(); c.traj_len.clear(); c.group.clear(); c.first.clear();
+            rpco::corridor_candidates(k, k + 1, T, traj_len, v_low, v_up, box_off, bx, n_samples, x0_lon, x0_lat, c);
+        } catch (...) {
+            ok = false;
+            part_failed.store(true);
+        }
+        const size_t m = ok ? c.T.size() : 0, mg = ok ? c.first.size() : 0;
         int64_t at;
         while ((at = ends[(size_t)k].load(std::memory_order_acquire)) < 0) __builtin_ia32_pause();
         const int64_t gat = gends[(size_t)k].load(std::memory_order_relaxed);   // (written before ends[k], read behind it)
@@ -2012,6 +2059,7 @@ int rp_corridor_coeffs_grouped(int32_t nT, const double *T, const int32_t *traj_
         std::memcpy(lat_end + at, c.d_end.data(), sizeof(double) * m);
     });
     const int64_t C = ends[(size_t)nT].load(std::memory_order_acquire);
+    if (!items_ok || part_failed.load()) { *count = 0; return RP_ENOMEM; }
     *count = C;
     if (n_groups) *n_groups = gends[(size_t)nT].load(std::memory_order_relaxed);
     if (C > cap || (C && !have_out)) return RP_ENOMEM;   // *count: room needed

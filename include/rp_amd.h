@@ -234,14 +234,28 @@ int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *
  *                          until the first free one -- production-mode plans of large batches with obstacles;
  *   RP_PATH_LAZY_FALLBACK  the cost-ordered stage ran out of candidates (a scene where nearly everything collides) and the
  *                          eager kernel decided; results as RP_PATH_EAGER.
- * Winner, cost, infeasible_count_collision and the kinematic counters are the same on every path.
- * Where both apply, a context picks by its own clock: it times its whole-call plans (rp_plan, rp_plan_packed, rp_plan_coeffs)
- * per path, takes the faster one and measures the other again every 64th plan; a stage that ran out of candidates keeps the
- * next 1, 2, 4 .. 64 plans eager.  RP_AMD_LAZY=0 / 1 in the environment pins the choice (tests, measurements). */
+ * Winner, cost, infeasible_count_collision and the kinematic counters are the same on every path; what differs are the labels of
+ * colliding candidates BEHIND the winner (RP_LABEL_INFEASIBLE_COLLISION above) and rp_result.n_collision.
+ * Which path a production-mode plan of a large batch takes is a setting of the context (rp_set_collision_path):
+ *   RP_COLLISION_AUTO          (default) cost-ordered, except that a stage that ran out of candidates or needed its third and last
+ *                              list to find the winner keeps the next 1, 2, 4 .. 64 eligible plans eager.  A rule over the
+ *                              SEQUENCE OF PLANS: the same calls label the same candidates in every run.
+ *   RP_COLLISION_EAGER         always the eager query: every colliding candidate is labelled (what rp_select needs).
+ *   RP_COLLISION_COST_ORDERED  always the cost-ordered stage where the launch path allows it (eager fallback when it runs dry).
+ *   RP_COLLISION_TIMED         the context's own clock decides: it times its whole-call plans (rp_plan, rp_plan_packed,
+ *                              rp_plan_coeffs) per path, takes the faster one and measures the other again every 64th plan.
+ *                              Fastest on average; which candidates behind the winner carry a collision label then depends on
+ *                              earlier timings -- read rp_last_path() before interpreting them.
+ * RP_AMD_LAZY=0 / 1 in the environment pins the choice for every context (tests, measurements). */
 #define RP_PATH_EAGER 0
 #define RP_PATH_LAZY 1
 #define RP_PATH_LAZY_FALLBACK 2
 int rp_last_path(const rp_ctx *ctx);
+#define RP_COLLISION_AUTO 0
+#define RP_COLLISION_EAGER 1
+#define RP_COLLISION_COST_ORDERED 2
+#define RP_COLLISION_TIMED 3
+int rp_set_collision_path(rp_ctx *ctx, int mode);
 /* status[count], cost[count] (NaN where no cost) for local candidates first .. first+count-1
  * (local = relative to cand_begin).  Either pointer may be NULL. */
 int rp_fetch_status(rp_ctx *ctx, int64_t first, int64_t count, uint32_t *status, double *cost);
@@ -250,10 +264,13 @@ int rp_fetch_states(rp_ctx *ctx, int64_t first, int64_t count, double *states);
 /* state block of one (global) candidate index of the last plan, re-evaluated on the device. */
 int rp_eval_one(rp_ctx *ctx, int64_t index, double *states, uint32_t *status, double *cost);
 /* Multi-GPU second pass: number of colliding feasible local candidates that precede the global
- * winner (cost, index) in the reference's sorted order. */
+ * winner (cost, index) in the reference's sorted order.  After a cost-ordered plan (rp_last_path() == RP_PATH_LAZY) the labels are
+ * complete up to the plan's own winner: a key that sorts behind it is refused with RP_ESTATE. */
 int rp_count_collisions_before(rp_ctx *ctx, double cost, int64_t index, int64_t *count);
 /* Plug-in cost functions (RP_COST_EXTERNAL): upload one cost per local candidate (NaN = skip) and
- * redo the selection (argmin + collision counters) on the device. */
+ * redo the selection (argmin + collision counters) on the device.  Needs a plan that labelled every colliding candidate: after a
+ * cost-ordered plan (rp_last_path() == RP_PATH_LAZY) the call returns RP_ESTATE (plans with RP_COST_EXTERNAL or
+ * RP_FLAG_MATERIALIZE_ALL -- what a plug-in cost needs anyway -- always take the eager query). */
 int rp_select(rp_ctx *ctx, const double *costs, int64_t count, rp_result *result, double *best_states);
 
 /* Smallest and largest cost among the local candidates of the last plan that have one (the kinematically feasible ones,

@@ -13,7 +13,10 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def case_names():
-    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith(("scenario_", "plan_", "frontend_", "corridor_", "loop_")))
+    # (cfg<k>_ref*: BASELINE.json's configurations at full size, tests/test_baseline_reference.py)
+    import re
+    return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+                  if not n.startswith(("scenario_", "plan_", "frontend_", "corridor_", "loop_")) and not re.match(r"cfg\d_ref", n))
 
 
 class Golden:
@@ -96,7 +99,8 @@ def build_planner_from_plan_golden(name: str, backend_factory, planner_cls=None)
         planning=dict(dt=float(z["dt"]), time_steps_computation=int(z["N"]), factor=int(z["factor"]),
                       low_vel_mode_threshold=float(z["low_vel_mode_threshold"]),
                       continuous_collision_check=bool(int(z["continuous"]))),
-        sampling=dict(longitudinal_mode="stopping" if int(z["lon_mode"]) else "velocity_keeping", t_min=float(z["t_min"]))))
+        sampling=dict(longitudinal_mode="stopping" if int(z["lon_mode"]) else "velocity_keeping", t_min=float(z["t_min"])),
+        debug=dict(draw_traj_set=bool(int(z.get("draw", 0))), show_plots=bool(int(z.get("draw", 0))))))
     cls = planner_cls or ReactivePlanner
     rp = cls(cfg, backend_factory=backend_factory)
     rp.set_reference_path(coordinate_system=CoordinateSystem(z["ref_path"], float(z["proj_d_limit"])))
@@ -140,3 +144,25 @@ def compare_plan_result(res, rp, z, atol):
     np.testing.assert_allclose(v, z["cvln"], rtol=0, atol=atol)
     np.testing.assert_allclose(np.array(lon_list, dtype=float), z["lon_list"], rtol=0, atol=atol)
     np.testing.assert_allclose(np.array(lat_list, dtype=float), z["lat_list"], rtol=0, atol=atol)
+
+
+LOOP_REASONS = ("velocity", "acceleration", "kappa", "kappa_dot", "yaw_rate")
+
+
+def record_plan_stats(planner):
+    """Wraps ``planner.plan`` (instance attribute; the reference's class or this build's) so that every call leaves a row
+    [planned, low-velocity mode, infeasible_count_kinematics, infeasible_count_collision, the five reason counters, number of stored
+    trajectories] in the returned list -- read right behind ``plan()``: the driver loop's ``reset()`` clears the counters
+    (reactive_planner.py:186), so a callback behind it sees zeros."""
+    rows = []
+    inner = planner.plan
+
+    def plan(*a, **k):
+        res = inner(*a, **k)
+        rd = planner._infeasible_reason_dict
+        rows.append([int(res is not None), int(planner._low_vel_mode), int(planner._infeasible_count_kinematics),
+                     int(planner._infeasible_count_collision)] + [int(rd.get(q, 0)) for q in LOOP_REASONS] +
+                    [len(planner.stored_trajectories or [])])
+        return res
+    planner.plan = plan
+    return rows

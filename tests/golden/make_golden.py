@@ -100,7 +100,8 @@ def make_planner(case):
                  save_plots=False),
         vehicle=rp.vehicle_params, scenario=None, planning_problem=None)
     rp.config = cfg
-    rp._co = CoordinateSystem(case["ref_path"], proj_domain_d_limit=case.get("proj_d_limit", 20.0))
+    # (BASELINE workloads hand over the coordinate system they were built on: make_baseline_golden.py)
+    rp._co = case.get("coordinate_system") or CoordinateSystem(case["ref_path"], proj_domain_d_limit=case.get("proj_d_limit", 20.0))
     tables = case.get("obstacles")
     if case.get("via_scenario"):
         # the reference's own set_collision_checker(scenario=...) (reactive_planner.py:218-251) on a duck-typed
@@ -689,11 +690,14 @@ def run_loop_case(case):
     def on_step(k, planner, optimal):
         flags.append((int(planner._low_vel_mode), int(len(optimal[0].state_list) == planner.N),          # standstill trajectories hold N states
                       planner._infeasible_count_kinematics, planner._infeasible_count_collision))
+    from _golden import record_plan_stats
+    stats = record_plan_stats(rp)   # counters of every plan() call (reset() clears them before the loop's callback runs: the last
+                                    # two columns of `flags` are zeros)
     res = run_closed_loop(rp, max_steps=case["steps"], replanning_frequency=1, desired_velocity=ramp_schedule, on_step=on_step)
     trace = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration or 0.0, s.steering_angle or 0.0]
                       for s in res.states], dtype=float)
     return dict(inputs, completed=int(res.completed), n_replans=res.n_replans, trace=trace, flags=np.array(flags, dtype=np.int64),
-                hold_cycles=RAMP_HOLD_CYCLES, pull_away_speed=RAMP_SPEED, steps=case["steps"])
+                plan_stats=np.array(stats, dtype=np.int64), hold_cycles=RAMP_HOLD_CYCLES, pull_away_speed=RAMP_SPEED, steps=case["steps"])
 
 
 def main():

@@ -1,0 +1,135 @@
+"""BASELINE.json's own configurations against the REFERENCE ITSELF (fixtures ``tests/golden/cfg{1,2,3,4}_ref*.npz``, produced by
+``tests/golden/make_baseline_golden.py``: the reference's ``generate_trajectories_at_level -> _check_kinematics -> sort ->
+_check_collisions`` on the workloads of ``commonroad_rp_amd/workloads.py`` -- cfg1 at the reference's sampling levels 1-3, cfg2 and
+cfg3 at full size, cfg4 on every 8th time sample (65 024 candidates) -- with and without the road boundary, cfg1-cfg3 also with
+``draw_traj_set``).
+
+  * CPU (``-m "not gpu"``): the oracle is held to them;
+  * GPU (``-m gpu``): the HIP path, through the C ABI, is compared with them DIRECTLY, on every launch path.
+
+Compared per candidate: label, first-failure reason, cost (1e-9 relative); winner, ``infeasible_count_*``, the reason counters;
+the 14 state rows of a stratified subset (1e-6, BASELINE.json north_star).  Collision labels follow the reference's lazy walk
+(reactive_planner.py:1031-1062): what it found colliding is colliding, what it left FEASIBLE behind the winner may be either --
+and for a sample of 2 000 feasible candidates the fixture holds the reference's own verdict, which an eager plan must reproduce.
+"""
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _golden import GOLDEN_DIR, Golden
+from _paths import LAUNCH_PATHS, launch_path_env
+from commonroad_rp_amd._capi import FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, PlanInputs, copy_params
+
+STATE_ATOL = 1e-6
+COST_RTOL = 1e-9
+NAMES = sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "cfg*_ref*.npz")))
+               if re.match(r"cfg\d_ref", n))
+
+
+def test_every_baseline_configuration_has_a_reference_fixture():
+    have = set(NAMES)
+    for rb in ("", "_rb"):
+        for draw in ("", "_draw"):
+            for base in ("cfg1_ref_l1", "cfg1_ref_l2", "cfg1_ref_l3", "cfg2_ref", "cfg3_ref"):
+                assert base + rb + draw in have
+        assert "cfg4_ref" + rb in have
+    z = np.load(os.path.join(GOLDEN_DIR, "cfg3_ref.npz"))
+    assert len(z["label"]) == 62496 and int(z["N"]) == 60 and z["dyn_obb"].shape[0] == 50
+    z = np.load(os.path.join(GOLDEN_DIR, "cfg4_ref.npz"))
+    assert len(z["label"]) == 8 * 127 * 64 and int(z["N"]) == 100
+    assert [len(np.load(os.path.join(GOLDEN_DIR, f"cfg1_ref_l{k}.npz"))["label"]) for k in (1, 2, 3)] == [120, 630, 3060]
+
+
+def _with_flags(inp: PlanInputs, extra: int) -> PlanInputs:
+    p = copy_params(inp.params)
+    p.flags = p.flags | extra
+    return PlanInputs(p, inp.cost, inp.T, inp.traj_len, inp.L, inp.D)
+
+
+def check_against_reference(z, status, cost, out, eager: bool):
+    """status / cost / result of one plan over the whole grid of fixture ``z`` against what the reference produced."""
+    ref = z["label"].astype(np.uint32)
+    lab = status & 3
+    winner, wcost = int(z["winner"]), float(z["winner_cost"])
+    # kinematic verdicts and first-failure reasons: exact
+    kin = (ref == 0) | (ref == 2)
+    np.testing.assert_array_equal(lab[kin], ref[kin])
+    np.testing.assert_array_equal((lab == 0) | (lab == 2), kin)
+    np.testing.assert_array_equal((status >> 4) & 7, z["reason"])
+    # costs
+    has = ~np.isnan(z["cost"])
+    assert np.all(np.isnan(cost[~has]))
+    np.testing.assert_allclose(cost[has], z["cost"][has], rtol=COST_RTOL)
+    # winner and the counters the planner reports
+    assert out.best_index == winner
+    assert out.n_candidates == len(ref)
+    assert out.n_infeasible_kinematics == int(z["n_infeasible_kinematics"])
+    assert out.n_collision_before_best == int(z["n_infeasible_collision"])
+    np.testing.assert_array_equal(out.reason_counts[1:6], z["reason_counts"])
+    if winner >= 0:
+        np.testing.assert_allclose(out.best_cost, wcost, rtol=COST_RTOL)
+        k = list(z["state_index"]).index(winner)
+        np.testing.assert_allclose(out.best_states, z["states"][k], rtol=0, atol=STATE_ATOL)
+    # collision labels: the reference's lazy walk labels the colliding candidates that sort before the winner (all of them without one)
+    assert np.all(lab[ref == 3] == 3)
+    extra = np.flatnonzero((ref == 1) & (lab == 3))
+    if len(extra):
+        assert winner >= 0
+        assert np.all((z["cost"][extra] > wcost) | ((z["cost"][extra] == wcost) & (extra > winner)))
+    # ... and its verdict for the sample: exact after an eager plan; a cost-ordered plan labels at least what sorts before the winner
+    ci, cv = z["collide_index"], z["collide"].astype(bool)
+    if eager:
+        np.testing.assert_array_equal(lab[ci] == 3, cv)
+    else:
+        assert not np.any((lab[ci] == 3) & ~cv)
+        before = (z["cost"][ci] < wcost) | ((z["cost"][ci] == wcost) & (ci < winner)) if winner >= 0 else np.ones(len(ci), dtype=bool)
+        np.testing.assert_array_equal((lab[ci] == 3)[before], cv[before])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_on_baseline_configs(name):
+    from oracle import oracle
+    g = Golden(name)
+    z = g.z
+    tb = g.oracle_tables()
+    run = oracle.plan(g.inputs, tb, want_states=False, nthreads=8)
+    check_against_reference(z, run.status, run.cost, run.out, eager=True)
+    for k, i in enumerate(z["state_index"]):
+        one = oracle.plan(g.inputs, tb, int(i), int(i) + 1, want_states=True)
+        np.testing.assert_allclose(one.states[0], z["states"][k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(one.coeffs[0, 0:6][:z["lon_coeffs"].shape[1]], z["lon_coeffs"][k], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(one.coeffs[0, 6:12], z["lat_coeffs"][k], rtol=1e-9, atol=1e-12)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=list(LAUNCH_PATHS))
+def ctx(request):
+    from commonroad_rp_amd._capi import RpContext
+    with launch_path_env(request.param):
+        c = RpContext(0)
+        yield c
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_matches_reference_on_baseline_configs(ctx, name):
+    g = Golden(name)
+    z = g.z
+    g.setup_context(ctx)
+    out = ctx.plan(g.inputs)
+    status, cost = ctx.fetch_status()
+    check_against_reference(z, status, cost, out, eager=ctx.last_path() != 1)
+    # state rows of the stratified subset, from a plan that keeps every candidate's rows
+    inp = _with_flags(g.inputs, FLAG_MATERIALIZE_ALL)
+    out2 = ctx.plan(inp)
+    assert out2.best_index == int(z["winner"])
+    for k, i in enumerate(z["state_index"]):
+        np.testing.assert_allclose(ctx.fetch_states(int(i), 1)[0], z["states"][k], rtol=0, atol=STATE_ATOL)
+    for i in z["state_index"][:2]:   # single-candidate re-evaluation agrees with the batch
+        blk = ctx.fetch_states(int(i), 1)[0]
+        st, s1, c1 = ctx.eval_one(int(i))
+        np.testing.assert_array_equal(st, blk)

@@ -174,3 +174,100 @@ def test_next_level_starts_while_the_current_one_is_on_the_device():
     for got in (first, second):
         assert got == want
     rp.close()
+
+
+def test_level_started_ahead_is_collected_before_the_context_is_used_again():
+    """level L fails, L + 1 (second context) succeeds, L + 2 has been started ahead on the primary context and stays in
+    flight.  The next cycle may take the general loop (standstill: ``x_0.velocity <= 0.05``), a new reference path or new obstacle
+    tables may arrive in between -- ``rp_plan_begin`` / ``rp_set_reference`` / ``rp_set_obstacles`` refuse a context with a plan in
+    flight (RP_ESTATE).  The planner collects the leftover before it asks the context for anything else."""
+    from _oracle_ctx import OracleContext
+    from commonroad_rp_amd.collision import ObstacleTables
+
+    class Strict(OracleContext):
+        """refuses what librp_amd.so refuses while a plan is in flight; reports no winner for the smallest level"""
+        def _free(self, what):
+            if getattr(self, "_pending", None) is not None:
+                raise RuntimeError(f"{what}: a plan is already in flight on this context (RP_ESTATE)")
+
+        def plan_begin(self, inp, *a, **k):
+            self._free("rp_plan_begin")
+            return super().plan_begin(inp, *a, **k)
+
+        def plan(self, inp, *a, **k):
+            if not getattr(self, "_in_wait", False):
+                self._free("rp_plan")
+            out = super().plan(inp, *a, **k)
+            if inp.n_candidates <= 120:
+                out.best_index, out.best_states = -1, None
+            return out
+
+        def plan_wait(self):
+            self._in_wait = True
+            try:
+                return super().plan_wait()
+            finally:
+                self._in_wait = False
+
+        plan_packed = None   # (the begin / wait path: what a planner with an on_device_launched hook or levels ahead takes)
+
+        def set_reference(self, *a, **k):
+            self._free("rp_set_reference")
+            return super().set_reference(*a, **k)
+
+        def set_obstacles(self, *a, **k):
+            self._free("rp_set_obstacles")
+            return super().set_obstacles(*a, **k)
+
+    rp, z = build_planner_from_plan_golden("plan_arc_hv_obs", Strict)
+    assert rp._fast_path_ok()
+    assert rp.plan() is not None and rp._levels_ahead                      # level 1 "fails", level 2 delivers
+    assert rp.plan() is not None                                           # levels 1 + 2 together, 3 started ahead and not needed
+    assert rp.__dict__.get("_rp_inflight") is not None
+    # (a) new obstacle tables before the next cycle
+    rp.set_collision_checker(collision_checker=ObstacleTables(static_obb=z["static_obb"], static_tri=z["static_tri"],
+                                                              static_circ=z["static_circ"], dyn_obb=z["dyn_obb"], dyn_t0=int(z["dyn_t0"])))
+    assert rp.plan() is not None
+    assert rp.__dict__.get("_rp_inflight") is not None
+    # (b) a standstill cycle: the general loop calls ctx.plan() on the primary context
+    x0 = rp.x_0
+    x0.velocity = 0.0
+    rp.reset(initial_state_cart=x0, initial_state_curv=([rp.x_0_cl[0][0], 0.0, 0.0], list(rp.x_0_cl[1])),
+             collision_checker=rp.collision_checker, coordinate_system=rp.coordinate_system)
+    assert not rp._fast_path_ok()
+    rp.plan()
+    assert rp.__dict__.get("_rp_inflight") is None
+    rp.close()
+
+
+def test_closed_planner_plans_again_with_fresh_arena_buffers():
+    """the sampling space caches NumPy views of the context's pinned arena (rp_coeffs_arena).  ``close()`` destroys the
+    context and with it the arena: the views go with it, and a planner that plans again hands out the NEW context's arrays."""
+    from _oracle_ctx import OracleContext
+
+    class Arena(OracleContext):
+        n_made = 0
+
+        def __init__(self, device=0):
+            super().__init__(device)
+            Arena.n_made += 1
+            self.tag = Arena.n_made
+
+        def coeffs_arena(self, cap):
+            return (np.empty((cap, 6)), np.empty((cap, 6)), np.empty(cap, dtype=np.int32))
+
+    rp, _ = build_planner_from_plan_golden("plan_arc_hv_obs", Arena)
+
+    class Space:   # a batch-view sampling space: what _create_trajectory_bundle asks for the arena on behalf of
+        def coeffs_at_level(self, *a):
+            return (np.zeros((0, 6)), np.zeros((0, 6)), np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0))
+    rp.sampling_space = Space()
+    rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], 1)
+    first = rp.sampling_space.__dict__["_arena_owner"]
+    assert first is rp._rp_ctx and rp.sampling_space.__dict__["_native_buffers"]["alloc"].__self__ is first
+    rp.close()
+    assert "_arena_owner" not in rp.sampling_space.__dict__ and "_native_buffers" not in rp.sampling_space.__dict__
+    rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], 1)
+    second = rp.sampling_space.__dict__["_arena_owner"]
+    assert second is rp._rp_ctx and second is not first and rp.sampling_space.__dict__["_native_buffers"]["alloc"].__self__ is second
+    rp.close()

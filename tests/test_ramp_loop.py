@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from _golden import GOLDEN_DIR, build_planner_from_plan_golden
+from _golden import GOLDEN_DIR, build_planner_from_plan_golden, record_plan_stats
 from commonroad_rp_amd.harness import run_closed_loop
 
 
@@ -21,6 +21,7 @@ def _run(backend):
     finally:
         os.remove(os.path.join(GOLDEN_DIR, "_tmp_loop_plan.npz"))
     flags = []
+    stats = record_plan_stats(rp)
 
     def on_step(k, planner, optimal):
         flags.append((int(planner._low_vel_mode), int(len(optimal[0].state_list) == planner.N),
@@ -31,13 +32,16 @@ def _run(backend):
                       for s in res.states], dtype=float)
     if hasattr(rp, "close"):
         rp.close()
-    return z, res, trace, np.array(flags, dtype=np.int64)
+    return z, res, trace, np.array(flags, dtype=np.int64), np.array(stats, dtype=np.int64)
 
 
-def _check(z, res, trace, flags, atol):
+def _check(z, res, trace, flags, stats, atol):
     assert res.completed and res.n_replans == int(z["n_replans"]) == 45
     np.testing.assert_array_equal(flags[:, :2], z["flags"][:, :2])          # which cycles ran in low-velocity mode / ended at standstill
-    np.testing.assert_array_equal(flags[:, 2:], z["flags"][:, 2:])          # rejected candidates (kinematics, collisions) per cycle
+    # counters of every plan() call -- planned, low-velocity mode, rejected candidates (kinematics, collisions), the five reasons --
+    # read right behind plan(): the loop's reset() clears them (reactive_planner.py:186), behind it they are zeros
+    np.testing.assert_array_equal(stats, z["plan_stats"])
+    assert stats[:, 2].min() > 0
     assert flags[:, 1].sum() == 3 and 0 < flags[:, 0].sum() < len(flags)    # standstill, low-velocity and time-based cycles all occur
     np.testing.assert_allclose(trace, z["trace"], rtol=0, atol=atol)
     assert trace[-1, 4] > 7.0                                               # it did pull away

@@ -1,0 +1,55 @@
+"""The scenarios BASELINE.json's configurations name -- ZAM_Over-1_1, ZAM_Tjunction-1_42_T-1, DEU_Test-1_1_T-1 -- in closed loop
+(the driver loop of the reference, run_planner.py:61-107: plan, adopt state 1 + temp of the optimal trajectory, reset) with the
+settings of the shipped YAML files (configurations/*.yaml: N = 20, t_min, low_vel_mode_threshold; DEU_Test with draw_traj_set),
+the scenario's own obstacles and the road boundary.  30+ replanning cycles each; the fixtures ``tests/golden/loop_*.npz`` hold
+the state sequence and the counters of every ``plan()`` call as the REFERENCE planner produced them
+(tests/golden/make_baseline_golden.py::run_scenario_loop).  ZAM-Ramp: tests/test_ramp_loop.py."""
+import os
+
+import numpy as np
+import pytest
+
+from _golden import GOLDEN_DIR, build_planner_from_plan_golden, record_plan_stats
+from commonroad_rp_amd.harness import run_closed_loop
+
+LOOPS = ["loop_zam_over", "loop_zam_tjunction", "loop_deu_test"]
+
+
+def _run(name, backend, overlap=False):
+    z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    tmp = f"_tmp_{name}_{os.getpid()}"
+    np.savez(os.path.join(GOLDEN_DIR, tmp + ".npz"), **dict(z, continuous=0, via_scenario=0, planned=1))
+    try:
+        rp, _ = build_planner_from_plan_golden(tmp, backend)
+    finally:
+        os.remove(os.path.join(GOLDEN_DIR, tmp + ".npz"))
+    stats = record_plan_stats(rp)
+    res = run_closed_loop(rp, max_steps=int(z["steps"]), replanning_frequency=int(z["replanning_frequency"]),
+                          on_step=(lambda k, planner, optimal: None) if overlap else None, overlap=overlap)
+    trace = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration or 0.0, s.steering_angle or 0.0]
+                      for s in res.states], dtype=float)
+    if hasattr(rp, "close"):
+        rp.close()
+    return z, res, trace, np.array(stats, dtype=np.int64)
+
+
+def _check(z, res, trace, stats, atol):
+    assert res.completed and res.n_replans == int(z["n_replans"]) >= 30
+    assert len(trace) == int(z["steps"]) + 1
+    np.testing.assert_array_equal(stats, z["plan_stats"])     # per plan(): planned, mode, rejected (kinematics, collisions), reasons, stored
+    assert stats[:, 2].min() > 0
+    np.testing.assert_allclose(trace, z["trace"], rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("name", LOOPS)
+def test_scenario_closed_loop_cpu_glue(name):
+    from _oracle_ctx import OracleContext
+    _check(*_run(name, OracleContext), atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", LOOPS)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_scenario_closed_loop_gpu(name, overlap):
+    from commonroad_rp_amd._capi import RpContext
+    _check(*_run(name, RpContext, overlap=overlap), atol=1e-6)
