@@ -217,6 +217,16 @@ def test_select_after_plan_without_states(ctx, name):
     user = np.where((lab == 1) | (lab == 3), 10.0 + np.arange(len(lab)) * 1e-3, np.nan)
     pick = int(feas[len(feas) // 2])
     user[pick] = 1.0
+    if ctx.last_path() == 1:
+        # the plan answered the collision query in cost order: candidates behind its winner were never looked at, a selection with
+        # other costs could crown a colliding one -- refused; plans for plug-in costs materialise and run eager
+        with pytest.raises(_capi.RpError, match="cost order"):
+            ctx.select(user)
+        ctx.plan(_with_flags(g.inputs, FLAG_MATERIALIZE_ALL))
+        assert ctx.last_path() == 0
+        out = ctx.select(user)
+        assert out.best_index == pick and out.best_cost == 1.0
+        return
     out = ctx.select(user)
     assert out.best_index == pick and out.best_cost == 1.0
     assert out.n_collision_before_best == 0
