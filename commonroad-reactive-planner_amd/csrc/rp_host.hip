@@ -144,6 +144,7 @@ struct rp_ctx {
     std::chrono::steady_clock::time_point t_entry;
     bool last_rows_on_device = false;   // d_result holds the winner's state rows of the last plan (finalize copied them)
     int last_G = 0;              // lanes per candidate of the last plan
+    int last_block = 0;          // threads per workgroup of its evaluation kernel
     size_t last_fused_lds = 0;   // LDS bytes of the single-launch variant if the last plan used it (else 0)
     KArgs last{};
     KArgsG kargs_g{};            // launch block of the evaluation kernels: KArgs + the grids of the last rp_plan (if they fit)
@@ -265,7 +266,14 @@ int collision_level(const KArgs &ka) {
 }
 
 template <int G, bool MAT, bool CIN, int COLL, bool STAGE>
-void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds) {
+void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int block = RP_BLOCK) {
+    if constexpr (G == 16 && !STAGE) {   // one wavefront per workgroup (large batches of the two-kernel path: eval_block)
+        if (block == 64) {
+            if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, false, false, 64>, grid, 64, lds, ka);
+            else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, false, false, 64>, grid, 64, lds, ka);
+            return;
+        }
+    }
     if (ka.N + 1 <= G) launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, true, STAGE, false>, grid, RP_BLOCK, lds, ka);
     else launch_kargs(c, (const void *)rp_eval_kernel<G, MAT, CIN, COLL, false, STAGE, false>, grid, RP_BLOCK, lds, ka);
 }
@@ -353,19 +361,19 @@ inline int state_layout(int n, int G, bool fused, bool staged, int *ns) {
 }
 
 template <int G, bool MAT, bool CIN, int COLL>
-void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid) {
+void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid, int block) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
     const bool stage = stage_out_applies(ka, G, MAT);
     if (MAT && stage) launch_eval_tcs<G, MAT, CIN, COLL, true>(c, ka, grid, tile);
-    else launch_eval_tcs<G, MAT, CIN, COLL, false>(c, ka, grid, 0);
+    else launch_eval_tcs<G, MAT, CIN, COLL, false>(c, ka, grid, 0, block);
 }
 
 template <int G, bool MAT, bool CIN>
-void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid) {
+void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid, int block) {
     const int coll = collision_level(ka);
-    if (coll == 2) launch_eval_tc<G, MAT, CIN, 2>(c, ka, grid);
-    else if (coll == 1) launch_eval_tc<G, MAT, CIN, 1>(c, ka, grid);
-    else launch_eval_tc<G, MAT, CIN, 0>(c, ka, grid);
+    if (coll == 2) launch_eval_tc<G, MAT, CIN, 2>(c, ka, grid, block);
+    else if (coll == 1) launch_eval_tc<G, MAT, CIN, 1>(c, ka, grid, block);
+    else launch_eval_tc<G, MAT, CIN, 0>(c, ka, grid, block);
 }
 
 // Lanes per candidate.  The time axis is cut into step blocks of G lanes; fewer lanes per candidate
@@ -402,15 +410,31 @@ int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
 }
 
 template <int G>
-void launch_eval_g(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin) {
-    if (mat) { if (cin) launch_eval_t<G, true, true>(c, ka, grid); else launch_eval_t<G, true, false>(c, ka, grid); }
-    else     { if (cin) launch_eval_t<G, false, true>(c, ka, grid); else launch_eval_t<G, false, false>(c, ka, grid); }
+void launch_eval_g(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int block) {
+    if (mat) { if (cin) launch_eval_t<G, true, true>(c, ka, grid, block); else launch_eval_t<G, true, false>(c, ka, grid, block); }
+    else     { if (cin) launch_eval_t<G, false, true>(c, ka, grid, block); else launch_eval_t<G, false, false>(c, ka, grid, block); }
 }
 
-void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int G) {
-    if (G == 16) launch_eval_g<16>(c, ka, grid, mat, cin);
-    else if (G == 32) launch_eval_g<32>(c, ka, grid, mat, cin);
-    else launch_eval_g<64>(c, ka, grid, mat, cin);
+// block: threads per workgroup of the batch's launch (eval_block); every other launch -- one candidate, a round's list -- takes RP_BLOCK
+void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int G, int block = RP_BLOCK) {
+    if (G == 16) launch_eval_g<16>(c, ka, grid, mat, cin, block);
+    else if (G == 32) launch_eval_g<32>(c, ka, grid, mat, cin, RP_BLOCK);
+    else launch_eval_g<64>(c, ka, grid, mat, cin, RP_BLOCK);
+}
+
+// Threads per workgroup of the evaluation kernel of a batch (two-kernel path).  A workgroup's slot on the CU is freed when its LAST
+// wavefront is done, and the four wavefronts of a 256-thread workgroup finish apart (in-kernel stamps on cfg3: first wavefront
+// 30 k cycles, workgroup 42 k): one wavefront per workgroup frees a slot as soon as ITS wavefront is done.  Measured (A/B on one
+// box, profiles/r04_block_ab.txt), kernel time 256 -> 64 threads: costs-only plans cfg4 414 -> 378 us, cfg5 1 027 -> 934 us,
+// cfg3 89.8 -> 88 us; plans that write state rows cfg3 102.7 -> 100.8, cfg4 1 080 -> 1 086, cfg5 2 120 -> 2 145, cfg3f 137 -> 142
+// (the row stores of four wavefronts that march together fill whole DRAM pages).  Four times the block partials: a batch whose
+// 256-thread grid would stay under the fold threshold pays a fold kernel for them (cfg3: +5 us for -2).  So: one wavefront per
+// workgroup for costs-only plans of batches that fold anyway.  RP_AMD_EVAL_BLOCK=64|256 pins the choice.
+int eval_block(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool mat) {
+    (void)c;
+    if (G != 16 || stage_out_applies(ka, G, mat) || ka.single_index || ka.index_list) return RP_BLOCK;
+    if (const char *e = std::getenv("RP_AMD_EVAL_BLOCK")) { const int b = std::atoi(e); if (b == 64 || b == RP_BLOCK) return b; }
+    return (!mat && count > (int64_t)kFoldThreshold * (RP_BLOCK / 16)) ? 64 : RP_BLOCK;
 }
 
 template <int G, bool CIN>
@@ -433,8 +457,8 @@ void launch_lon(rp_ctx *c, const KArgs &ka, bool cin) {
     else         { if (cin) launch_lon_t<64, true>(c, ka, grid); else launch_lon_t<64, false>(c, ka, grid); }
 }
 
-int eval_grid(const rp_ctx *c, int64_t count, int G) {
-    const int gpb = RP_BLOCK / G;
+int eval_grid(const rp_ctx *c, int64_t count, int G, int block = RP_BLOCK) {
+    const int gpb = block / G;
     int64_t blocks = (count + gpb - 1) / gpb;
     (void)c;
     return (int)std::max<int64_t>(1, blocks);   // the grid covers the batch: one candidate per lane group
@@ -713,7 +737,9 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         c->last_fused_lds = fused_lds; c->last_G = G;
         ka.tail_split = state_layout(n, G, fused_lds != 0, !fused_lds && stage_out_applies(ka, G, mat), &ka.row_stride);   // (rp_select keeps the plan's)
     }
-    const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G);
+    int block = c->last_block ? c->last_block : RP_BLOCK;   // (rp_select: nothing of the batch is launched again)
+    if (!skip_eval) { block = fused_lds ? RP_BLOCK : eval_block(c, ka, count, G, mat); c->last_block = block; }
+    const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G, block);
     if (std::max(grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
@@ -787,7 +813,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);
-            else launch_eval(c, k, grid, mat_, cin, G);
+            else launch_eval(c, k, grid, mat_, cin, G, block);
             if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
             c->time_next_launch = false;
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));

@@ -1590,8 +1590,12 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
 // gridDim.x * GPB >= count): the workgroup first computes the longitudinal profiles of the (at most
 // a.lds_pairs) pairs its own candidates belong to into LDS -- the work of rp_lon_kernel without the
 // launch, the global round trip of the profile rows and the kernel boundary.
-template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED>
-__global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgsG ag) {
+// BLOCK: threads per workgroup.  256 (four wavefronts) wherever the workgroup shares something -- the single-launch variant's
+// tables and profile rows, the LDS tile of the staged copy-out; the plain two-kernel variants of LARGE batches run one wavefront
+// per workgroup (BLOCK = 64): a workgroup is placed, and its slot freed, as a whole, and the four wavefronts of a 256-thread
+// workgroup finish far apart (in-kernel stamps on cfg3: the first at 30 k cycles, the workgroup at 42 k).
+template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED, int BLOCK = RP_BLOCK>
+__global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgsG ag) {
     const KArgs &a = ag.k;
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
@@ -1605,7 +1609,8 @@ __global__ __launch_bounds__(RP_BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(co
     const int lane = tid & 63;
     const int gl = lane & (G - 1);        // lane inside the group = time step inside the chunk
     const int gbase = lane & ~(G - 1);    // first lane of the group inside the wave
-    constexpr int GPB = RP_BLOCK / G;     // groups per block
+    static_assert(BLOCK == RP_BLOCK || (!LON_FUSED && !STAGE_OUT), "smaller workgroups: plain two-kernel variants only");
+    constexpr int GPB = BLOCK / G;        // groups per block
     constexpr int GPW = 64 / G;           // groups per wave
     constexpr int PFN = COLL ? PF_FIELDS : PF_COS_REF;   // profile rows this variant reads
     const int wave_in_block = tid >> 6;

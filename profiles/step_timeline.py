@@ -11,7 +11,7 @@ for name, s, e, g in ev:
         cur = {"lon": (s, e)}
     elif cur is not None and name == "rp_eval_kernel" and "eval" not in cur:
         cur["eval"] = (s, e)
-    elif cur is not None and name == "rp_finalize_kernel":
+    elif cur is not None and name in ("rp_finalize_kernel", "rp_select_kernel"):
         cur["fin"] = (s, e); steps.append(cur); cur = None
 steps = steps[len(steps) // 4:]   # drop warm-up
 def us(a): return np.median(a) / 1e3
