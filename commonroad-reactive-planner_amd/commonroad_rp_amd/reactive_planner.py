@@ -213,6 +213,8 @@ class GpuBackendMixin:
     shard_device = None
     shard_transport = "auto"
     shard_min_candidates = SHARD_MIN_CANDIDATES
+    shard_single_rank = False   # True: a group of ONE rank still takes the sharded path (the whole exchange with itself: tests of the
+                                # RCCL transport on a one-GPU box)
     #: called once per ``plan()`` of the stand-alone planner, between the launch of the cycle's kernels and the wait for their
     #: result (``rp_plan_begin`` / ``rp_plan_wait``): the caller's own work overlaps the device (harness.run_closed_loop)
     on_device_launched = None
@@ -242,6 +244,8 @@ class GpuBackendMixin:
         if dist is None or not grid_plan or external or self._draw_traj_set:
             return 1
         world = dist.get_world_size()
+        if world == 1 and self.shard_single_rank and n_candidates >= self.shard_min_candidates:
+            return -1   # (a world of one, sharded all the same: see shard_single_rank)
         return world if (world > 1 and n_candidates >= self.shard_min_candidates) else 1
 
     # ---- context and tables -----------------------------------------------------------------------
@@ -457,7 +461,12 @@ class GpuBackendMixin:
                 self._infeasible_count_kinematics = 0
                 return None
             world = self._shard_world(C, True, external)
-            if world > 1:   # this rank's contiguous range of the reference list index, then the winner exchange
+            if world == -1:
+                world = 1
+                force_exchange = True
+            else:
+                force_exchange = False
+            if world > 1 or force_exchange:   # this rank's contiguous range of the reference list index, then the winner exchange
                 from .distributed import exchange_winner, shard_range
                 lo, hi = shard_range(C, self.shard_dist.get_rank(), world)
                 out = ctx.plan(PlanInputs(params, cost, T, traj_len, L, D), lo, hi)
