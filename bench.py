@@ -349,6 +349,10 @@ def run_single(args, torch, device):
         if not args.no_configs:
             result["configs"] = side_configs(args, torch, device, skip=base.name)
         result["plan_latency_ms"] = plan_latency(base, device)
+        try:
+            result["level_loop_latency_ms"] = level_loop_latency(device)
+        except Exception as e:   # (a record beside the headline: never the reason for a missing line)
+            result["level_loop_latency_ms"] = {"error": repr(e)}
         result["corridor_sampling"] = corridor_sampling_cost(base, device)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(base, with_mode(seq, args.mode)[0], args.cpu_seconds)
@@ -414,6 +418,58 @@ def plan_latency(base, device, n_replans=220, warm=20):
     return {"p50": float(np.percentile(lat, 50)), "p90": float(np.percentile(lat, 90)), "p99": float(np.percentile(lat, 99)),
             "n": int(len(lat)), "loops": loops, "what": "ReactivePlanner.plan() wall time per closed-loop replan (every time step a new "
             "state, velocity grid and time index), one sampling level of the workload's grid, production mode, Python included"}
+
+
+def level_loop_latency(device, n_replans=220, warm=20):
+    """``ReactivePlanner.plan()`` on BASELINE.json configs[0] as the reference drives it (run_planner.py:28-107): ZAM_Over-1_1 with the
+    reference's OWN sampling levels (120 / 630 / 3 060 candidates, N = 20, t_min 0.2), its static obstacle and the road boundary, in
+    closed loop.  plan() hands the grids of all three levels to the device in one call (rp_plan_levels: one round trip whatever
+    level delivers).  Second record: the same scene behind a wall -- no level has a winner, every cycle visits all three."""
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext
+    from commonroad_rp_amd.collision import ObstacleTables
+    from commonroad_rp_amd.harness import run_closed_loop
+    w = W.cfg1(level=1, road_boundary=True)
+    ctx = RpContext(device)
+
+    class Shared:
+        def __new__(cls, dev):
+            return ctx
+    out = {}
+    wall = ObstacleTables(static_circ=[[float(w.coordinate_system.reference[70][0]), float(w.coordinate_system.reference[70][1]), 60.0]])
+    w2 = W.Workload(w.name, w.description, w.inputs, w.coordinate_system, wall)
+    for policy in ("adaptive", "chain", "sequential"):   # ReactivePlanner.level_policy (adaptive: the default)
+        rec = {}
+        lat, loops, levels = [], 0, []
+        while len(lat) < n_replans + warm and loops < 40:
+            rp = W.make_level_planner(w, t_min=0.2, backend_factory=Shared, device=device)
+            rp.level_policy = policy
+            res = run_closed_loop(rp, max_steps=60, replanning_frequency=1)
+            lat += res.plan_times if res.completed else res.plan_times[:-1]
+            loops += 1
+        a = np.asarray(lat[warm:]) * 1e3
+        if len(a):
+            rec["closed_loop"] = {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "p99": float(np.percentile(a, 99)),
+                                  "n": int(len(a)), "loops": loops}
+        # every level fails: a wall across the road -- three levels per cycle
+        rp = W.make_level_planner(w2, t_min=0.2, backend_factory=Shared, device=device)
+        rp.level_policy = policy
+        t = []
+        for _ in range(warm + 100):
+            t0 = time.perf_counter()
+            r = rp.plan()
+            t.append(time.perf_counter() - t0)
+            assert r is None
+        a = np.asarray(t[warm:]) * 1e3
+        rec["all_levels_fail"] = {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "n": int(len(a)),
+                                  "first_cycle": float(t[0] * 1e3), "candidates": [120, 630, 3060]}
+        out[policy] = rec
+    ctx.close()
+    out["what"] = ("ReactivePlanner.plan() wall time, ZAM_Over-1_1 with the reference's sampling levels 1-3 (120 / 630 / 3 060 candidates, "
+                   "N = 20) + road boundary, production mode, Python included, per ReactivePlanner.level_policy: chain = all levels in one "
+                   "rp_plan_levels call every cycle, adaptive (default) = the first level alone, the remaining ones in one call when it fails "
+                   "and whole cycles for a while after that, sequential = one call per level; all_levels_fail: a wall across the road")
+    return out
 
 
 def corridor_sampling_cost(base, device, reps=15):

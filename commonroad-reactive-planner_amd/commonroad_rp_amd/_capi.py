@@ -221,6 +221,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                               C.POINTER(RpResult), dp]),
         "rp_plan_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64, C.c_int32]),
         "rp_plan_wait": (C.c_int, [ctx, C.POINTER(RpResult), dp]),
+        "rp_plan_levels": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.POINTER(RpResult), dp, ip]),
+        "rp_plan_levels_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.c_int32]),
+        "rp_plan_levels_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, ip, C.POINTER(RpResult), C.c_void_p, ip]),
+        "rp_last_level": (C.c_int, [ctx]),
         "rp_pack_trajectory": (C.c_int, [C.c_int32, dp, C.c_double, C.c_double, C.c_double, dp]),
         "rp_fast_buffer": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "rp_plan_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.c_int32, C.c_int32, C.POINTER(RpResult), C.c_void_p]),
@@ -270,11 +274,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+_OPTIONAL_IN_AB_BUILDS = ("rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
                           "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
                           "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path", "rp_set_collision_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -544,6 +548,63 @@ class RpContext:
         if res.best_index < 0:
             return res, None, None
         return res, out[:N_ARRAYS * n].reshape(N_ARRAYS, n), out[N_ARRAYS * n:].reshape(n, 13)
+
+    def plan_levels_packed(self, params: RpParams, cost: RpCost, levels):
+        """``rp_plan_levels_packed``: the level loop of ``plan()`` (reactive_planner.py:616-636) in one call and one device round
+        trip.  ``levels``: [(T, traj_len, L, D), ...] in the order the loop would visit them -> (result struct, index of the level
+        the result belongs to, state block [14, N + 1], packed output [N + 1, 13]); the last two ``None`` without a winner."""
+        fb = getattr(self, "_fast", None)
+        if fb is None:
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
+            raw = (C.c_char * nbytes.value).from_address(ptr.value)
+            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan_packed)
+        f64v, i32v = fb[0], fb[1]
+        nlev = len(levels)
+        dims = getattr(self, "_lvl_dims", None)
+        if dims is None or len(dims) < 3 * nlev:
+            dims = self._lvl_dims = (C.c_int32 * (3 * max(nlev, 8)))()
+            self._lvl_out = C.c_int32(0)
+        at = 0
+        for k, (T, traj_len, L, D) in enumerate(levels):
+            nT, nL, nD = len(T), len(L), len(D)
+            nd = nT + nL + nD
+            words = nd + (nT + 1) // 2
+            if (at + words) * 8 > f64v.nbytes:
+                raise RpError("plan_levels_packed: grids larger than the context's buffer")
+            f64v[at:at + nT] = T
+            f64v[at + nT:at + nT + nL] = L
+            f64v[at + nT + nL:at + nd] = D
+            i32v[2 * (at + nd):2 * (at + nd) + nT] = traj_len
+            dims[3 * k], dims[3 * k + 1], dims[3 * k + 2] = nT, nL, nD
+            at += words
+        self._fast_last = None   # (the buffer no longer holds what plan_packed left there)
+        n = params.N + 1
+        out = np.empty((N_ARRAYS + 13) * n)
+        res, lvl = self._res, self._lvl_out
+        rc = self._lib.rp_plan_levels_packed(self._h, params, cost, nlev, dims, res, out.ctypes.data, lvl)
+        if rc != 0:
+            self._check(rc, "rp_plan_levels_packed")
+        self._N = params.N
+        self._last_count = res.n_candidates
+        self._serial += 1
+        self._last_best = None
+        if res.best_index < 0:
+            return res, lvl.value, None, None
+        return res, lvl.value, out[:N_ARRAYS * n].reshape(N_ARRAYS, n), out[N_ARRAYS * n:].reshape(n, 13)
+
+    def plan_levels_begin(self, params: RpParams, cost: RpCost, levels, want_best_states: bool = True):
+        """First half of ``rp_plan_levels`` (collected by ``plan_wait``, which then also reports ``last_level()``)."""
+        nlev = len(levels)
+        inputs = [PlanInputs.trusted(params, cost, T, tl, L, D) for (T, tl, L, D) in levels]
+        arr = (RpGrids * nlev)(*[q.grids() for q in inputs])
+        rc = self._lib.rp_plan_levels_begin(self._h, C.byref(params), C.byref(cost), nlev, arr, 1 if want_best_states else 0)
+        if rc != 0:
+            self._check(rc, "rp_plan_levels_begin")
+        self._inflight = (inputs[0], want_best_states)
+
+    def last_level(self) -> int:
+        return int(self._lib.rp_last_level(self._h))
 
     def plan_begin(self, inp: PlanInputs, cand_begin: int = 0, cand_end: int = -1, want_best_states: bool = True):
         """First half of ``plan``: the kernels of the plan go onto the context's stream and the call returns; ``plan_wait``

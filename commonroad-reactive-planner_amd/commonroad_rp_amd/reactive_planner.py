@@ -218,7 +218,6 @@ class GpuBackendMixin:
     #: called once per ``plan()`` of the stand-alone planner, between the launch of the cycle's kernels and the wait for their
     #: result (``rp_plan_begin`` / ``rp_plan_wait``): the caller's own work overlaps the device (harness.run_closed_loop)
     on_device_launched = None
-    _levels_ahead = False
 
     def set_process_group(self, dist, device=None, transport: str = "auto", min_candidates: Optional[int] = None):
         """One planner per rank, the same inputs on every rank (the reference's only parallel backend also lives inside
@@ -249,17 +248,7 @@ class GpuBackendMixin:
         return world if (world > 1 and n_candidates >= self.shard_min_candidates) else 1
 
     # ---- context and tables -----------------------------------------------------------------------
-    def _collect_inflight(self):
-        """A sampling level started ahead in the last cycle and never needed (``_plan_fast``) is still in flight on its context:
-        collect it before that context is asked for anything else -- ``rp_plan_begin`` / ``rp_set_reference`` / ``rp_set_obstacles``
-        refuse a context with a plan in flight (RP_ESTATE)."""
-        ctx = self.__dict__.get("_rp_inflight")
-        if ctx is not None:
-            self._rp_inflight = None
-            ctx.plan_wait()
-
     def _gpu_ctx(self):
-        self._collect_inflight()
         ctx = getattr(self, "_rp_ctx", None)
         if ctx is None:
             ctx = self._rp_ctx = self.backend_factory(self.gpu_device)
@@ -278,22 +267,6 @@ class GpuBackendMixin:
                 tables = self._obstacle_tables = ObstacleTables()
             ctx.set_obstacles(tables)
             self._rp_obs_id = tables
-        return ctx
-
-    def _gpu_ctx2(self):
-        """A second context with the same tables: the next sampling level starts on it while the current one is still on the
-        device (``_plan_fast``).  Created when a cycle first needs it."""
-        ctx = getattr(self, "_rp_ctx2", None)
-        if ctx is None:
-            ctx = self._rp_ctx2 = self.backend_factory(self.gpu_device)
-            self._rp_ref_id2 = self._rp_obs_id2 = None
-        if self._rp_ref_id2 is not self._co:
-            ctx.set_coordinate_system(self._co)
-            self._rp_ref_id2 = self._co
-        tables = self._obstacle_tables
-        if self._rp_obs_id2 is not tables:
-            ctx.set_obstacles(tables)
-            self._rp_obs_id2 = tables
         return ctx
 
     def set_collision_checker(self, scenario=None, collision_checker=None, road_boundary_obstacle=None):
@@ -342,15 +315,10 @@ class GpuBackendMixin:
         self._rp_tables_checker = getattr(self, "_cc", None)   # (drop-in mode: these tables stand for the planner's checker)
 
     def close(self):
-        try:
-            self._collect_inflight()
-        except Exception:   # (a context that cannot deliver any more is destroyed all the same)
-            self._rp_inflight = None
-        for name in ("_rp_ctx", "_rp_ctx2"):
-            ctx = getattr(self, name, None)
-            if ctx is not None:
-                ctx.close()
-                setattr(self, name, None)
+        ctx = getattr(self, "_rp_ctx", None)
+        if ctx is not None:
+            ctx.close()
+            self._rp_ctx = None
         # a sampling space that wrote its candidates into pinned arrays of the context just destroyed (rp_coeffs_arena) must not
         # keep views of them: the next context hands out its own
         sp = getattr(self, "sampling_space", None)
@@ -797,9 +765,6 @@ class ReactivePlanner(GpuBackendMixin):
         assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
         x_0_lon, x_0_lat = self.x_0_cl
         self._low_vel_mode = bool(self.x_0.velocity < self.config.planning.low_vel_mode_threshold)
-        if self.__dict__.get("_rp_inflight") is not None:   # (whatever path this cycle takes: the context is free first)
-            self._collect_inflight()
-
         optimal, bundle = None, None
         i = 1 if current_sampling_level is None else current_sampling_level
         if self._fast_path_ok():
@@ -845,97 +810,84 @@ class ReactivePlanner(GpuBackendMixin):
                 and self.x_0.velocity > 0.05 and not self.config.planning.continuous_collision_check
                 and "_compute_trajectory_pair" not in d and "_get_optimal_trajectory" not in d and "_create_trajectory_bundle" not in d)
 
+    #: How ``plan()`` hands the sampling levels of a cycle to the device (reactive_planner.py:616-636 visits them one by one):
+    #:   "chain"      every level the loop could visit in ONE call (``rp_plan_levels``: the kernels of all levels back to back on the
+    #:                stream, the epilogue of a level that finds a winner stops the levels behind it) -- one device round trip whatever
+    #:                level delivers, at the price of launching the later levels every cycle (ZAM_Over, levels 1-3: p50 54 us against
+    #:                47 us for the first level alone; a cycle in which all three fail: 89 us instead of three round trips);
+    #:   "adaptive"   (default) the first level alone -- in the reference's shipped scenarios it always delivers -- and, when it has
+    #:                no winner, the REMAINING levels in one call; after such a cycle the next ``LEVEL_CHAIN_CYCLES`` cycles are
+    #:                handed over whole (a scene that needed a finer level tends to need it again);
+    #:   "sequential" one call per level.
+    level_policy = "adaptive"
+    LEVEL_CHAIN_CYCLES = 16
+
     def _plan_fast(self, x_0_lon, x_0_lat, level: int, single_level: bool):
-        """The level loop of ``plan()`` (reactive_planner.py:616-636) on the arrays themselves: grids -> ``rp_plan`` ->
-        counters, then the output packing of :514-568 in one host call (``rp_pack_trajectory``).  Same results, same
-        counters as the general loop (tests/test_planner_mirror.py runs both)."""
+        """The level loop of ``plan()`` (reactive_planner.py:616-636) on the arrays themselves: grids -> ``rp_plan_levels`` (or
+        ``rp_plan_packed`` for one level) -> counters, the output packing of :514-568 done in the same call.  Which levels travel
+        together: ``level_policy``.  Same results, same counters as the general loop (tests/test_planner_mirror.py runs both)."""
         cost = self._gpu_cost()
         if cost is None:
             return NotImplemented
         ctx = self._gpu_ctx()
         sp, mode = self.sampling_space, self.config.sampling.longitudinal_mode
         params = self._gpu_params(x_0_lon, x_0_lat, 0)
-        rd = self._infeasible_reason_dict
         hook = self.on_device_launched
-        split = hasattr(ctx, "plan_begin")
-        # A level without a winner costs a whole round trip before the next one can start (reactive_planner.py:616-636).  When the
-        # last cycle needed a second level, this one puts level i + 1 on the device -- on a second context -- right behind level i
-        # and collects it only if level i fails: one round trip for both.
-        ahead = split and self._levels_ahead and not single_level
-        out, started, first = None, None, level   # started: (level, context, inputs) of the plan begun ahead
-        packed_call = getattr(ctx, "plan_packed", None) if (not ahead and hook is None) else None
-        blk = buf = None
-        while packed_call is not None and level < self.sampling_level:
-            # one call per level: grids through the context's own buffer, counters read off the C result, output packed in C
-            T, traj_len, L, D = sp.grids_at_level(level, x_0_lon, x_0_lat, mode)
-            self._reset_statistics()
-            if len(T) * len(L) * len(D):
-                res, blk, buf = packed_call(params, cost, T, traj_len, L, D)
-                self._infeasible_count_kinematics = res.n_candidates - res.n_feasible
-                self._infeasible_count_collision = res.n_collision_before_best
-                rc = res.reason_counts
-                for k, name in _REASON_ITEMS:
-                    if name in rd:
-                        rd[name] = int(rc[k])
-                if blk is not None:
-                    break
-            if single_level:
-                break
-            level += 1
-        if packed_call is not None:
-            if not single_level:
-                self._levels_ahead = level > first
-            if blk is None:
-                return None
-            return self._fast_output(blk, buf)
-        while level < self.sampling_level:
-            if started is not None and started[0] == level:
-                cur, inp = started[1], started[2]
-                started = None
-            else:
-                T, traj_len, L, D = sp.grids_at_level(level, x_0_lon, x_0_lat, mode)
-                cur, inp = ctx, (PlanInputs.trusted(params, cost, T, traj_len, L, D) if len(T) * len(L) * len(D) else None)
-                if inp is not None and (ahead or hook is not None) and split:
-                    cur.plan_begin(inp)
-                elif inp is not None:
-                    cur = None   # (one blocking call below)
-            if ahead and level + 1 < self.sampling_level and inp is not None:
-                other = self._gpu_ctx2() if cur is ctx else ctx
-                T, traj_len, L, D = sp.grids_at_level(level + 1, x_0_lon, x_0_lat, mode)
-                if len(T) * len(L) * len(D):
-                    nxt = PlanInputs.trusted(params, cost, T, traj_len, L, D)
-                    other.plan_begin(nxt)
-                    started = (level + 1, other, nxt)
-            self._reset_statistics()
-            if inp is None:
-                out = None
-            else:
-                if cur is None:
-                    out = ctx.plan(inp)
-                else:
-                    if hook is not None and level == first:
-                        hook()   # the device is busy with this cycle: the caller's own work (harness: the last cycle's bookkeeping)
-                    out = cur.plan_wait()
-                self._infeasible_count_kinematics = out.n_candidates - out.n_feasible
-                self._infeasible_count_collision = out.n_collision_before_best
-                rc = out.reason_counts
-                for k, name in _REASON_ITEMS:
-                    if name in rd:
-                        rd[name] = int(rc[k])
-                if out.best_index >= 0:
-                    break
-            if single_level:
-                break
-            level += 1
-        if started is not None:
-            self._rp_inflight = started[1]   # collected at the start of the next cycle (waiting for it here would cost this one)
-        if not single_level:
-            self._levels_ahead = level > first   # this cycle needed more than its first level: the next one starts two at once
-        if out is None or out.best_index < 0:
+        stop = min(level + 1, self.sampling_level) if single_level else self.sampling_level
+        self._reset_statistics()
+        if level >= stop:
             return None
-        # output packing: positions, lon / lat samples, shifted orientations, steering angles and yaw rates in one pass in C
-        blk = out.best_states
-        return self._fast_output(blk, _capi.pack_trajectory(blk, self.dt, self.vehicle_params.wheelbase, self.x_0.orientation))
+        policy = self.level_policy
+        chain_left = self.__dict__.get("_chain_cycles", 0)
+        whole = policy == "chain" or (policy == "adaptive" and chain_left > 0)
+        res = blk = buf = None
+        first, decided = level, level
+        while level < stop and blk is None:
+            # the levels of this call: all that are left, or the next one alone
+            upto = stop if (whole or (policy == "adaptive" and level > first)) else level + 1
+            levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)]
+            many = len(levels) > 1
+            packed = getattr(ctx, "plan_levels_packed" if many else "plan_packed", None) if hook is None else None
+            begin = getattr(ctx, "plan_levels_begin", None) if (hook is not None or (many and packed is None)) else None
+            if packed is not None and many:
+                res, k, blk, buf = packed(params, cost, levels)
+                decided = level + k
+            elif packed is not None:
+                T, traj_len, L, D = levels[0]
+                if len(T) * len(L) * len(D):
+                    res, blk, buf = packed(params, cost, T, traj_len, L, D)
+                decided = level
+            elif begin is not None:
+                # the same in two halves: the caller's own work (harness: the last cycle's bookkeeping) runs while the device is busy
+                begin(params, cost, levels)
+                if hook is not None and level == first:
+                    hook()
+                res = ctx.plan_wait()
+                blk = res.best_states if res.best_index >= 0 else None
+                decided = level + (ctx.last_level() if hasattr(ctx, "last_level") else 0)
+            else:   # a context without these calls (test doubles, recorders): level by level
+                upto = level + 1
+                T, traj_len, L, D = levels[0]
+                if len(T) * len(L) * len(D):
+                    res = ctx.plan(PlanInputs.trusted(params, cost, T, traj_len, L, D))
+                    blk = res.best_states if res.best_index >= 0 else None
+                decided = level
+            level = upto
+        if not single_level and policy == "adaptive":
+            self._chain_cycles = self.LEVEL_CHAIN_CYCLES if (blk is None or decided > first) else max(0, chain_left - 1)
+        if res is not None:
+            rd = self._infeasible_reason_dict
+            self._infeasible_count_kinematics = res.n_candidates - res.n_feasible
+            self._infeasible_count_collision = res.n_collision_before_best
+            rc = res.reason_counts
+            for k, name in _REASON_ITEMS:
+                if name in rd:
+                    rd[name] = int(rc[k])
+        if blk is None:
+            return None
+        if buf is None:   # output packing: positions, lon / lat samples, shifted orientations, steering angles and yaw rates in one pass in C
+            buf = _capi.pack_trajectory(blk, self.dt, self.vehicle_params.wheelbase, self.x_0.orientation)
+        return self._fast_output(blk, buf)
 
     def _fast_output(self, blk, buf):
         """(Cartesian trajectory, curvilinear trajectory, lon list, lat list) of reactive_planner.py:514-568 from the winner's state

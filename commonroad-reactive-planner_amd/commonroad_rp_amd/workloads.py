@@ -258,6 +258,34 @@ def make_planner(w: Workload, backend_factory=None, device: int = 0, draw: bool 
     return rp
 
 
+def make_level_planner(w: Workload, t_min: float, backend_factory=None, device: int = 0, low_vel_mode_threshold: float = 4.0,
+                       draw: bool = False):
+    """A ``ReactivePlanner`` on a workload's scenario (reference path, obstacles, initial state) with the REFERENCE's OWN sampling
+    scheme -- levels 1 .. num_sampling_levels - 1 of ``FixedIntervalSampling``, velocity range from ``set_desired_velocity`` -- and
+    the settings of the shipped YAML files (configurations/*.yaml: N = 20, dt 0.1, t_min per scenario): what run_planner.py:28-107
+    drives.  The workload's own grids are not used."""
+    from .config import ReactivePlannerConfiguration
+    from .reactive_planner import ReactivePlanner
+    from .state import ReactivePlannerState
+    p = w.inputs.params
+    cfg = ReactivePlannerConfiguration.from_dict(dict(
+        planning=dict(dt=p.dt, time_steps_computation=20, factor=p.factor, low_vel_mode_threshold=low_vel_mode_threshold),
+        sampling=dict(longitudinal_mode="velocity_keeping", t_min=t_min),
+        debug=dict(draw_traj_set=draw, show_plots=draw)))
+    rp = ReactivePlanner(cfg, backend_factory=backend_factory, device=device)
+    co = w.coordinate_system
+    rp.set_reference_path(coordinate_system=co)
+    rp.set_collision_checker(collision_checker=w.obstacles)
+    pos = co.convert_to_cartesian_coords(p.x0_lon[0], p.x0_lat[0])
+    v0 = float(w.inputs.cost.desired_speed)
+    x0 = ReactivePlannerState(time_step=p.time_step0, position=pos, orientation=p.x0_orientation, velocity=v0, steering_angle=0.0,
+                              acceleration=0.0, yaw_rate=0.0)
+    rp.reset(initial_state_cart=x0, initial_state_curv=(list(p.x0_lon), list(p.x0_lat)), collision_checker=rp.collision_checker,
+             coordinate_system=co)
+    rp.set_desired_velocity(desired_velocity=v0, current_speed=v0)
+    return rp
+
+
 def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_factory=None, nL: Optional[int] = None):
     """The inputs of ``n_states`` consecutive replanning cycles of a workload ("replan sequence = closed
     loop over the scenario (cfg1-4) or a fixed list of initial states drawn with seed 1 (cfg5)"), as a list of
@@ -290,7 +318,8 @@ def replan_sequence(w: Workload, n_states: int = 32, device: int = 0, backend_fa
     factory = backend_factory or RpContext
 
     class Recording(factory):
-        plan_packed = None   # (the planner's one-call cycle bypasses plan(): off, so that every level's inputs pass through here)
+        # (the planner's one-call cycle bypasses plan(): off, so that every level's inputs pass through here)
+        plan_packed = plan_levels_packed = plan_levels_begin = None
 
         def plan(self, inp, *a, **k):
             recorded.append(PlanInputs(copy_params(inp.params), inp.cost, inp.T.copy(), inp.traj_len.copy(), inp.L.copy(),

@@ -125,6 +125,24 @@ struct rp_ctx {
         KArgs ka{};
         std::chrono::steady_clock::time_point tp0, tp1;
     } pending;
+    // a chain of sampling levels in flight (rp_plan_levels_begin .. rp_plan_wait): what every level's launch left behind -- the
+    // result names the level it belongs to, whose state then becomes the context's "last plan"
+    struct LevelState {
+        Pending pending;
+        std::vector<char> staged;
+        bool staged_on_device = false, last_rows_on_device = false;
+        int last_G = 0, last_block = 0;
+        size_t last_fused_lds = 0;
+        int grid_index = 0;   // index of the level in the caller's array
+    };
+    std::vector<LevelState> chain;          // levels of the chain in flight (empty: a plan on its own)
+    int chain_total = 0;                    // levels the caller handed over (levels behind the chain run one by one in rp_plan_wait)
+    unsigned long long *d_gate = nullptr;   // device word of the chain (KArgs::gate)
+    struct ChainInputs {                    // the caller's arguments, kept for the levels behind the chain
+        rp_params p; rp_cost cost; std::vector<rp_grids> grids; std::vector<std::vector<double>> T, L, D; std::vector<std::vector<int32_t>> tl;
+        int want = 0;
+    } chain_in;
+    int last_level = 0;                     // rp_last_level: index (into the caller's grids) of the level the last result belongs to
     char *d_result = nullptr, *h_result = nullptr, *h_result_dev = nullptr;   // h_result_dev: device address of the pinned block
     size_t cap_result = 0;
     int64_t *d_single = nullptr, *h_single = nullptr;
@@ -498,6 +516,7 @@ void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs
     ka.obs = c->obs;
     ka.debug = c->d_debug;
     ka.has_obstacles = (c->obs.n_sobb + c->obs.n_tri + c->obs.n_circ > 0 || (c->obs.n_dyn > 0 && c->obs.n_steps > 0)) ? 1 : 0;
+    ka.ticket_if_none = 1;   // (gate == nullptr: a plan on its own)
 }
 
 // Part of the reference-table block a grid plan can touch (single-launch variant: every workgroup stages the block in
@@ -708,7 +727,8 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_ro
 // eval -> finalize (-> count for huge batches) (-> winner re-evaluation when nothing was materialised).
 // The result block lands in pinned host memory straight from the kernels; one stream sync per plan.
 int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states);
-int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, bool want_rows) {
+// chain_last: the level is the last one of its chain (or a plan on its own): its epilogue reports whatever it found
+int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, bool want_rows, bool chain_last = true) {
     if (c->time_whole) c->plan_t0 = std::chrono::steady_clock::now();
     c->path_adaptive = false;
     double *const best_states = want_rows ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
@@ -758,16 +778,17 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     c->last_rows_on_device = copy_states || count == 0;
     const bool ticket = c->spin_wait;   // (large batches too: their selection epilogue hands the ticket over itself)
     ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
-    unsigned long long seq = ++c->seq;
-    if (ticket) hrb_host->seq = 0;
+    // (a level of a chain: the chain's one ticket, reset by the chain's first level)
+    unsigned long long seq = ka.gate ? ka.gate_seq : ++c->seq;
+    if (ticket && !ka.gate) hrb_host->seq = 0;
     unsigned long long fin_seq = (ticket && !winner_pass) ? seq : 0ull;
     // (A selection epilogue run by the evaluation kernel's last workgroup was tried and measured slower -- cfg2: eval
     //  21.6 -> 37.8 us: every workgroup then pays an agent-scope release fence, an L2 write-back, before its ticket.)
-    const bool timed = c->profiling > 0 && !skip_eval && (c->calls++ % (unsigned long long)c->profiling) == 0;
+    const bool timed = c->profiling > 0 && !skip_eval && !ka.gate && (c->calls++ % (unsigned long long)c->profiling) == 0;
     bool time_valid = false;
     const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     bool lazy_done = false;   // the cost-ordered collision stage delivered the result (its last round handed the ticket over)
-    if (c->epilogue_dirty) {   // (the last chain on this context did not reach its result: see rp_ctx::epilogue_dirty)
+    if (c->epilogue_dirty && (!ka.gate || ka.gate_level == 1)) {   // (the last chain of kernels on this context did not reach its result: see rp_ctx::epilogue_dirty)
         HIP_TRY(c, hipMemsetAsync(c->d_sel_scratch, 0, RP_SEL_SCRATCH * sizeof(unsigned long long), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_lazy_ctl, 0, sizeof(LazyCtl), c->stream));
@@ -825,7 +846,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         // =1 whenever the launch path allows it (tests), default: batches beyond the one-workgroup epilogue, unless the last
         // attempts had to fall back to the eager kernel (a scene where nearly everything collides).
         bool lazy_possible = count > 0 && !mat && !fused_lds && collision_level(ka) > 0 && !(ka.flags & RP_FLAG_DRAW_ALL) &&
-                             ka.cost_kind != RP_COST_EXTERNAL && !ka.single_index;
+                             ka.cost_kind != RP_COST_EXTERNAL && !ka.single_index && !ka.gate;   // (a chain of levels has no host in between)
         const char *lazy_e = lazy_possible ? std::getenv("RP_AMD_LAZY") : nullptr;   // (read per plan: the tests switch paths)
         const int lazy_env = lazy_e ? std::atoi(lazy_e) : -1;
         lazy_possible = lazy_possible && lazy_env != 0 && (c->collision_mode != RP_COLLISION_EAGER || lazy_env == 1);
@@ -905,6 +926,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         fa.N = ka.N; fa.n_partials = n_partials; fa.copy_states = copy_states ? 1 : 0;
         fa.row_stride = ka.row_stride; fa.tail_split = ka.tail_split; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
         fa.scratch = c->d_sel_scratch;
+        fa.gate = const_cast<unsigned long long *>(ka.gate); fa.gate_seq = ka.gate_seq; fa.gate_level = ka.gate_level; fa.gate_last = chain_last ? 1 : 0;
         if (small) {   // one workgroup does it all (count of the colliding candidates before the winner included)
             fa.count_inline = 1;
             launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
@@ -929,6 +951,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         kw.partials = nullptr;
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
+        kw.ticket_if_none = (!ka.gate || chain_last) ? 1 : 0;
         if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds, G);
         // (two-kernel path: one candidate is one workgroup whatever the lanes -- a whole wavefront per candidate makes its chain
         //  of step blocks four times shorter than the batch's 16 lanes: cfg3 19 -> ~10 us.  Nothing was materialised that these
@@ -1444,6 +1467,21 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     return RP_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct LevelGate {   // a level of a chain (rp_plan_levels): see KArgs::gate
+    const unsigned long long *gate;
+    unsigned long long seq;
+    int level;     // 1, 2, ...
+    bool last;     // last level of the chain: reports whatever it finds
+};
+int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
+                    int32_t want_best_states, const LevelGate *lg);
+}  // namespace
+
+extern "C" {
+
 int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
             rp_result *result, double *best_states) {
     if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
@@ -1459,14 +1497,61 @@ int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
     if (!result) return fail(c, RP_EINVAL, "rp_plan_wait: null result");
     if (!c->pending.active) return fail(c, RP_ESTATE, "rp_plan_wait: no plan in flight on this context");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int rc = pipeline_wait(c, result, best_states);
-    if (rc != RP_OK) return rc;
+    if (c->chain.size() > 1) {
+        // a chain of levels: one ticket; the result block names the level it belongs to, whose launch state becomes the context's
+        int rc = wait_ticket(c, c->chain.front().pending.seq);
+        if (rc != RP_OK) { c->pending.active = false; c->chain.clear(); return rc; }
+        const int tag = (int)reinterpret_cast<const ResultBlock *>(c->h_result)->pad_;
+        if (tag < 1 || tag > (int)c->chain.size()) { c->pending.active = false; c->chain.clear(); return fail(c, RP_EHIP, "rp_plan_wait: result block of a level chain without its level"); }
+        rp_ctx::LevelState &st = c->chain[(size_t)tag - 1];
+        c->pending = st.pending;
+        c->pending.done = true;   // (the ticket has arrived)
+        c->staged = st.staged; c->staged_on_device = false; c->last_rows_on_device = st.last_rows_on_device;
+        c->last_G = st.last_G; c->last_block = st.last_block; c->last_fused_lds = st.last_fused_lds;
+        // the grids of that level are what later launches on this context (winner re-evaluation, rp_eval_one) find in their launch blocks
+        if (!c->staged.empty() && c->staged.size() <= sizeof(c->kargs_g.grid)) {
+            std::memcpy(c->kargs_g.grid, c->staged.data(), c->staged.size());
+            std::memcpy(c->kargs_gl.grid, c->staged.data(), c->staged.size());
+        }
+        c->last_level = st.grid_index;
+    } else if (c->chain.size() == 1) {
+        c->last_level = c->chain[0].grid_index;
+    }
+    int rc = pipeline_wait(c, result, best_states);
+    if (rc != RP_OK) { c->chain.clear(); return rc; }
     c->last = c->pending.ka; c->have_last = true; c->last_mat = c->pending.mat; c->last_coeffs = c->pending.coeffs;
+    if (!c->chain.empty()) {
+        // levels behind the chain (too large to ride in it): one by one, while there is no winner (reactive_planner.py:616-636)
+        int next = c->chain.back().grid_index + 1;
+        const int total = c->chain_total;
+        c->chain.clear();
+        while (result->best_index < 0 && next < total) {
+            const rp_ctx::ChainInputs &in = c->chain_in;
+            const int64_t cnt = (int64_t)in.grids[next].nT * in.grids[next].nL * in.grids[next].nD;
+            if (cnt > 0) {
+                rc = plan_begin_impl(c, &in.p, &in.cost, &in.grids[next], 0, -1, in.want, nullptr);
+                if (rc == RP_OK) rc = pipeline_wait(c, result, best_states);
+                if (rc != RP_OK) return rc;
+                c->last = c->pending.ka; c->have_last = true; c->last_mat = c->pending.mat; c->last_coeffs = c->pending.coeffs;
+                c->last_level = next;
+            }
+            ++next;
+        }
+    }
     return RP_OK;
 }
 
 int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
                   int32_t want_best_states) {
+    if (c) { c->chain.clear(); c->chain_total = 0; c->last_level = 0; }
+    return plan_begin_impl(c, p, cost, g, cand_begin, cand_end, want_best_states, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
+                    int32_t want_best_states, const LevelGate *lg) {
     rp_result dummy_result;
     rp_result *const result = &dummy_result;   // (validate only checks it for null)
     double *const best_states = want_best_states ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
@@ -1544,10 +1629,136 @@ int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_g
     if (c->obs.n_dyn <= 0 && c->obs.n_clus == 0) ka.use_near_mask = 0;
     table_window(c, p, g, ka);
     c->have_last = false;
-    rc = pipeline_begin(c, ka, mat, false, false, best_states != nullptr);
+    if (lg) { ka.gate = lg->gate; ka.gate_seq = lg->seq; ka.gate_level = lg->level; }
+    rc = pipeline_begin(c, ka, mat, false, false, best_states != nullptr, lg ? lg->last : true);
     if (rc != RP_OK) return rc;
     c->pending.mat = mat; c->pending.coeffs = false;
     return RP_OK;
+}
+
+// Can this level ride in a chain?  Its grids travel in the launches' kernarg segments (the staging buffer is one per context), its
+// epilogue is the one-workgroup kernel, and the plan needs no decision of the host between its kernels.
+bool level_chainable(const rp_ctx *c, const rp_params *p, const rp_grids *g) {
+    (void)c;
+    if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return false;
+    const int64_t total = (int64_t)g->nT * g->nL * g->nD;
+    const size_t sbytes = ((size_t)g->nT + g->nL + g->nD) * sizeof(double) + (size_t)g->nT * sizeof(int32_t);
+    if (total > RP_FINALIZE_MAX || sbytes > sizeof(((KArgsG *)nullptr)->grid) || std::getenv("RP_AMD_NO_INLINE_GRIDS")) return false;
+    // (plans of this size that want the winner's rows write every candidate's: no winner re-evaluation, no cost-ordered stage)
+    return (size_t)total * RP_N_ARRAYS * (size_t)(p->N + 1) * sizeof(double) <= kAutoMaterializeBytes;
+}
+}  // namespace
+
+extern "C" {
+
+int rp_last_level(const rp_ctx *c) { return c ? c->last_level : 0; }
+
+int rp_plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, int32_t want_best_states) {
+    if (!c) return RP_EINVAL;
+    if (n_levels < 1 || n_levels > 64 || !grids) return fail(c, RP_EINVAL, "rp_plan_levels: need 1 .. 64 levels");
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_levels_begin: a plan is already in flight on this context (rp_plan_wait first)");
+    c->chain.clear(); c->chain_total = n_levels; c->last_level = 0;
+    // the caller's inputs are kept: levels behind the chain (too large for it) run one by one inside rp_plan_wait
+    rp_ctx::ChainInputs &in = c->chain_in;
+    if (!p || !cost) return fail(c, RP_EINVAL, "null params / cost / result");
+    in.p = *p; in.cost = *cost; in.want = want_best_states;
+    in.grids.assign(grids, grids + n_levels);
+    in.T.resize(n_levels); in.L.resize(n_levels); in.D.resize(n_levels); in.tl.resize(n_levels);
+    for (int k = 0; k < n_levels; ++k) {
+        const rp_grids &g = grids[k];
+        if (g.nT < 0 || g.nL < 0 || g.nD < 0 || ((int64_t)g.nT * g.nL * g.nD > 0 && (!g.T || !g.traj_len || !g.L || !g.D)))
+            return fail(c, RP_EINVAL, "rp_plan_levels: bad grids");
+        in.T[k].assign(g.T, g.T + (g.T ? g.nT : 0)); in.L[k].assign(g.L, g.L + (g.L ? g.nL : 0)); in.D[k].assign(g.D, g.D + (g.D ? g.nD : 0));
+        in.tl[k].assign(g.traj_len, g.traj_len + (g.traj_len ? g.nT : 0));
+        in.grids[k].T = in.T[k].data(); in.grids[k].L = in.L[k].data(); in.grids[k].D = in.D[k].data(); in.grids[k].traj_len = in.tl[k].data();
+    }
+    // the chain: leading levels that can ride in it (at least the first level is launched, chainable or not -- then as a plan on its own)
+    int n_chain = 0;
+    while (n_chain < n_levels && level_chainable(c, p, &grids[n_chain])) ++n_chain;
+    if (n_chain <= 1) {   // nothing to chain: the first level as an ordinary plan, the others (if any) behind it in rp_plan_wait
+        const int rc = plan_begin_impl(c, p, cost, &grids[0], 0, -1, want_best_states, nullptr);
+        if (rc != RP_OK) { c->chain_total = 0; return rc; }
+        rp_ctx::LevelState st;
+        st.grid_index = 0;
+        c->chain.push_back(st);   // (marks "a levels call": rp_plan_wait goes on with level 1 when this one has no winner)
+        c->chain.back().pending = c->pending;
+        return RP_OK;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->d_gate) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_gate, sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_gate, 0, sizeof(unsigned long long)));
+    }
+    int rc = ensure_result(c, p->N + 1);
+    if (rc != RP_OK) return rc;
+    {   // every buffer the levels share has its final size BEFORE the first launch: a buffer that grew between two levels would be
+        // freed under the kernels of the level before (and the context's "last plan" would point into the new, empty one)
+        int64_t cmax = 0, pmax = 0;
+        for (int k = 0; k < n_chain; ++k) {
+            cmax = std::max<int64_t>(cmax, (int64_t)grids[k].nT * grids[k].nL * grids[k].nD);
+            pmax = std::max<int64_t>(pmax, (int64_t)grids[k].nT * grids[k].nL);
+        }
+        const int n = p->N + 1;
+        if ((rc = grow(c, c->d_status, c->cap_status, (size_t)cmax)) != RP_OK) return rc;
+        if ((rc = grow(c, c->d_cost, c->cap_cost, (size_t)cmax)) != RP_OK) return rc;
+        if ((rc = grow(c, c->d_states, c->cap_states, (size_t)cmax * RP_N_ARRAYS * (size_t)((n + 15) & ~15))) != RP_OK) return rc;
+        if ((rc = grow(c, c->d_profile, c->cap_profile, (size_t)pmax * PF_FIELDS * (size_t)n)) != RP_OK) return rc;
+        if ((rc = grow(c, c->d_pair_hdr, c->cap_pair_hdr, (size_t)pmax)) != RP_OK) return rc;
+    }
+    const unsigned long long seq = ++c->seq;
+    reinterpret_cast<ResultBlock *>(c->h_result)->seq = 0;
+    int launched = 0;
+    for (int k = 0; k < n_chain; ++k) {
+        const int64_t total = (int64_t)grids[k].nT * grids[k].nL * grids[k].nD;
+        bool later = false;   // is there a later chain level with candidates?
+        for (int q = k + 1; q < n_chain; ++q) later = later || (int64_t)grids[q].nT * grids[q].nL * grids[q].nD > 0;
+        if (total == 0 && (later || launched > 0)) continue;   // an empty level has nothing to say (the reference's loop moves on: :616-636)
+        const LevelGate lg = {c->d_gate, seq, launched + 1, !later};
+        c->pending.active = false;
+        if (launched > 0) c->epilogue_dirty = false;   // (the level before is on the stream: its epilogue leaves the scratch words as it found them)
+        rc = plan_begin_impl(c, p, cost, &grids[k], 0, -1, want_best_states, &lg);
+        if (rc != RP_OK) { c->chain.clear(); c->chain_total = 0; c->pending.active = false; return rc; }
+        rp_ctx::LevelState st;
+        st.pending = c->pending; st.staged = c->staged; st.staged_on_device = c->staged_on_device; st.last_rows_on_device = c->last_rows_on_device;
+        st.last_G = c->last_G; st.last_block = c->last_block; st.last_fused_lds = c->last_fused_lds; st.grid_index = k;
+        c->chain.push_back(std::move(st));
+        ++launched;
+    }
+    c->pending.active = true;   // (one plan in flight, as far as the other entry points are concerned)
+    return RP_OK;
+}
+
+int rp_plan_levels(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, rp_result *result,
+                   double *best_states, int32_t *level) {
+    if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
+    int rc = rp_plan_levels_begin(c, p, cost, n_levels, grids, best_states != nullptr ? 1 : 0);
+    if (rc == RP_OK) rc = rp_plan_wait(c, result, best_states);
+    if (rc == RP_OK && level) *level = c->last_level;
+    return rc;
+}
+
+int rp_plan_levels_packed(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const int32_t *dims, rp_result *result, double *out,
+                          int32_t *level) {
+    if (!c) return RP_EINVAL;
+    if (!p || !cost || !result || !out || !dims || n_levels < 1 || n_levels > 64) return fail(c, RP_EINVAL, "rp_plan_levels_packed: null argument / level count");
+    if (c->fast_buf.empty()) return fail(c, RP_EINVAL, "rp_plan_levels_packed: rp_fast_buffer was never asked for");
+    rp_grids g[64];
+    const double *b = c->fast_buf.data();
+    size_t at = 0;   // doubles
+    for (int k = 0; k < n_levels; ++k) {
+        const int nT = dims[3 * k], nL = dims[3 * k + 1], nD = dims[3 * k + 2];
+        if (nT < 0 || nL < 0 || nD < 0) return fail(c, RP_EINVAL, "rp_plan_levels_packed: negative grid size");
+        const size_t words = (size_t)nT + nL + nD + ((size_t)nT + 1) / 2;
+        if (at + words > c->fast_buf.size()) return fail(c, RP_EINVAL, "rp_plan_levels_packed: grids do not fit the buffer of rp_fast_buffer");
+        g[k].nT = nT; g[k].nL = nL; g[k].nD = nD; g[k].reserved_ = 0;
+        g[k].T = b + at; g[k].L = b + at + nT; g[k].D = b + at + nT + nL;
+        g[k].traj_len = reinterpret_cast<const int32_t *>(b + at + nT + nL + nD);
+        at += words;
+    }
+    const int rc = rp_plan_levels(c, p, cost, n_levels, g, result, out, level);
+    if (rc != RP_OK || result->best_index < 0) return rc;
+    const int n = p->N + 1;
+    return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
 }
 
 int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len) {

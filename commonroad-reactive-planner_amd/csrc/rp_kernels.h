@@ -110,7 +110,21 @@ struct KArgs {
     unsigned long long *debug;      // diagnostic build (-DRP_STAMPS) only: s_memtime stamps of block 0 / wave 0
     unsigned long long *host_seq;   // winner re-evaluation only: completion ticket in the host mirror
     unsigned long long seq_value;
+    // Chain of sampling levels on one stream (rp_plan_levels: the level loop of plan(), reactive_planner.py:616-636, without a host
+    // round trip per level): `gate` is a device word the epilogue of the level that finds a winner sets to (gate_seq << 8) | its
+    // number (1, 2, ...); the kernels of every LATER level find it set and leave at once.  nullptr: a plan on its own.
+    const unsigned long long *gate;
+    unsigned long long gate_seq;
+    int32_t gate_level;       // number (1, 2, ...) of the level this launch belongs to
+    int32_t ticket_if_none;   // winner re-evaluation: hand the completion ticket over also when there is no winner (not in a chain's earlier levels)
 };
+
+// true: an earlier level of the chain this launch belongs to has found its winner -- nothing of this level is wanted any more
+__device__ __forceinline__ bool level_gate_closed(const unsigned long long *gate, unsigned long long seq, int level) {
+    if (!gate) return false;
+    const unsigned long long g = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (g >> 8) == seq && (int)(g & 0xffull) < level;
+}
 
 // What the evaluation and profile kernels take: the KArgs block and, behind it, room for the sample grids of the launch
 // [T (nT doubles) | L (nL) | D (nD) | traj_len (nT int32)].  A replanning cycle changes the grids every time (the velocity
@@ -428,6 +442,11 @@ struct FinArgs {
     const uint32_t *list_count;
     struct LazyCtl *lazy;
     int32_t list_cap, level;
+    // a level of a chain (see KArgs::gate): the device word, the chain's sequence number, this level's number, and whether it is the
+    // chain's last level (which hands the completion ticket over whatever it found)
+    unsigned long long *gate;
+    unsigned long long gate_seq;
+    int32_t gate_level, gate_last;
 };
 #ifdef RP_STAMPS
 #define RP_FSTAMP(k)                                                                             \
@@ -458,7 +477,8 @@ __device__ __forceinline__ void result_host_store(void *p, unsigned long long v)
 __device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, FinalizeOut *host_out, int tid, int64_t widx, double wcost, int64_t count,
                                                     const unsigned int *c32 /* [10] n_feasible, n_collision, reasons[8] */,
                                                     unsigned long long before, bool rows_here,
-                                                    const unsigned long long *extra = nullptr /* [4]: words 31 .. 34 (w_coeffs[0..3]) */) {
+                                                    const unsigned long long *extra = nullptr /* [4]: words 31 .. 34 (w_coeffs[0..3]) */,
+                                                    int level_tag = 0) {
     constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
     static_assert(words == 44 && sizeof(rp_result) == 28 * 8, "FinalizeOut layout");
     if (tid < words) {
@@ -474,7 +494,8 @@ __device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, Finali
         else if (k == 3 || k == 5 || (k >= 6 && k < 14)) v = (unsigned long long)c32[ci];
         else if (k == 4 || k == 28) v = before;
         else if (k == 27) v = 0ull;                                  // kernel_ms
-        else if (k == 29) v = have ? (unsigned long long)(RP_LABEL_FEASIBLE | (rows_here ? 0u : RP_WSTATUS_ROWS_ON_HOST)) : 0ull;   // w_status | pad
+        else if (k == 29) v = (have ? (unsigned long long)(RP_LABEL_FEASIBLE | (rows_here ? 0u : RP_WSTATUS_ROWS_ON_HOST)) : 0ull) |
+                              ((unsigned long long)(unsigned int)level_tag << 32);   // w_status | pad (pad: number of the chain's level, 0 outside a chain)
         else if (extra && k >= 31 && k < 35) v = extra[k - 31];
         reinterpret_cast<unsigned long long *>(dev_out)[k] = v;
         result_host_store(reinterpret_cast<unsigned long long *>(host_out) + k, v);
@@ -490,6 +511,7 @@ __device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, Finali
 // release fence also writes the L2 back, 1.1 us for nothing here.  In-kernel stamps before / after:
 // profiles/r02_finalize_stamps.txt.
 __device__ __forceinline__ void finalize_body(const FinArgs &a) {
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;   // (uniform) an earlier level of the chain has delivered
     __shared__ unsigned long long sh_before;
     __shared__ unsigned int sh_c32[10];
     const int tid = threadIdx.x;
@@ -623,7 +645,7 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     RP_FSTAMP(27);   // count done
     FinalizeOut *const dev_out = a.dev_out, *const host_out = a.host_out;
     auto host_store = [](void *p, unsigned long long v) { result_host_store(p, v); };
-    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows, lazy ? sh_extra : nullptr);
+    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows, lazy ? sh_extra : nullptr, a.gate_level);
     RP_FSTAMP(28);   // header stored
     if (want_rows) {   // winner's state block straight from the materialised states
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
@@ -639,7 +661,10 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
         }
     }
     RP_FSTAMP(29);   // rows stored
-    if (a.seq) {   // completion ticket for the spinning host thread: after every wavefront's result stores have been acknowledged
+    // a level of a chain: a winner closes the gate for the levels behind; without one only the last level reports
+    if (a.gate && widx >= 0 && tid == 0)
+        __hip_atomic_store(a.gate, (a.gate_seq << 8) | (unsigned long long)a.gate_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.seq && (!a.gate || widx >= 0 || a.gate_last)) {   // completion ticket for the spinning host thread: after every wavefront's result stores have been acknowledged
         __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0): this wavefront's stores have left for the host
         __syncthreads();
         RP_FSTAMP(30);   // stores acknowledged
@@ -692,6 +717,7 @@ __device__ __forceinline__ void partials_min(const Partials &pp, int n_partials,
 // release / acquire fences (each an L2 write-back or invalidate, a microsecond or two on a chain that is nothing but round trips).
 __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs a) {
     touch_kernargs<3>();
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;   // (uniform over the grid) an earlier level of the chain has delivered
     __shared__ double sh_cost[RP_SEL_THREADS / 64];
     __shared__ long long sh_idx[RP_SEL_THREADS / 64];
     __shared__ unsigned int sh_c32[RP_PARTIAL_CNT];
@@ -797,7 +823,9 @@ __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs
     if (tid == RP_PARTIAL_CNT) sh_before = __hip_atomic_load(&a.scratch[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (tid < 12) __hip_atomic_store(&a.scratch[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows);
+    store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows, nullptr, a.gate_level);
+    if (a.gate && widx >= 0 && tid == 0)
+        __hip_atomic_store(a.gate, (a.gate_seq << 8) | (unsigned long long)a.gate_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (want_rows) {
         double *d1 = reinterpret_cast<double *>(dev_out + 1), *d2 = reinterpret_cast<double *>(host_out + 1);
 #pragma unroll
@@ -811,7 +839,7 @@ __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs
             result_host_store(d2 + k, (unsigned long long)__double_as_longlong(v));
         }
     }
-    if (a.seq) {
+    if (a.seq && (!a.gate || widx >= 0 || a.gate_last)) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&host_out->seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1401,6 +1429,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
     RP_LSTAMP(0);
     touch_kernargs<10>();
     RP_LSTAMP(1);
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;   // (uniform) an earlier level of the chain has delivered
     const int tid = threadIdx.x;
     const int n_ref = a.n_ref;
     if (a.publish_grids && blockIdx.x == 0) {   // the grids of this launch's kernarg segment -> device memory, for the kernels behind
@@ -1617,8 +1646,11 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
     const int group_in_wave = gbase / G;
     const int grp = tid / G;              // group inside the block
 
+    // a level of a chain (rp_plan_levels) behind the one that delivered: nothing to do.  (The winner re-evaluation of the level that
+    // delivered belongs to that level: its number is not below the gate's.)
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;
     if (a.single_index && *a.single_index < 0) {   // no winner to re-evaluate (uniform): only the completion ticket
-        if (a.host_seq && tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (a.host_seq && a.ticket_if_none && tid == 0) __hip_atomic_store(a.host_seq, a.seq_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     const int64_t wave_first = ((int64_t)blockIdx.x * GPB) + (int64_t)wave_in_block * GPW;  // first group of this wave

@@ -198,6 +198,26 @@ int rp_plan_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, con
                   int64_t cand_end, int32_t want_best_states);
 int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *best_states);
 
+/* The LEVEL LOOP of plan() (commonroad_rp/reactive_planner.py:616-636: `while optimal_trajectory is None and i < sampling_level`,
+ * one _create_trajectory_bundle + _get_optimal_trajectory per sampling level) in one call and ONE device round trip: grids[k] are the
+ * sample grids of the levels in the order the loop would visit them.  The kernels of every level go onto the stream back to back;
+ * the epilogue of a level that finds a winner closes a gate in device memory, and the kernels of the levels behind it leave at
+ * once -- the result is the one of the first level that has a winner (or of the last level), as if the levels had been planned one
+ * after the other with rp_plan.  *level: index into grids of the level the result belongs to (also rp_last_level); the calls that
+ * read "the last plan" (rp_fetch_status, rp_cost_range, rp_eval_one, ...) refer to that level.
+ * Levels of up to 16 384 candidates whose grids fit the launch block (96 doubles: the reference's sampling levels hold at most
+ * 29 + 17 + 18 samples) ride in the chain; a level that does not, and the levels behind it, are planned one by one inside the call.
+ * rp_plan_levels = rp_plan_levels_begin + rp_plan_wait; rp_plan_levels_packed: the grids from the context's buffer
+ * (rp_fast_buffer), level after level [T | L | D | traj_len (int32, padded to 8 bytes)], dims[k] = nT, nL, nD; output as
+ * rp_plan_packed. */
+int rp_plan_levels(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids,
+                   rp_result *result, double *best_states, int32_t *level);
+int rp_plan_levels_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids,
+                         int32_t want_best_states);
+int rp_plan_levels_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const int32_t *dims /* [n_levels][3] */,
+                          rp_result *result, double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */, int32_t *level);
+int rp_last_level(const rp_ctx *ctx);
+
 /* Generic entry for foreign SamplingSpace plug-ins (sampling.py:165-175): the polynomials come
  * from the plug-in's TrajectorySample objects.  lon_coeffs/lat_coeffs: [C][6]; lon_T/lat_T: [C]
  * delta_tau of each polynomial; traj_len: [C].  Candidate index = list index. */

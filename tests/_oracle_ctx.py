@@ -50,10 +50,43 @@ class OracleContext:
             return out, None, None
         return out, out.best_states, pack_trajectory(np.ascontiguousarray(out.best_states), params.dt, params.wheelbase, params.x0_orientation)
 
+    def plan_levels_packed(self, params, cost, levels):
+        """the level loop, level by level (what rp_plan_levels does in one device round trip)"""
+        res = blk = buf = None
+        lvl = 0
+        for lvl, (T, tl, L, D) in enumerate(levels):
+            if len(T) * len(L) * len(D) == 0 and lvl + 1 < len(levels):
+                continue
+            res, blk, buf = self.plan_packed(params, cost, T, tl, L, D)
+            if blk is not None:
+                break
+        self._level = lvl
+        return res, lvl, blk, buf
+
+    def plan_levels_begin(self, params, cost, levels, want_best_states=True):
+        self._pending_levels = (params, cost, levels)
+        self._pending = "levels"
+
+    def last_level(self):
+        return getattr(self, "_level", 0)
+
     def plan_begin(self, inp, cand_begin=0, cand_end=-1, want_best_states=True):
         self._pending = (inp, cand_begin, cand_end)
 
     def plan_wait(self):
+        if self._pending == "levels":
+            from commonroad_rp_amd._capi import PlanInputs
+            params, cost, levels = self._pending_levels
+            self._pending = None
+            out = None
+            for lvl, (T, tl, L, D) in enumerate(levels):
+                if len(T) * len(L) * len(D) == 0 and lvl + 1 < len(levels):
+                    continue
+                out = self.plan(PlanInputs(params, cost, T, tl, L, D))
+                self._level = lvl
+                if out.best_index >= 0:
+                    break
+            return out
         inp, lo, hi = self._pending
         self._pending = None
         return self.plan(inp, lo, hi)

@@ -69,9 +69,9 @@ def test_closed_loop_overlap_defers_bookkeeping_into_device_time():
     events = []
 
     class Ctx(OracleContext):
-        def plan_begin(self, inp, *a, **k):
+        def plan_levels_begin(self, *a, **k):
             events.append("begin")
-            return super().plan_begin(inp, *a, **k)
+            return super().plan_levels_begin(*a, **k)
 
         def plan_wait(self):
             events.append("wait")
@@ -122,17 +122,115 @@ def test_plan_begin_wait_gpu():
 
 
 @pytest.mark.gpu
-def test_levels_ahead_gpu():
-    """The stand-alone planner's cycle on the device when level 1 has no winner: first cycle level by level, the next one with two
-    levels in flight (second context); same results as the oracle-backed planner both times."""
+@pytest.mark.parametrize("policy", ["chain", "adaptive", "sequential"])
+@pytest.mark.parametrize("name", ["plan_all_collide", "plan_arc_hv_obs", "plan_scurve_lv", "plan_arc_stop"])
+def test_level_loop_in_one_round_trip_gpu(name, policy):
+    """The stand-alone planner's cycle on the device: the level loop of plan() (reactive_planner.py:616-636) through rp_plan_levels
+    -- every level's kernels on the stream at once, a level that finds a winner stops the ones behind it.  Same trajectory, counters
+    and reasons as the oracle-backed planner, which visits the levels one by one; plan_all_collide visits all three."""
     from _oracle_ctx import OracleContext
     from commonroad_rp_amd._capi import RpContext
-    a, _ = build_planner_from_plan_golden("plan_all_collide", RpContext)
-    b, _ = build_planner_from_plan_golden("plan_all_collide", OracleContext)
+    a, _ = build_planner_from_plan_golden(name, RpContext)
+    b, _ = build_planner_from_plan_golden(name, OracleContext)
+    assert a._fast_path_ok()
+    a.level_policy = policy
     for cycle in range(3):
         ra, rb = a.plan(), b.plan()
-        assert ra is None and rb is None
+        assert (ra is None) == (rb is None)
         assert (a.infeasible_count_kinematics, a.infeasible_count_collision) == (b.infeasible_count_kinematics, b.infeasible_count_collision)
         assert dict(a.infeasible_reason_dict) == dict(b.infeasible_reason_dict)
-    assert a._levels_ahead and getattr(a, "_rp_ctx2", None) is not None
+        if ra is not None:
+            for k in (0, 5, -1):
+                np.testing.assert_allclose(ra[0].state_list[k].position, rb[0].state_list[k].position, rtol=0, atol=1e-6)
+                np.testing.assert_allclose(ra[2][k], rb[2][k], rtol=0, atol=1e-6)
     a.close()
+
+
+@pytest.mark.gpu
+def test_plan_levels_entry_gpu():
+    """rp_plan_levels against rp_plan level by level: (a) the first level wins -- the levels behind it never run, the context's "last
+    plan" is that level; (b) a first level without a winner (everything collides) -- the result, counters and rows are the second
+    level's; (c) no level has a winner -- the last level's counters; (d) an empty level in the chain is passed over; (e) a level too
+    large for the chain is planned behind it, inside the same call; (f) the two-halves form."""
+    from _golden import Golden
+    from commonroad_rp_amd import workloads as W
+    from commonroad_rp_amd._capi import RpContext, PlanInputs
+    from commonroad_rp_amd.collision import ObstacleTables
+    ctx, ref = RpContext(0), RpContext(0)
+
+    def grids(inp):
+        return (inp.T, inp.traj_len, inp.L, inp.D)
+
+    def same(res, out):
+        assert (res.best_index, res.n_candidates, res.n_feasible, res.n_collision_before_best) == \
+            (out.best_index, out.n_candidates, out.n_feasible, out.n_collision_before_best)
+        np.testing.assert_array_equal(np.array(res.reason_counts[:]), out.reason_counts)
+        if out.best_index >= 0:
+            assert res.best_cost == out.best_cost
+    ws = [W.cfg1(level=k) for k in (1, 2, 3)]
+    for c in (ctx, ref):
+        ws[0].setup(c)
+    p, cost = ws[0].inputs.params, ws[0].inputs.cost
+    outs = [ref.plan(w.inputs) for w in ws]
+    assert outs[0].best_index >= 0
+    # (a)
+    res, lvl, blk, buf = ctx.plan_levels_packed(p, cost, [grids(w.inputs) for w in ws])
+    assert lvl == 0 and ctx.last_level() == 0
+    same(res, outs[0])
+    np.testing.assert_array_equal(blk, outs[0].best_states)
+    st, cs = ctx.fetch_status()
+    assert len(st) == ws[0].n_candidates
+    ref.plan(ws[0].inputs)
+    np.testing.assert_array_equal(st, ref.fetch_status()[0])
+    # (b) an obstacle over the whole road: level 1 ... and with a far smaller one only the coarse level fails
+    wall = ObstacleTables(static_circ=[[ws[0].coordinate_system.reference[60][0], ws[0].coordinate_system.reference[60][1], 40.0]])
+    for c in (ctx, ref):
+        c.set_obstacles(wall)
+    outs_w = [ref.plan(w.inputs) for w in ws]
+    assert all(o.best_index < 0 for o in outs_w)
+    # (c)
+    res, lvl, blk, buf = ctx.plan_levels_packed(p, cost, [grids(w.inputs) for w in ws])
+    assert lvl == 2 and blk is None
+    same(res, outs_w[2])
+    for c in (ctx, ref):
+        ws[0].setup(c)
+    # (b) a first level without a winner (target speeds three times the limit: every candidate fails its kinematics), the second delivers
+    i0 = ws[0].inputs
+    sub = PlanInputs(p, cost, i0.T, i0.traj_len, i0.L * 3.0 + 30.0, i0.D)
+    o_sub, o2 = ref.plan(sub), ref.plan(ws[1].inputs)
+    assert o_sub.best_index < 0 and o2.best_index >= 0
+    res, lvl, blk, buf = ctx.plan_levels_packed(p, cost, [grids(sub), grids(ws[1].inputs), grids(ws[2].inputs)])
+    assert lvl == 1 and ctx.last_level() == 1
+    same(res, o2)
+    np.testing.assert_array_equal(blk, o2.best_states)
+    st, cs = ctx.fetch_status()                 # "the last plan" is the level that delivered
+    assert len(st) == ws[1].n_candidates
+    np.testing.assert_array_equal(st, ref.fetch_status()[0])
+    one, s1, c1 = ctx.eval_one(o2.best_index)   # ... also for launches that read its grids again
+    np.testing.assert_array_equal(one, o2.best_states)
+    # (d) empty levels in the chain are passed over
+    empty = (i0.T[:0], i0.traj_len[:0], i0.L, i0.D)
+    res, lvl, blk, buf = ctx.plan_levels_packed(p, cost, [empty, grids(sub), empty, grids(ws[1].inputs)])
+    assert lvl == 3
+    same(res, o2)
+    res, lvl, blk, buf = ctx.plan_levels_packed(p, cost, [empty, empty])
+    assert res.best_index < 0 and res.n_candidates == 0 and blk is None
+    # (e) a level beyond the chain's size behind a failing one: cfg2's grid (7 440 candidates, 61 samples fit; cfg3's does not)
+    w3 = W.cfg3()
+    for c in (ctx, ref):
+        w3.setup(c)
+    p3, c3 = w3.inputs.params, w3.inputs.cost
+    big = ref.plan(w3.inputs)
+    i3 = w3.inputs
+    none = PlanInputs(p3, c3, i3.T[:1], i3.traj_len[:1], i3.L[-1:] * 3.0, i3.D[:4])   # (target speed three times the limit: infeasible)
+    o_none = ref.plan(none)
+    assert o_none.best_index < 0
+    res, lvl, blk, buf = ctx.plan_levels_packed(p3, c3, [grids(none), grids(i3)])
+    assert lvl == 1
+    same(res, big)
+    # (f) begin / wait
+    ctx.plan_levels_begin(p3, c3, [grids(none), grids(none), grids(i3)])
+    out = ctx.plan_wait()
+    assert ctx.last_level() == 2 and out.best_index == big.best_index and out.n_feasible == big.n_feasible
+    ctx.close()
+    ref.close()

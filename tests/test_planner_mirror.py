@@ -135,109 +135,74 @@ def test_fast_cycle_equals_general_cycle(name):
         np.testing.assert_array_equal(a[1][3], b[1][3])
 
 
-def test_next_level_starts_while_the_current_one_is_on_the_device():
-    """A cycle whose first level has no winner costs a whole device round trip before the second can start
-    (reactive_planner.py:616-636).  After such a cycle the planner puts level i + 1 on a second context right behind level i:
-    both are on the device before the first result is waited for; results as before."""
+def test_level_loop_goes_to_the_device_in_one_call():
+    """A cycle whose first level has no winner costs the reference a whole pass per level (reactive_planner.py:616-636).  The
+    stand-alone planner hands the grids of every level the loop could visit to the context in ONE call (rp_plan_levels: one device
+    round trip whatever level delivers); with an ``on_device_launched`` hook the same in two halves, the hook in between; a context
+    without the levels call is asked level by level.  Results as the general loop's."""
     from _oracle_ctx import OracleContext
     log = []
 
     class Logged(OracleContext):
-        def plan_begin(self, inp, *a, **k):
-            log.append(("begin", inp.n_candidates))
-            return super().plan_begin(inp, *a, **k)
+        def plan_levels_packed(self, params, cost, levels):
+            log.append(("levels_packed", [len(T) * len(L) * len(D) for (T, tl, L, D) in levels]))
+            return super().plan_levels_packed(params, cost, levels)
+
+        def plan_levels_begin(self, params, cost, levels, want_best_states=True):
+            log.append(("levels_begin", len(levels)))
+            return super().plan_levels_begin(params, cost, levels, want_best_states)
 
         def plan_wait(self):
             log.append(("wait",))
-            self._in_wait = True
-            try:
-                return super().plan_wait()
-            finally:
-                self._in_wait = False
+            return super().plan_wait()
+
+    class PerLevel(OracleContext):
+        plan_levels_packed = plan_levels_begin = plan_packed = None
 
         def plan(self, inp, *a, **k):
-            if not getattr(self, "_in_wait", False):
-                log.append(("plan", inp.n_candidates))
+            log.append(("plan", inp.n_candidates))
             return super().plan(inp, *a, **k)
 
     name = "plan_all_collide"          # (no level has a winner: plan() visits all three)
     ref, z = build_planner_from_plan_golden(name, OracleContext)
+    ref._get_optimal_trajectory = ref._get_optimal_trajectory        # (an instance attribute: the general loop)
     want = _plan_summary(ref.plan(), ref)
     rp, _ = build_planner_from_plan_golden(name, Logged)
     assert rp._fast_path_ok()
-    first = _plan_summary(rp.plan(), rp)
-    assert [e[0] for e in log] == ["plan", "plan", "plan"] and rp._levels_ahead      # level by level, and it took more than one
+    rp.level_policy = "chain"                      # every level in one call, every cycle
+    assert _plan_summary(rp.plan(), rp) == want
+    assert log == [("levels_packed", [120, 540, 2754])]
     del log[:]
-    second = _plan_summary(rp.plan(), rp)
-    # two levels on the device before the first wait; the third starts (on the context level 1 has left) before the second is waited for
-    assert [e[0] for e in log] == ["begin", "begin", "wait", "begin", "wait", "wait"]
-    for got in (first, second):
-        assert got == want
+    rp.on_device_launched = lambda: log.append(("hook",))
+    assert _plan_summary(rp.plan(), rp) == want
+    assert log == [("levels_begin", 3), ("hook",), ("wait",)]
+    del log[:]
+    assert _plan_summary(rp.plan(current_sampling_level=2), rp)[0] == _plan_summary(ref.plan(current_sampling_level=2), ref)[0]
+    assert log[0] == ("levels_begin", 1)
     rp.close()
-
-
-def test_level_started_ahead_is_collected_before_the_context_is_used_again():
-    """level L fails, L + 1 (second context) succeeds, L + 2 has been started ahead on the primary context and stays in
-    flight.  The next cycle may take the general loop (standstill: ``x_0.velocity <= 0.05``), a new reference path or new obstacle
-    tables may arrive in between -- ``rp_plan_begin`` / ``rp_set_reference`` / ``rp_set_obstacles`` refuse a context with a plan in
-    flight (RP_ESTATE).  The planner collects the leftover before it asks the context for anything else."""
-    from _oracle_ctx import OracleContext
-    from commonroad_rp_amd.collision import ObstacleTables
-
-    class Strict(OracleContext):
-        """refuses what librp_amd.so refuses while a plan is in flight; reports no winner for the smallest level"""
-        def _free(self, what):
-            if getattr(self, "_pending", None) is not None:
-                raise RuntimeError(f"{what}: a plan is already in flight on this context (RP_ESTATE)")
-
-        def plan_begin(self, inp, *a, **k):
-            self._free("rp_plan_begin")
-            return super().plan_begin(inp, *a, **k)
-
-        def plan(self, inp, *a, **k):
-            if not getattr(self, "_in_wait", False):
-                self._free("rp_plan")
-            out = super().plan(inp, *a, **k)
-            if inp.n_candidates <= 120:
-                out.best_index, out.best_states = -1, None
-            return out
-
-        def plan_wait(self):
-            self._in_wait = True
-            try:
-                return super().plan_wait()
-            finally:
-                self._in_wait = False
-
-        plan_packed = None   # (the begin / wait path: what a planner with an on_device_launched hook or levels ahead takes)
-
-        def set_reference(self, *a, **k):
-            self._free("rp_set_reference")
-            return super().set_reference(*a, **k)
-
-        def set_obstacles(self, *a, **k):
-            self._free("rp_set_obstacles")
-            return super().set_obstacles(*a, **k)
-
-    rp, z = build_planner_from_plan_golden("plan_arc_hv_obs", Strict)
-    assert rp._fast_path_ok()
-    assert rp.plan() is not None and rp._levels_ahead                      # level 1 "fails", level 2 delivers
-    assert rp.plan() is not None                                           # levels 1 + 2 together, 3 started ahead and not needed
-    assert rp.__dict__.get("_rp_inflight") is not None
-    # (a) new obstacle tables before the next cycle
-    rp.set_collision_checker(collision_checker=ObstacleTables(static_obb=z["static_obb"], static_tri=z["static_tri"],
-                                                              static_circ=z["static_circ"], dyn_obb=z["dyn_obb"], dyn_t0=int(z["dyn_t0"])))
-    assert rp.plan() is not None
-    assert rp.__dict__.get("_rp_inflight") is not None
-    # (b) a standstill cycle: the general loop calls ctx.plan() on the primary context
-    x0 = rp.x_0
-    x0.velocity = 0.0
-    rp.reset(initial_state_cart=x0, initial_state_curv=([rp.x_0_cl[0][0], 0.0, 0.0], list(rp.x_0_cl[1])),
-             collision_checker=rp.collision_checker, coordinate_system=rp.coordinate_system)
-    assert not rp._fast_path_ok()
-    rp.plan()
-    assert rp.__dict__.get("_rp_inflight") is None
-    rp.close()
+    del log[:]
+    rp2, _ = build_planner_from_plan_golden(name, PerLevel)
+    assert _plan_summary(rp2.plan(), rp2) == want
+    assert log == [("plan", 120), ("plan", 540), ("plan", 2754)]
+    # the default policy: the first level alone; it fails -> the REMAINING levels in one call; the next cycles go over whole
+    del log[:]
+    rp3, _ = build_planner_from_plan_golden(name, Logged)
+    assert rp3.level_policy == "adaptive"
+    packed1 = []
+    inner = rp3._gpu_ctx().plan_packed
+    rp3._gpu_ctx().plan_packed = lambda *a: (packed1.append(len(a[2]) * len(a[4]) * len(a[5])), inner(*a))[1]
+    assert _plan_summary(rp3.plan(), rp3) == want
+    # (the oracle-backed double serves its levels call through plan_packed: only the FIRST entry is the planner's own call)
+    assert packed1[0] == 120 and log == [("levels_packed", [540, 2754])]
+    del log[:], packed1[:]
+    assert _plan_summary(rp3.plan(), rp3) == want
+    assert packed1[0] == 120 and log == [("levels_packed", [120, 540, 2754])]
+    # ... and a scene whose first level delivers never sends more than that level
+    del log[:]
+    rp4, _ = build_planner_from_plan_golden("plan_arc_hv_obs", Logged)
+    for _ in range(3):
+        assert rp4.plan() is not None
+    assert log == []
 
 
 def test_closed_planner_plans_again_with_fresh_arena_buffers():
