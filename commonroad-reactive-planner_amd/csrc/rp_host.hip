@@ -643,7 +643,8 @@ int wait_ticket(rp_ctx *c, unsigned long long seq) {
 // The longitudinal profiles are in place (run_pipeline launched rp_lon_kernel).  *done: the result block in pinned host memory is
 // final (winner or "no candidate survives"); otherwise the caller runs the eager kernel over the whole batch.
 template <typename LaunchEval>
-int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, int grid, bool want_rows, LaunchEval &launch_main_eval, bool *done, int *rounds) {
+int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* workgroups of pass 1: known once it is launched */, bool want_rows,
+             LaunchEval &launch_main_eval, bool *done, int *rounds) {
     *done = false;
     *rounds = 0;
     (void)G;
@@ -771,6 +772,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     ka.partials = c->d_partials;
     ka.partials_cap = c->cap_partials + kFoldPartials;   // slots per array (the folded ones sit behind the workgroups')
     int n_partials = grid;
+    int main_grid = grid;   // workgroups (= block partials) of the batch's evaluation launch: fewer when rp_cost_kernel takes it
 
     const bool small = count <= RP_FINALIZE_MAX;
     const bool copy_states = mat && best_states != nullptr && count > 0;
@@ -828,13 +830,30 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         // the evaluation kernel's duration: events attached to the launch itself (hipExtModuleLaunchKernel; RP_AMD_EVENT_BRACKET=1:
         // two hipEventRecord around it, which adds the dispatch and completion handling of the bracket -- ~2.5 us on a 14-us kernel)
         const bool by_launch = timed && count > 0 && !std::getenv("RP_AMD_EVENT_BRACKET");
+        // Costs-only launches of large grid batches -- no state rows, no collision query: production-mode plans without obstacles and
+        // the first pass of the cost-ordered stage -- take rp_cost_kernel: one lane per candidate, the lane walks the steps
+        // (rp_kernels.h).  It needs wavefronts of 64 candidates to fill the chip: from 131 072 candidates (two per SIMD) on;
+        // RP_AMD_COST_KERNEL=0 / 1 never / whenever the variant applies (tests).
+        bool cost_kernel_ok = count > 0 && !fused_lds && !cin && !(ka.flags & RP_FLAG_DRAW_ALL) && !ka.single_index && !ka.index_list &&
+                              ka.cost_kind != RP_COST_EXTERNAL;
+        if (cost_kernel_ok) {
+            const char *e = std::getenv("RP_AMD_COST_KERNEL");
+            const int ev = e ? std::atoi(e) : -1;
+            cost_kernel_ok = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * 512);
+        }
         auto launch_main_eval = [&](const KArgs &k, bool mat_) -> int {   // the batch's evaluation kernel, timed if this step is
             c->timed_by_launch = false;
             c->time_next_launch = by_launch;
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);
-            else launch_eval(c, k, grid, mat_, cin, G, block);
+            if (cost_kernel_ok && !mat_ && collision_level(k) == 0) {
+                main_grid = (int)((count + RP_COST_BLOCK - 1) / RP_COST_BLOCK);
+                launch_kargs(c, (const void *)rp_cost_kernel, main_grid, RP_COST_BLOCK, 0, k);
+            } else {
+                main_grid = grid;
+                if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);
+                else launch_eval(c, k, grid, mat_, cin, G, block);
+            }
             if (c->timing) c->t_sum[4] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - te0).count();
             c->time_next_launch = false;
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -873,7 +892,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         c->last_lazy = 0;
         if (lazy_try) {
             int lazy_rounds = 0;
-            if ((rc = run_lazy(c, ka, cin, G, grid, best_states != nullptr, launch_main_eval, &lazy_done, &lazy_rounds)) != RP_OK) return rc;
+            if ((rc = run_lazy(c, ka, cin, G, main_grid, best_states != nullptr, launch_main_eval, &lazy_done, &lazy_rounds)) != RP_OK) return rc;
             if (lazy_done) {
                 c->last_lazy = 1; c->last_rows_on_device = best_states != nullptr;
                 // A stage that needed its third list to find the winner (three rounds and their epilogues, host decisions in
@@ -897,7 +916,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             }
         }
         if (count > 0 && !lazy_done && (rc = launch_main_eval(ka, mat)) != RP_OK) return rc;
-        if (count == 0) n_partials = 0;
+        n_partials = count == 0 ? 0 : main_grid;
     } else {
         n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
         if (count > 0)

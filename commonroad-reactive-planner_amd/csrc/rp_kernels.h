@@ -2473,6 +2473,233 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
 }
 
 // ------------------------------------------------------------------------------------------------
+// rp_cost_kernel -- costs-only evaluation of LARGE grid batches, ONE LANE PER CANDIDATE, the lane walks its candidate's steps.
+//
+// What rp_eval_kernel's layout (a group of 16 lanes per candidate, lane = time step) pays for the time axis lying across lanes --
+// previous-step values through DPP shifts, first-failure votes through ballots and ds_bpermute, the horizon extension's parked
+// state and scans, group-uniform values parked in LDS and re-read, lanes behind step N idle, per-candidate bookkeeping four
+// times per wavefront -- buys coalesced state ROWS.  A plan that keeps no rows (production mode: 12 B per candidate leave the
+// kernel) does not need that: with the time axis inside the lane the previous step is a register, the first failure is the
+// step the loop is at, the extension reads registers, and what is uniform over a (T, longitudinal sample) pair -- the whole
+// profile step -- is the same for (nearly) all lanes of the wavefront.  ~165 vector instructions per (wavefront, step) for 64
+// candidates against ~290 per step block of 16 steps for 4.
+// Arithmetic: expression for expression that of rp_eval_kernel (same labels, reasons, first failing steps, costs).  The cost is
+// summed in rp_eval_kernel's order too -- sixteen partial sums by step mod 16 (one lane of the group each, there), combined in
+// the order of group_sum_last<16> -- so the two kernels agree bit for bit.
+// Grid plans without the collision query (no obstacles, RP_FLAG_SKIP_COLLISION, or the first pass of the cost-ordered stage),
+// no state rows, two-kernel path (profiles from rp_lon_kernel).  One wavefront per workgroup; slot = blockIdx.x * 64 + lane.
+// ------------------------------------------------------------------------------------------------
+#define RP_COST_BLOCK 64
+__global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kernel(const KArgsG ag) {
+    const KArgs &a = ag.k;
+    touch_kernargs<10>();
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;
+    const int lane = threadIdx.x;
+    const int64_t count = a.count;
+    const int64_t w0 = (int64_t)blockIdx.x * RP_COST_BLOCK;
+    if (a.lazy_ctl && blockIdx.x == 0 && lane < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
+        reinterpret_cast<unsigned long long *>(a.lazy_ctl)[lane] = 0ull;
+    const int64_t slot = w0 + lane;
+    const bool valid = slot < count;
+    const int64_t gidx = a.cand_begin + (valid ? slot : w0);   // (lanes behind the batch shadow the wavefront's first candidate)
+    // ---- candidate: lateral sample, pair header, lateral polynomial (sampling.py:226-238, 268-270)
+    const uint32_t g32 = (uint32_t)gidx, nd = (uint32_t)a.nD;
+    const uint32_t p32 = g32 / nd;
+    const double d_target = grid_base(a)[a.nT + a.nL + (int)(g32 - p32 * nd)];
+    const int64_t pair_slot = (int64_t)p32 - a.pair_begin;
+    const PairHdr h = a.pair_hdr[pair_slot];
+    const int L = h.L;
+    const double s0 = h.s0;
+    const uint32_t pre_reason = (uint32_t)h.pre_reason;
+    const Poly lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], d_target, 0.0, 0.0, h.lat_T);
+    double P[16];
+    park_poly(P, lat);
+    const int N = a.N, n = N + 1;
+    const double dt = a.dt;
+    const bool low = a.low_vel_mode != 0;
+    const uint32_t cm = a.constraint_mask;
+    const int mid = n / 2;
+    const double *const prow = a.profile + ((size_t)pair_slot * PF_FIELDS) * (size_t)n;
+
+    auto cost_terms = [&](int i, double acc, double v, double s, double d, double th_cl) -> double {   // (rp_eval_kernel's, word for word)
+        double e, cst;
+        e = a.w_a * acc; cst = e * e;
+        e = 0.25 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+        e = 0.25 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+        if (a.has_speed) { e = 5.0 * (v - a.desired_speed); cst = __builtin_fma(e, e, cst); }
+        if (a.has_s) { e = 0.25 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        if (i == N) {
+            e = 20.0 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+            e = 5.0 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+            if (a.has_speed) { e = v - a.desired_speed; cst += 50.0 * (e * e); }
+            if (a.has_s) { e = 20.0 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        }
+        if (i == mid && a.has_speed) { e = v - a.desired_speed; cst += 100.0 * (e * e); }
+        return cst;
+    };
+
+    int fail_step = -1, ood_step = -1;
+    uint32_t fail_reason = RP_REASON_NONE;
+    // the sixteen partial sums of the cost (step mod 16: what the sixteen lanes of a group hold in rp_eval_kernel) live in LDS,
+    // [k][lane]: the step loop touches one of them per step, by a wave-uniform k (in registers a run-time k costs a chain of 64
+    // selects per step, unrolled sixteen-fold the loop does not fit the instruction cache)
+    __shared__ double sh_csum[16][RP_COST_BLOCK];
+    typedef double __attribute__((address_space(3))) *lds_double;
+    const lds_double csum = (lds_double)&sh_csum[0][lane];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) csum[k * RP_COST_BLOCK] = 0.0;
+    bool alive = valid && pre_reason == RP_REASON_NONE;
+    if (__ballot(alive) != 0) {   // wave-uniform
+        double th_prev = a.x0_orientation, ka_prev = 0.0;
+        // last valid state (step L - 1) for the horizon extension (trajectories.py:168-197, 302-332)
+        double l_v = 0.0, l_acc = 0.0, l_s = 0.0, l_d = 0.0, l_thcl = 0.0, l_sd = 0.0, l_dd = 0.0;
+        // profile rows: wave-uniform row bases (scalar registers) + one 32-bit byte offset per lane (its pair's block)
+        const uint32_t voff = (uint32_t)pair_slot * (uint32_t)PF_FIELDS * (uint32_t)n * 8u;
+        const char *const pb = reinterpret_cast<const char *>(a.profile);
+        const size_t n8 = (size_t)n * 8;
+#pragma nounroll
+        for (int i = 0; i <= N; ++i) {   // wave-uniform
+            const bool act = i < L;
+            const lds_double cs_k = csum + (i & 15) * RP_COST_BLOCK;
+            if (__any(act)) {   // (wave-uniform) some lane's step i is a valid one
+                // -- the pair's profile at this step (the lanes of a pair read the same words)
+                const char *const ob = pb + (size_t)i * 8;
+                auto fld = [&](int k) -> double { return *reinterpret_cast<const double *>(ob + (size_t)k * n8 + voff); };
+                double s = fld(PF_S), sd = fld(PF_SD), sdd = fld(PF_SDD);
+                const double inv_sd = fld(PF_INV_SD), th_ref = fld(PF_TH_REF);
+                const double k_r = fld(PF_KR), k_r_d = fld(PF_KRD);
+                const bool s_in_dom = fld(PF_INDOM) != 0.0;
+                // -- lateral polynomial, reactive_planner.py:756-777
+                const double t = (double)i * dt;
+                const double tau = low ? s - s0 : t;
+                double d = poly_pos(P, tau), dd = poly_vel(P, tau), ddd = poly_acc(P, tau);
+                if (fabs(dd) < RP_EPS) dd = 0.0;
+                // -- d', d'' (:810-832)
+                const bool moving = inv_sd > 0.0;
+                double dp, dpp;
+                if (!low) {
+                    dp = dd * inv_sd;
+                    const double ddot = ddd - dp * sdd;
+                    dpp = ddot * inv_sd * inv_sd;
+                } else {
+                    dp = dd;
+                    dpp = ddd;
+                }
+                // -- orientations (:842-873) incl. the standstill carry of :866
+                const bool use_atan = moving || low;
+                double th_cl = rp_atan(dp);
+                double th_gl = th_cl + th_ref;
+                const double w2 = __builtin_fma(dp, dp, 1.0);
+                double cosT = rp_rsqrt(w2);
+                double secT = w2 * cosT;
+                double tanT = dp;
+                if (__any(act && !use_atan)) {   // standstill lanes keep the orientation of the step before (:866)
+                    if (!use_atan) {
+                        th_gl = th_prev;
+                        th_cl = th_gl - th_ref;
+                    }
+                    double sn, cs;
+                    rp_sincos(th_cl, &sn, &cs);
+                    const double sc = rp_rcp(cs);
+                    cosT = use_atan ? cosT : cs;
+                    secT = use_atan ? secT : sc;
+                    tanT = use_atan ? tanT : sn * sc;
+                }
+                // -- curvature, velocity, acceleration (:883-896)
+                const double oneKrD = 1.0 - k_r * d;
+                const double q = cosT * rp_rcp(oneKrD);
+                const double kterm = k_r_d * d + k_r * dp;
+                double kappa = (dpp + kterm * tanT) * cosT * (q * q) + q * k_r;
+                const double f = oneKrD * secT;
+                double v = sd * f;
+                double acc = sdd * f + (sd * sd * secT) * (oneKrD * tanT * (kappa * f - k_r) - kterm);
+                const double dth = i > 0 ? th_gl - th_prev : 0.0;
+                const double kdot = i > 0 ? kappa - ka_prev : 0.0;
+                // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
+                uint32_t reason = RP_REASON_NONE;
+                {
+                    const double a_max = a.a_max, v_switch = a.v_switch, kappa_max = a.kappa_max;
+                    const double wk = a.wheelbase * kappa;
+                    const bool bad_yaw = fabs(rint(dth * a.c_yaw)) > kappa_max * v * 1e5;
+                    const bool bad_kd = fabs(kdot) > a.c_kdot * __builtin_fma(wk, wk, 1.0);
+                    const bool fast = v > v_switch;
+                    const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
+                    const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
+                    const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
+                    reason = (((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc) ? RP_REASON_ACCELERATION : reason;
+                    reason = (((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd) ? RP_REASON_KAPPA_DOT : reason;
+                    reason = (((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw) ? RP_REASON_YAW_RATE : reason;
+                    reason = (((cm & RP_CHECK_KAPPA) != 0) & bad_k) ? RP_REASON_KAPPA : reason;
+                    reason = (((cm & RP_CHECK_VELOCITY) != 0) & bad_v) ? RP_REASON_VELOCITY : reason;
+                    reason = act ? reason : RP_REASON_NONE;
+                }
+                if (reason != RP_REASON_NONE && fail_step < 0) { fail_step = i; fail_reason = reason; alive = false; }
+                // -- out of the projection domain (:908-917): no reason counter, the kinematic verdict of a later step still counts
+                const bool in_dom = s_in_dom && fabs(d) <= a.proj_d_limit;
+                if (act && !in_dom && ood_step < 0) ood_step = i;
+                if (act) {
+                    *cs_k += cost_terms(i, acc, v, s, d, th_cl);
+                    th_prev = th_gl;
+                    ka_prev = kappa;
+                    if (i == L - 1) { l_v = v; l_acc = acc; l_s = s; l_d = d; l_thcl = th_cl; l_sd = sd; l_dd = dd; }
+                }
+                if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wavefront is decided
+            }
+            if (!act) {   // i >= L: extended state (cost_function.py sums over the extended arrays)
+                const double tk = (double)(i - L + 1) * dt;   // np.arange(1, steps + 1) * dt
+                double vt = l_v + tk * l_acc;                 // :182
+                vt = vt * (vt >= 0.0 ? 1.0 : 0.0);            // :184
+                const double e_s = l_s + tk * l_sd;           // :330
+                const double e_d = l_d + tk * l_dd;           // :331
+                *cs_k += cost_terms(i, l_acc, vt, e_s, e_d, l_thcl);
+            }
+        }
+    }
+    // ---- label, reason, cost
+    uint32_t status;
+    const bool decided_bad = pre_reason != RP_REASON_NONE || fail_step >= 0 || ood_step >= 0;
+    if (pre_reason != RP_REASON_NONE) status = RP_LABEL_NONE | (pre_reason << 4);
+    else if (fail_step >= 0) status = RP_LABEL_INFEASIBLE_KINEMATIC | (fail_reason << 4) | ((uint32_t)fail_step << 8);
+    else if (ood_step >= 0) status = RP_LABEL_NONE | (RP_REASON_OUT_OF_DOMAIN << 4) | ((uint32_t)ood_step << 8);
+    else status = RP_LABEL_FEASIBLE;
+    // the sixteen partial sums in the order of group_sum_last<16> (lane 15's tree: ror 8, 4, 2, 1)
+    double cost;
+    {
+        double s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] = csum[(8 + k) * RP_COST_BLOCK] + csum[k * RP_COST_BLOCK];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] = s8[4 + k] + s8[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) s2[k] = s4[2 + k] + s4[k];
+        cost = s2[1] + s2[0];
+    }
+    if (decided_bad) cost = __builtin_nan("");
+    if (valid) {
+        a.status[slot] = status;
+        a.cost[slot] = cost;
+    }
+    // ---- block partial: lexicographic (cost, index) min + counters of this wavefront
+    if (a.partials) {
+        const uint32_t lab = RP_STATUS_LABEL(status), rs = RP_STATUS_REASON(status);
+        double bc = (valid && lab == RP_LABEL_FEASIBLE && cost == cost) ? cost : 0.0;
+        long long bi = (valid && lab == RP_LABEL_FEASIBLE && cost == cost) ? (long long)gidx : -1;
+        wave_min_pair(bc, bi);
+        const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+        const unsigned int n_feas = (unsigned int)__popcll(__ballot(valid && (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION)));
+        unsigned int mine = 0;
+#pragma unroll
+        for (uint32_t r = 1; r < 8; ++r) {
+            const unsigned int cnt = (unsigned int)__popcll(__ballot(valid && rs == r));
+            mine = lane == (int)(2 + r) ? cnt : mine;
+        }
+        mine = lane == 0 ? n_feas : mine;   // [0] n_feasible, [1] n_collision (none here), [2 + r] reasons
+        if (lane < RP_PARTIAL_CNT) bp.cnt[lane] = mine;
+        if (lane == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Multi-GPU winner exchange on the device (replaces the multiprocessing.Queue fan-in of
 // ReactivePlanner._get_optimal_trajectory, reactive_planner.py:1084-1111): every rank's result block -- FinalizeOut header
 // + winner state rows, exactly what rp_finalize_kernel left in device memory -- has been all-gathered (RCCL) into `msgs`
