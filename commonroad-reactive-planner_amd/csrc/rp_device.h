@@ -91,9 +91,11 @@ struct Poly {
 // QuinticTrajectory._calc_coeffs_static (polynomial_trajectory.py:292-320): closed-form solution of
 // the 3x3 system instead of LAPACK gesv.
 __device__ __forceinline__ Poly quintic_coeffs(double p0, double v0, double a0, double pf, double vf, double af, double T) {
+    // (the fused multiply-adds are spelled out wherever a sum of two products could be contracted either way round: every kernel
+    //  that inlines this function then computes the same bits -- see frenet_kappa in rp_kernels.h)
     const double T2 = T * T;
-    const double bp = pf - (p0 + v0 * T + 0.5 * a0 * T2);
-    const double bv = vf - (v0 + a0 * T);
+    const double bp = pf - __builtin_fma(0.5 * a0, T2, __builtin_fma(v0, T, p0));
+    const double bv = vf - __builtin_fma(a0, T, v0);
     const double ba = af - a0;
     // c3 = (20 bp - 8 T bv + T^2 ba) / (2 T^3), c4 = (-30 bp + 14 T bv - 2 T^2 ba) / (2 T^4),
     // c5 = (12 bp - 6 T bv + T^2 ba) / (2 T^5): one Newton-refined reciprocal of T, then products
@@ -102,22 +104,22 @@ __device__ __forceinline__ Poly quintic_coeffs(double p0, double v0, double a0, 
     const double Tbv = T * bv, T2ba = T2 * ba;
     Poly c;
     c.c0 = p0; c.c1 = v0; c.c2 = 0.5 * a0;
-    c.c3 = (20.0 * bp - 8.0 * Tbv + T2ba) * (0.5 * iT3);
-    c.c4 = (-30.0 * bp + 14.0 * Tbv - 2.0 * T2ba) * (0.5 * iT3 * iT);
-    c.c5 = (12.0 * bp - 6.0 * Tbv + T2ba) * (0.5 * iT3 * iT2);
+    c.c3 = (__builtin_fma(20.0, bp, -(8.0 * Tbv)) + T2ba) * (0.5 * iT3);
+    c.c4 = __builtin_fma(-2.0, T2ba, __builtin_fma(-30.0, bp, 14.0 * Tbv)) * (0.5 * iT3 * iT);
+    c.c5 = (__builtin_fma(12.0, bp, -(6.0 * Tbv)) + T2ba) * (0.5 * iT3 * iT2);
     return c;
 }
 
 // QuarticTrajectory._calc_coeffs_static_ (polynomial_trajectory.py:341-360), closed form of the 2x2.
 __device__ __forceinline__ Poly quartic_coeffs(double p0, double v0, double a0, double T, double vd) {
-    const double bv = vd - v0 - a0 * T;
+    const double bv = __builtin_fma(-a0, T, vd - v0);
     const double ba = -a0;
     const double iT = rp_rcp(T);
     const double iT2 = iT * iT;
     Poly c;
     c.c0 = p0; c.c1 = v0; c.c2 = 0.5 * a0;
-    c.c3 = (3.0 * bv - T * ba) * (iT2 * (1.0 / 3.0));
-    c.c4 = (T * ba - 2.0 * bv) * (0.25 * iT2 * iT);
+    c.c3 = __builtin_fma(3.0, bv, -(T * ba)) * (iT2 * (1.0 / 3.0));
+    c.c4 = __builtin_fma(T, ba, -(2.0 * bv)) * (0.25 * iT2 * iT);
     c.c5 = 0.0;
     return c;
 }

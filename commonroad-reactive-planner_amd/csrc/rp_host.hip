@@ -848,7 +848,8 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             if (cost_kernel_ok && !mat_ && collision_level(k) == 0) {
                 main_grid = (int)((count + RP_COST_BLOCK - 1) / RP_COST_BLOCK);
-                launch_kargs(c, (const void *)rp_cost_kernel, main_grid, RP_COST_BLOCK, 0, k);
+                if (k.low_vel_mode) launch_kargs(c, (const void *)rp_cost_kernel<true>, main_grid, RP_COST_BLOCK, 0, k);
+                else launch_kargs(c, (const void *)rp_cost_kernel<false>, main_grid, RP_COST_BLOCK, 0, k);
             } else {
                 main_grid = grid;
                 if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);

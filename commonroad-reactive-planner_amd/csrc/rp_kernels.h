@@ -1040,6 +1040,20 @@ __global__ __launch_bounds__(RP_GATHER_THREADS) void rp_lazy_gather_kernel(const
     }
 }
 
+// Frenet -> Cartesian curvature and acceleration (reactive_planner.py:883-896) with the fused multiply-adds SPELLED OUT.  Sums of two
+// products -- k_r' d + k_r d', (..) (q q) + q k_r, s'' f + (..)(..) -- can be contracted either way round, and the compiler's choice
+// depends on the code around the expression: two kernels that inline the same source line may then differ in the last bit (seen
+// between rp_eval_kernel and rp_cost_kernel: 44 of 186 968 costs of cfg4 one ulp apart).  These are the forms rp_eval_kernel has
+// always compiled to.
+__device__ __forceinline__ double frenet_kterm(double k_r_d, double d, double k_r, double dp) { return __builtin_fma(k_r_d, d, k_r * dp); }
+__device__ __forceinline__ double frenet_kappa(double dpp, double kterm, double tanT, double cosT, double q, double k_r) {
+    return __builtin_fma(k_r, q, (__builtin_fma(kterm, tanT, dpp) * cosT) * (q * q));
+}
+__device__ __forceinline__ double frenet_acc(double sdd, double f, double sd, double secT, double oneKrD, double tanT, double kappa, double k_r,
+                                             double kterm) {
+    return __builtin_fma(sdd, f, (sd * sd * secT) * __builtin_fma(oneKrD * tanT, __builtin_fma(kappa, f, -k_r), -kterm));
+}
+
 // Per-group LDS scratch of the evaluation kernel.  Values that are identical in all lanes of a group
 // and live for the whole candidate are parked here and re-read (broadcast reads) where they are used.
 //   poly[0..14]  lateral polynomial: c0..c5 | c1, 2c2, 3c3, 4c4, 5c5 | 2c2, 6c3, 12c4, 20c5
@@ -2143,11 +2157,11 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                 // -- curvature, velocity, acceleration (:883-896)
                 const double oneKrD = 1.0 - k_r * d;
                 const double q = cosT * rp_rcp(oneKrD);
-                const double kterm = k_r_d * d + k_r * dp;
-                double kappa = (dpp + kterm * tanT) * cosT * (q * q) + q * k_r;
+                const double kterm = frenet_kterm(k_r_d, d, k_r, dp);
+                double kappa = frenet_kappa(dpp, kterm, tanT, cosT, q, k_r);
                 const double f = oneKrD * secT;
                 double v = sd * f;
-                double acc = sdd * f + (sd * sd * secT) * (oneKrD * tanT * (kappa * f - k_r) - kterm);
+                double acc = frenet_acc(sdd, f, sd, secT, oneKrD, tanT, kappa, k_r, kterm);
 
                 // -- previous-step values for the finite differences (DPP lane shift)
                 double th_prev = lane_prev(th_gl), ka_prev = lane_prev(kappa);
@@ -2490,7 +2504,13 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
 // no state rows, two-kernel path (profiles from rp_lon_kernel).  One wavefront per workgroup; slot = blockIdx.x * 64 + lane.
 // ------------------------------------------------------------------------------------------------
 #define RP_COST_BLOCK 64
-__global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kernel(const KArgsG ag) {
+#ifndef RP_COST_WAVES
+#define RP_COST_WAVES 4   // 128 registers (ten of them spilled): cfg5 442 -> 411 us, cfg4 316 -> 295 us against three wavefronts per SIMD
+#endif
+// LOW: low-velocity mode (the lateral polynomial runs over the arc length, reactive_planner.py:756-772) -- launch-uniform, a template
+// parameter so that the step loop carries no selects for it
+template <bool LOW>
+__global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(const KArgsG ag) {
     const KArgs &a = ag.k;
     touch_kernargs<10>();
     if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;
@@ -2516,10 +2536,14 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kern
     park_poly(P, lat);
     const int N = a.N, n = N + 1;
     const double dt = a.dt;
-    const bool low = a.low_vel_mode != 0;
+    constexpr bool low = LOW;
     const uint32_t cm = a.constraint_mask;
     const int mid = n / 2;
-    const double *const prow = a.profile + ((size_t)pair_slot * PF_FIELDS) * (size_t)n;
+    // Horner steps as three-address v_fma_f64 (rp_math.h: rp_fma3): the coefficients stay where they are -- the compiler's two-address
+    // v_fmac_f64 wants a copy of the coefficient per step (13 v_mov_b64 per time step).  Same operations as poly_pos / poly_vel / poly_acc.
+    auto p_pos = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(rp_fma3(rp_fma3(P[5], t, P[4]), t, P[3]), t, P[2]), t, P[1]), t, P[0]); };
+    auto p_vel = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(rp_fma3(P[10], t, P[9]), t, P[8]), t, P[7]), t, P[6]); };
+    auto p_acc = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(P[14], t, P[13]), t, P[12]), t, P[11]); };
 
     auto cost_terms = [&](int i, double acc, double v, double s, double d, double th_cl) -> double {   // (rp_eval_kernel's, word for word)
         double e, cst;
@@ -2572,7 +2596,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kern
                 // -- lateral polynomial, reactive_planner.py:756-777
                 const double t = (double)i * dt;
                 const double tau = low ? s - s0 : t;
-                double d = poly_pos(P, tau), dd = poly_vel(P, tau), ddd = poly_acc(P, tau);
+                double d = p_pos(tau), dd = p_vel(tau), ddd = p_acc(tau);
                 if (fabs(dd) < RP_EPS) dd = 0.0;
                 // -- d', d'' (:810-832)
                 const bool moving = inv_sd > 0.0;
@@ -2593,7 +2617,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kern
                 double cosT = rp_rsqrt(w2);
                 double secT = w2 * cosT;
                 double tanT = dp;
-                if (__any(act && !use_atan)) {   // standstill lanes keep the orientation of the step before (:866)
+                if (!low && __any(act && !use_atan)) {   // standstill lanes keep the orientation of the step before (:866)
                     if (!use_atan) {
                         th_gl = th_prev;
                         th_cl = th_gl - th_ref;
@@ -2608,11 +2632,11 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kern
                 // -- curvature, velocity, acceleration (:883-896)
                 const double oneKrD = 1.0 - k_r * d;
                 const double q = cosT * rp_rcp(oneKrD);
-                const double kterm = k_r_d * d + k_r * dp;
-                double kappa = (dpp + kterm * tanT) * cosT * (q * q) + q * k_r;
+                const double kterm = frenet_kterm(k_r_d, d, k_r, dp);
+                double kappa = frenet_kappa(dpp, kterm, tanT, cosT, q, k_r);
                 const double f = oneKrD * secT;
                 double v = sd * f;
-                double acc = sdd * f + (sd * sd * secT) * (oneKrD * tanT * (kappa * f - k_r) - kterm);
+                double acc = frenet_acc(sdd, f, sd, secT, oneKrD, tanT, kappa, k_r, kterm);
                 const double dth = i > 0 ? th_gl - th_prev : 0.0;
                 const double kdot = i > 0 ? kappa - ka_prev : 0.0;
                 // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
@@ -2641,7 +2665,11 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_WAVES_PER_SIMD) void rp_cost_kern
                     *cs_k += cost_terms(i, acc, v, s, d, th_cl);
                     th_prev = th_gl;
                     ka_prev = kappa;
-                    if (i == L - 1) { l_v = v; l_acc = acc; l_s = s; l_d = d; l_thcl = th_cl; l_sd = sd; l_dd = dd; }
+                }
+                if (__any(i == L - 1)) {   // (wave-uniform; the lanes of a wavefront belong to one or two pairs: one or two such steps)
+                    const bool lastv = i == L - 1;
+                    l_v = lastv ? v : l_v; l_acc = lastv ? acc : l_acc; l_s = lastv ? s : l_s; l_d = lastv ? d : l_d;
+                    l_thcl = lastv ? th_cl : l_thcl; l_sd = lastv ? sd : l_sd; l_dd = lastv ? dd : l_dd;
                 }
                 if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wavefront is decided
             }
