@@ -830,26 +830,35 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         // the evaluation kernel's duration: events attached to the launch itself (hipExtModuleLaunchKernel; RP_AMD_EVENT_BRACKET=1:
         // two hipEventRecord around it, which adds the dispatch and completion handling of the bracket -- ~2.5 us on a 14-us kernel)
         const bool by_launch = timed && count > 0 && !std::getenv("RP_AMD_EVENT_BRACKET");
-        // Costs-only launches of large grid batches -- no state rows, no collision query: production-mode plans without obstacles and
-        // the first pass of the cost-ordered stage -- take rp_cost_kernel: one lane per candidate, the lane walks the steps
-        // (rp_kernels.h).  It needs wavefronts of 64 candidates to fill the chip: from 131 072 candidates (two per SIMD) on;
-        // RP_AMD_COST_KERNEL=0 / 1 never / whenever the variant applies (tests).
+        // Launches of large grid batches that keep no state rows -- production-mode plans, the first pass of the cost-ordered stage --
+        // take rp_cost_kernel: one lane per candidate, the lane walks the steps (rp_kernels.h).  It needs about one wavefront of 64
+        // candidates per SIMD to beat the 16-lane kernel (profiles/probe_cost_threshold.py: N = 60, 62 496 candidates 1.10 x;
+        // N = 100, 65 024: 0.90 x, 130 048: 1.23 x, 512 064: 1.62 x): from 61 440 candidates on for horizons of up to 64 steps,
+        // 98 304 beyond.  RP_AMD_COST_KERNEL=0 / 1: never / whenever the variant applies (tests).
+        // (WITH the eager collision query the walk over the obstacles is a chain of round trips per step: the 16-lane kernel, which
+        //  asks for sixteen steps of four candidates at a time, stays ahead until the batch fills the chip several times over --
+        //  profiles/probe_cost_kernel.py: cfg3 140 vs 195 us, cfg3f 165 vs 235 us, cfg5 + 50 obstacles 1 735 vs 1 147 us: from 262 144 candidates)
+        bool cost_kernel_big = false;
         bool cost_kernel_ok = count > 0 && !fused_lds && !cin && !(ka.flags & RP_FLAG_DRAW_ALL) && !ka.single_index && !ka.index_list &&
                               ka.cost_kind != RP_COST_EXTERNAL;
         if (cost_kernel_ok) {
             const char *e = std::getenv("RP_AMD_COST_KERNEL");
             const int ev = e ? std::atoi(e) : -1;
-            cost_kernel_ok = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * 512);
+            cost_kernel_ok = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * (ka.N + 1 <= 64 ? 240 : 384));
+            cost_kernel_big = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * 1024);
         }
         auto launch_main_eval = [&](const KArgs &k, bool mat_) -> int {   // the batch's evaluation kernel, timed if this step is
             c->timed_by_launch = false;
             c->time_next_launch = by_launch;
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (cost_kernel_ok && !mat_ && collision_level(k) == 0) {
+            if (cost_kernel_ok && !mat_ && (collision_level(k) == 0 || cost_kernel_big)) {
                 main_grid = (int)((count + RP_COST_BLOCK - 1) / RP_COST_BLOCK);
-                if (k.low_vel_mode) launch_kargs(c, (const void *)rp_cost_kernel<true>, main_grid, RP_COST_BLOCK, 0, k);
-                else launch_kargs(c, (const void *)rp_cost_kernel<false>, main_grid, RP_COST_BLOCK, 0, k);
+                const int coll = collision_level(k);
+                const void *fn = k.low_vel_mode
+                    ? (coll == 2 ? (const void *)rp_cost_kernel<true, 2> : coll == 1 ? (const void *)rp_cost_kernel<true, 1> : (const void *)rp_cost_kernel<true, 0>)
+                    : (coll == 2 ? (const void *)rp_cost_kernel<false, 2> : coll == 1 ? (const void *)rp_cost_kernel<false, 1> : (const void *)rp_cost_kernel<false, 0>);
+                launch_kargs(c, fn, main_grid, RP_COST_BLOCK, 0, k);
             } else {
                 main_grid = grid;
                 if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);

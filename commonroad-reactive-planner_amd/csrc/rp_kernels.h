@@ -1049,6 +1049,9 @@ __device__ __forceinline__ double frenet_kterm(double k_r_d, double d, double k_
 __device__ __forceinline__ double frenet_kappa(double dpp, double kterm, double tanT, double cosT, double q, double k_r) {
     return __builtin_fma(k_r, q, (__builtin_fma(kterm, tanT, dpp) * cosT) * (q * q));
 }
+// cos / sin of the heading theta_ref + theta_cl from cos / sin of both (sums of two products: spelled out, see above)
+__device__ __forceinline__ double heading_cos(double cos_ref, double sin_ref, double cosT, double sinT) { return __builtin_fma(cos_ref, cosT, -(sin_ref * sinT)); }
+__device__ __forceinline__ double heading_sin(double cos_ref, double sin_ref, double cosT, double sinT) { return __builtin_fma(sin_ref, cosT, cos_ref * sinT); }
 __device__ __forceinline__ double frenet_acc(double sdd, double f, double sd, double secT, double oneKrD, double tanT, double kappa, double k_r,
                                              double kterm) {
     return __builtin_fma(sdd, f, (sd * sd * secT) * __builtin_fma(oneKrD * tanT, __builtin_fma(kappa, f, -k_r), -kterm));
@@ -2150,8 +2153,8 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                 // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref (variants with a
                 // collision query; the others need them for one lane per candidate only, where the extension starts)
                 const double sinT = tanT * cosT;
-                double cos_gl = pf.f[PF_COS_REF] * cosT - pf.f[PF_SIN_REF] * sinT;
-                double sin_gl = pf.f[PF_SIN_REF] * cosT + pf.f[PF_COS_REF] * sinT;
+                double cos_gl = heading_cos(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
+                double sin_gl = heading_sin(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
                 RP_STAMP(5);   // atan + carry
 
                 // -- curvature, velocity, acceleration (:883-896)
@@ -2509,8 +2512,11 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
 #endif
 // LOW: low-velocity mode (the lateral polynomial runs over the arc length, reactive_planner.py:756-772) -- launch-uniform, a template
 // parameter so that the step loop carries no selects for it
-template <bool LOW>
-__global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(const KArgsG ag) {
+// COLL: 0 no collision query, 1 dynamic obstacles only, 2 static shapes as well (as rp_eval_kernel's): the eager query for every
+// pose of every candidate (reactive_planner.py:1033-1046) -- the lanes of a wavefront stand at the SAME step, so the (pair, step)
+// mask, the obstacle rows and the walk over them are (nearly) uniform over the wavefront.
+template <bool LOW, int COLL>
+__global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_WAVES) void rp_cost_kernel(const KArgsG ag) {
     const KArgs &a = ag.k;
     touch_kernargs<10>();
     if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;
@@ -2564,6 +2570,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
 
     int fail_step = -1, ood_step = -1;
     uint32_t fail_reason = RP_REASON_NONE;
+    bool collide = false;
     // the sixteen partial sums of the cost (step mod 16: what the sixteen lanes of a group hold in rp_eval_kernel) live in LDS,
     // [k][lane]: the step loop touches one of them per step, by a wave-uniform k (in registers a run-time k costs a chain of 64
     // selects per step, unrolled sixteen-fold the loop does not fit the instruction cache)
@@ -2577,6 +2584,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
         double th_prev = a.x0_orientation, ka_prev = 0.0;
         // last valid state (step L - 1) for the horizon extension (trajectories.py:168-197, 302-332)
         double l_v = 0.0, l_acc = 0.0, l_s = 0.0, l_d = 0.0, l_thcl = 0.0, l_sd = 0.0, l_dd = 0.0;
+        double l_x = 0.0, l_y = 0.0, l_cos = 1.0, l_sin = 0.0, cumx = 0.0, cumy = 0.0;   // (COLL: poses of the extended steps)
         // profile rows: wave-uniform row bases (scalar registers) + one 32-bit byte offset per lane (its pair's block)
         const uint32_t voff = (uint32_t)pair_slot * (uint32_t)PF_FIELDS * (uint32_t)n * 8u;
         const char *const pb = reinterpret_cast<const char *>(a.profile);
@@ -2585,10 +2593,11 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
         for (int i = 0; i <= N; ++i) {   // wave-uniform
             const bool act = i < L;
             const lds_double cs_k = csum + (i & 15) * RP_COST_BLOCK;
+            const char *const ob = pb + (size_t)i * 8;
+            auto fld = [&](int k) -> double { return *reinterpret_cast<const double *>(ob + (size_t)k * n8 + voff); };
+            double pose_x = 0.0, pose_y = 0.0, pose_cos = 1.0, pose_sin = 0.0;   // (COLL) rear-axle pose of this lane at step i
             if (__any(act)) {   // (wave-uniform) some lane's step i is a valid one
                 // -- the pair's profile at this step (the lanes of a pair read the same words)
-                const char *const ob = pb + (size_t)i * 8;
-                auto fld = [&](int k) -> double { return *reinterpret_cast<const double *>(ob + (size_t)k * n8 + voff); };
                 double s = fld(PF_S), sd = fld(PF_SD), sdd = fld(PF_SDD);
                 const double inv_sd = fld(PF_INV_SD), th_ref = fld(PF_TH_REF);
                 const double k_r = fld(PF_KR), k_r_d = fld(PF_KRD);
@@ -2661,6 +2670,13 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
                 // -- out of the projection domain (:908-917): no reason counter, the kinematic verdict of a later step still counts
                 const bool in_dom = s_in_dom && fabs(d) <= a.proj_d_limit;
                 if (act && !in_dom && ood_step < 0) ood_step = i;
+                if (COLL) {   // (s, d) -> (x, y) = foot point + d * unit normal (:908-917); heading from cos / sin of theta_ref and theta_cl
+                    const double sinT = tanT * cosT;
+                    pose_x = fld(PF_PX) + d * fld(PF_NX);
+                    pose_y = fld(PF_PY) + d * fld(PF_NY);
+                    pose_cos = heading_cos(fld(PF_COS_REF), fld(PF_SIN_REF), cosT, sinT);
+                    pose_sin = heading_sin(fld(PF_COS_REF), fld(PF_SIN_REF), cosT, sinT);
+                }
                 if (act) {
                     *cs_k += cost_terms(i, acc, v, s, d, th_cl);
                     th_prev = th_gl;
@@ -2670,6 +2686,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
                     const bool lastv = i == L - 1;
                     l_v = lastv ? v : l_v; l_acc = lastv ? acc : l_acc; l_s = lastv ? s : l_s; l_d = lastv ? d : l_d;
                     l_thcl = lastv ? th_cl : l_thcl; l_sd = lastv ? sd : l_sd; l_dd = lastv ? dd : l_dd;
+                    if (COLL) { l_x = lastv ? pose_x : l_x; l_y = lastv ? pose_y : l_y; l_cos = lastv ? pose_cos : l_cos; l_sin = lastv ? pose_sin : l_sin; }
                 }
                 if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wavefront is decided
             }
@@ -2680,6 +2697,27 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
                 const double e_s = l_s + tk * l_sd;           // :330
                 const double e_d = l_d + tk * l_dd;           // :331
                 *cs_k += cost_terms(i, l_acc, vt, e_s, e_d, l_thcl);
+                if (COLL) {   // x[L:] = x[last] + cumsum(dt * v_tmp * cos(theta[last])), same for y (:195-196); heading held (:188)
+                    cumx += dt * vt * l_cos;
+                    cumy += dt * vt * l_sin;
+                    pose_x = l_x + cumx; pose_y = l_y + cumy; pose_cos = l_cos; pose_sin = l_sin;
+                }
+            }
+            // -- eager collision query for this pose, reactive_planner.py:1033-1046 (a candidate that has collided is not asked again:
+            //    the label is all the reference keeps of a collision; the kinematic checks -- which can still turn it into
+            //    INFEASIBLE_KINEMATIC -- go on)
+            if (COLL) {
+                const bool want = alive && fail_step < 0 && ood_step < 0 && !collide;
+                const double ego_cx = pose_x + a.wb_rear_axle * pose_cos, ego_cy = pose_y + a.wb_rear_axle * pose_sin;
+                const uint64_t near_dyn = want ? double_as_mask(fld(PF_NEAR)) : 0;
+                uint64_t near_sta = 0;
+                if (COLL == 2 && want)
+                    near_sta = static_grid_mask(a.obs.grid, a.obs.gx0, a.obs.gy0, a.obs.ginv, a.obs.gnx, a.obs.gny, ego_cx, ego_cy);
+                const bool ask = want && (near_dyn | near_sta) != 0;
+                if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
+                    const Obb ego = {ego_cx, ego_cy, pose_cos, pose_sin, a.half_length, a.half_width};
+                    collide |= pose_collides<true, COLL == 2, false, true>(a.obs, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
+                }
             }
         }
     }
@@ -2689,7 +2727,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
     if (pre_reason != RP_REASON_NONE) status = RP_LABEL_NONE | (pre_reason << 4);
     else if (fail_step >= 0) status = RP_LABEL_INFEASIBLE_KINEMATIC | (fail_reason << 4) | ((uint32_t)fail_step << 8);
     else if (ood_step >= 0) status = RP_LABEL_NONE | (RP_REASON_OUT_OF_DOMAIN << 4) | ((uint32_t)ood_step << 8);
-    else status = RP_LABEL_FEASIBLE;
+    else status = collide ? RP_LABEL_INFEASIBLE_COLLISION : RP_LABEL_FEASIBLE;
     // the sixteen partial sums in the order of group_sum_last<16> (lane 15's tree: ror 8, 4, 2, 1)
     double cost;
     {
@@ -2721,7 +2759,9 @@ __global__ __launch_bounds__(RP_COST_BLOCK, RP_COST_WAVES) void rp_cost_kernel(c
             const unsigned int cnt = (unsigned int)__popcll(__ballot(valid && rs == r));
             mine = lane == (int)(2 + r) ? cnt : mine;
         }
-        mine = lane == 0 ? n_feas : mine;   // [0] n_feasible, [1] n_collision (none here), [2 + r] reasons
+        mine = lane == 0 ? n_feas : mine;   // [0] n_feasible, [1] n_collision, [2 + r] reasons
+        const unsigned int n_coll = (unsigned int)__popcll(__ballot(valid && lab == RP_LABEL_INFEASIBLE_COLLISION));
+        mine = lane == 1 ? n_coll : mine;
         if (lane < RP_PARTIAL_CNT) bp.cnt[lane] = mine;
         if (lane == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
     }

@@ -13,9 +13,12 @@ for name in names:
     ctx = RpContext(0)
     w.setup(ctx)
     got = {}
-    for skip in (True, False):
+    for skip in (True, False, "eager"):
         p = copy_params(w.inputs.params)
-        if skip:
+        os.environ.pop("RP_AMD_LAZY", None)
+        if skip == "eager":   # production mode with the eager collision query pinned (RP_AMD_LAZY=0)
+            os.environ["RP_AMD_LAZY"] = "0"
+        elif skip:
             p.flags |= FLAG_SKIP_COLLISION
         inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
         for ck in ("0", "1"):
@@ -29,9 +32,9 @@ for name in names:
             st, cs = ctx.fetch_status()
             got[(skip, ck)] = (st, cs, out, dt, ctx.last_path())
         a, b = got[(skip, "0")], got[(skip, "1")]
-        same_status = np.array_equal(a[0], b[0]) if a[4] == b[4] == 0 or skip else None
+        same_status = np.array_equal(a[0], b[0]) if (a[4] == b[4] == 0 or skip is True) else None
         same_cost = np.array_equal(a[1].view(np.uint64), b[1].view(np.uint64))
-        print(f"{name:8s} {'no collision query' if skip else 'production mode    '} C={len(a[0]):8d}  16 lanes/candidate {a[3]*1e6:8.1f} us  "
+        print(f"{name:8s} {'no collision query' if skip is True else ('eager query pinned ' if skip == 'eager' else 'production mode    ')} C={len(a[0]):8d}  16 lanes/candidate {a[3]*1e6:8.1f} us  "
               f"lane per candidate {b[3]*1e6:8.1f} us  ({a[3]/b[3]:.2f} x)  status identical: {same_status}  cost bits identical: {same_cost}  "
               f"winner {a[2].best_index} / {b[2].best_index}  paths {a[4]}/{b[4]}", flush=True)
     ctx.close()
