@@ -13,7 +13,7 @@ states), not one repeated input.  A timed region is exactly K steps; regions are
 
 N = 1 (default): headline = cfg3 (BASELINE.json configs[2], the largest configuration tagged 1 x MI355X) in draw mode, plus --
 in the same JSON line --
-  ``configs``          draw- and production-mode records of cfg2, cfg2 + road boundary, cfg3f (cfg3's grid in mostly-free traffic),
+  ``configs``          draw- and production-mode records of cfg1, cfg2, cfg3f (cfg3's grid in mostly-free traffic), <cfg>rb (cfg2, cfg3, cfg3f, cfg4 with the road boundary),
                        cfg4, cfg5, each with its own roofline
   ``fused_mode``       the headline workload in production mode (12 B per candidate leave the kernel)
   ``plan_latency_ms``  p50 / p90 of ReactivePlanner.plan() over closed-loop replans (Python boundary included)
@@ -52,8 +52,8 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # half the FP32 vector peak of the same table (157.3 TFLOPS): 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2.4 GHz
 # counter files written by profiles/collect_pmc.sh / collect_fp64.sh; every entry names the hash of the sources of the library it
 # was measured on (rp_source_hash): an entry is reported only when that is the library this run has loaded
-PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
-FLOP_FILE = os.path.join(REPO, "profiles", "r03_fp64_flops.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+FLOP_FILE = os.path.join(REPO, "profiles", "r04_fp64_flops.json")
 
 
 def parse_args():
@@ -197,26 +197,28 @@ def counter_entry(path, key):
     return e, None
 
 
-def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_ms, single_gpu=True):
-    """Roofline of rp_eval_kernel for one record.  draw / materialize: HBM write stream, algorithmic bytes per launch
-     / average kernel duration (HIP events inside rp_plan, on the context's stream).  fused: 12 B per candidate
-    leave the kernel, the kernel is FP64-VALU bound: counted FP64 flops of the executed instruction stream per (candidate,
-    step) (profiles/count_fp64.py over the disassembly of the variant this workload takes; profiles/r02_fp64_flops.json)
-    x candidates x steps / kernel duration against the FP64 vector peak."""
+def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_ms, single_gpu=True, kernel="rp_eval_kernel"):
+    """Roofline of the kernel that evaluates the batch (``kernel``: rp_last_kernel of the record's steps) for one record.
+    draw / materialize: HBM write stream, algorithmic bytes per launch / average kernel duration (HIP events inside
+    rp_plan, on the context's stream).  fused: 12 B per candidate leave the kernel, the kernel is FP64-VALU bound: counted FP64
+    flops of the executed instruction stream per (candidate, step) (SQ counters of the kernel this workload takes,
+    profiles/fp64_summary.py -> FLOP_FILE) x candidates x steps / kernel duration against the FP64 vector peak."""
     blk = 112 * n_steps_plus1
     pmc, stale = counter_entry(PMC_FILE, f"{name}:{mode}") if single_gpu else (None, None)
     traffic = pmc.get("traffic_bytes") if pmc else None
     extra = {"stale_profile": stale} if stale else {}
     if mode == "fused":
-        # (cfg2 + road boundary: the flop count of plain cfg2 -- the static-shape walk adds tests, so the fraction is a lower bound)
-        fl, stale_f = counter_entry(FLOP_FILE, "cfg2" if name == "cfg2rb" else name)
+        # (<name>rb, road boundary, when it has no count of its own: the flop count of the plain workload -- the static-shape walk adds tests, so the fraction is a lower bound)
+        fl, stale_f = counter_entry(FLOP_FILE, name)
+        if fl is None and name.endswith("rb"):
+            fl, stale_f = counter_entry(FLOP_FILE, name[:-2])
         if stale_f:
             extra = {"stale_profile": stale_f}
         if fl and kernel_ms > 0:
             flops = float(fl["flops_per_candidate_step"]) * cand_mean * n_steps_plus1
             ach = flops / (kernel_ms * 1e-3) / 1e12
             return {"bound": "valu", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VALU_PEAK_TFLOPS,
-                    "traffic": traffic, "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "flops_per_launch": flops,
+                    "traffic": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "flops_per_launch": flops,
                     "flops_per_candidate_step": fl["flops_per_candidate_step"], "flop_model": fl.get("model"), **extra}
         bytes_per_launch = cand_mean * 12
     elif mode == "draw":
@@ -225,7 +227,7 @@ def roofline_record(name, mode, n_steps_plus1, cand_mean, feasible_mean, kernel_
         bytes_per_launch = cand_mean * 12 + feasible_mean * blk
     ach = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else float("nan")
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "rp_eval_kernel", "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, **extra}
+            "kernel": kernel, "kernel_ms": kernel_ms, "bytes_per_launch": bytes_per_launch, **extra}
 
 
 def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, profile_every=8, caller="c"):
@@ -266,7 +268,8 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
            "caller": "compiled host loop over the C ABI (rp_hostloop.c)" if region is not None else "Python binding (ctypes), one call per step",
            # how the steps answered the collision query: eager (every pose of every candidate), cost-ordered stage, stage + eager fallback
            "collision_path_steps": {"eager": paths[0], "cost_ordered": paths[1], "cost_ordered_then_eager": paths[2]},
-           "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms)}
+           "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms,
+                                       kernel=ctx.last_kernel())}
     return rec
 
 
@@ -322,7 +325,8 @@ def run_single(args, torch, device):
     sync = torch.cuda.synchronize
     seq = W.replan_sequence(base, args.sequence, device=device)
     base.setup(ctx)
-    head = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, args.min_seconds, sync, caller=args.caller)
+    key = name + ("rb" if args.road_boundary else "")   # (the counter files' key of this workload)
+    head = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, args.min_seconds, sync, name=key, caller=args.caller)
     N = base.inputs.params.N
     result = {
         "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
@@ -337,13 +341,19 @@ def run_single(args, torch, device):
         "timing": dict(head["spread_ms"], what="K-step regions bracketed by device syncs, repeated until min-seconds; ms_per_step = median region",
                        caller=head["caller"]),
         "roofline": head["roofline"],
+        # what "value" has meant round by round (rounds 1-2 are not comparable with 3-4 on `value`; the riders keep the old lines)
+        "headline_definition": {"since_round": 3, "workload": "cfg3 (BASELINE.json configs[2]), draw mode", "caller": "compiled host loop over the C ABI",
+                                "n_gpus_gt_1": "weak scaling",
+                                "changed_from": {"rounds": "1-2", "workload": "cfg2 (configs[1]), draw mode", "caller": "Python binding (ctypes)",
+                                                 "n_gpus_gt_1": "strong scaling on cfg4"},
+                                "old_definition_rides_in": ["configs.cfg2", "python_binding", "strong"]},
     }
     if not args.main_only:
         if args.caller == "c":   # the same regions with the Python binding making the calls (what round 1 and 2 reported)
-            py = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, min(args.min_seconds, 0.5), sync, caller="python")
+            py = run_record(ctx, base, seq, args.mode, args.steps, args.warmup, min(args.min_seconds, 0.5), sync, name=key, caller="python")
             result["python_binding"] = {k: py[k] for k in ("ms_per_step", "value", "unit", "caller", "kernel_ms")}
         if args.mode != "fused":
-            result["fused_mode"] = run_record(ctx, base, seq, "fused", args.steps, args.warmup, args.min_seconds, sync)
+            result["fused_mode"] = run_record(ctx, base, seq, "fused", args.steps, args.warmup, args.min_seconds, sync, name=key)
         ctx.close()
         ctx = None
         if not args.no_configs:
@@ -368,12 +378,15 @@ def side_configs(args, torch, device, skip):
     from commonroad_rp_amd import workloads as W
     from commonroad_rp_amd._capi import RpContext
     out = {}
-    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.2, "cfg3f": 0.2, "cfg4": 1.4, "cfg5": 2.5}
-    # (cfg2rb: the T-junction with its road boundary in the obstacle tables, 85 thin rectangles from the lanelet network)
-    for name in ("cfg1", "cfg2", "cfg2rb", "cfg3", "cfg3f", "cfg4", "cfg5"):   # (cfg1: the size of the reference's shipped configurations, N = 20)
+    guess = {"cfg1": 0.03, "cfg2": 0.04, "cfg2rb": 0.05, "cfg3": 0.2, "cfg3rb": 0.2, "cfg3f": 0.2, "cfg3frb": 0.2, "cfg4": 1.4, "cfg4rb": 1.6, "cfg5": 2.5}
+    # <name>rb: the scenario's road boundary in the static obstacle tables (thin rectangles along the outer border of the lanelet
+    # network, what the reference's collision checker holds by default: reactive_planner.py:246-250) -- cfg2 / cfg4 (T-junction) 85
+    # rectangles, cfg3 (DEU_Test) 8.  With the boundary no candidate of cfg3 survives (the reference's own answer,
+    # tests/golden/cfg3_ref_rb.npz); cfg3frb -- cfg3's grid, mostly-free traffic -- keeps 30 070 of 61 271.
+    for name in ("cfg1", "cfg2", "cfg2rb", "cfg3", "cfg3rb", "cfg3f", "cfg3frb", "cfg4", "cfg4rb", "cfg5"):   # (cfg1: the size of the reference's shipped configurations, N = 20)
         if name == skip:
             continue
-        w = W.cfg2(road_boundary=True) if name == "cfg2rb" else W.WORKLOADS[name]()
+        w = W.WORKLOADS[name[:-2]](road_boundary=True) if name.endswith("rb") else W.WORKLOADS[name]()
         ctx = RpContext(device)
         w.setup(ctx)
         seq = W.replan_sequence(w, 16 if name != "cfg5" else 8, device=device)
@@ -610,7 +623,7 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
                 "value": cand / (sp["median"] * 1e-3), "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms,
                 "caller": caller,
                 "exchange": type(ex).__name__, "exchange_ms_per_step": float(np.median(t_ex) * 1e3) if t_ex else None,
-                "roofline": roofline_record(w.name, mode, n1, loc, 0.0, kernel_ms, single_gpu=False)}
+                "roofline": roofline_record(w.name, mode, n1, loc, 0.0, kernel_ms, single_gpu=False, kernel=ctx.last_kernel())}
 
     def sequence(w, n, nL=None):
         """rank 0 drives the closed loop, every rank gets the same inputs"""

@@ -213,6 +213,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_last_error": (C.c_char_p, [ctx]),
         "rp_set_profiling": (C.c_int, [ctx, C.c_int]),
         "rp_last_path": (C.c_int, [ctx]),
+        "rp_last_kernel": (C.c_int, [ctx]),
         "rp_set_collision_path": (C.c_int, [ctx, C.c_int]),
         "rp_set_reference": (C.c_int, [ctx, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double]),
         "rp_set_obstacles": (C.c_int, [ctx, C.c_int32, dp, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32,
@@ -274,10 +275,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+_OPTIONAL_IN_AB_BUILDS = ("rp_last_kernel", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
                           "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
                           "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
-EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path", "rp_set_collision_path",
+EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path", "rp_last_kernel", "rp_set_collision_path",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
@@ -463,6 +464,12 @@ class RpContext:
         candidates in ascending cost until the first free one), 2 cost-ordered stage exhausted, eager kernel decided."""
         fn = getattr(self._lib, "rp_last_path", None)
         return int(fn(self._h)) if fn is not None else 0
+
+    def last_kernel(self) -> str:
+        """``rp_last_kernel``: the kernel that evaluated the batch of the last plan -- "rp_eval_kernel" (lanes over time steps) or
+        "rp_cost_kernel" (one lane per candidate; large batches that keep costs and labels only)."""
+        fn = getattr(self._lib, "rp_last_kernel", None)
+        return "rp_cost_kernel" if fn is not None and int(fn(self._h)) == 1 else "rp_eval_kernel"
 
     def set_collision_path(self, mode: int):
         """``rp_set_collision_path``: how production-mode plans of large batches answer the collision query -- COLLISION_AUTO

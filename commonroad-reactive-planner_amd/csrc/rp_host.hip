@@ -102,6 +102,7 @@ struct rp_ctx {
     size_t cap_lazy_states = 0;
     int lazy_skip = 0, lazy_penalty = 0;   // plans that go eager straight away after a lazy attempt had to fall back (doubles per failure, up to 64)
     int collision_mode = RP_COLLISION_AUTO;   // rp_set_collision_path
+    int last_kernel = 0;                   // rp_last_kernel: which kernel evaluated the last plan's batch (RP_KERNEL_*)
     int last_lazy = 0;                     // 0: the last plan ran eager, 1: lazy, 2: lazy attempt + eager fallback (diagnostic, rp_last_path)
     double last_best_cost = 0.0;           // winner of the last collected plan (rp_count_collisions_before after a cost-ordered plan)
     int64_t last_best_index = -1;
@@ -854,6 +855,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             if (cost_kernel_ok && !mat_ && (collision_level(k) == 0 || cost_kernel_big)) {
                 main_grid = (int)((count + RP_COST_BLOCK - 1) / RP_COST_BLOCK);
+                c->last_kernel = RP_KERNEL_COST;
                 const int coll = collision_level(k);
                 const void *fn = k.low_vel_mode
                     ? (coll == 2 ? (const void *)rp_cost_kernel<true, 2> : coll == 1 ? (const void *)rp_cost_kernel<true, 1> : (const void *)rp_cost_kernel<true, 0>)
@@ -861,6 +863,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
                 launch_kargs(c, fn, main_grid, RP_COST_BLOCK, 0, k);
             } else {
                 main_grid = grid;
+                c->last_kernel = RP_KERNEL_EVAL;
                 if (fused_lds) launch_eval_fused(c, k, grid, mat_, cin, fused_lds, G);
                 else launch_eval(c, k, grid, mat_, cin, G, block);
             }
@@ -1200,6 +1203,7 @@ void rp_destroy(rp_ctx *c) {
 const char *rp_last_error(const rp_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int rp_last_path(const rp_ctx *c) { return c ? c->last_lazy : 0; }
+int rp_last_kernel(const rp_ctx *c) { return c ? c->last_kernel : 0; }
 
 int rp_set_collision_path(rp_ctx *c, int mode) {
     if (!c) return RP_EINVAL;

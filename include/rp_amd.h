@@ -271,6 +271,13 @@ int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *
 #define RP_PATH_LAZY 1
 #define RP_PATH_LAZY_FALLBACK 2
 int rp_last_path(const rp_ctx *ctx);
+/* Which kernel evaluated the batch of the last plan (diagnostic: what a measurement prices the plan against).
+ *   RP_KERNEL_EVAL  rp_eval_kernel: 16 / 32 / 64 lanes per candidate, a lane per time step (every plan that keeps state rows)
+ *   RP_KERNEL_COST  rp_cost_kernel: one lane per candidate walking the steps (large batches that keep costs and labels only)
+ * Results are the same bits either way. */
+#define RP_KERNEL_EVAL 0
+#define RP_KERNEL_COST 1
+int rp_last_kernel(const rp_ctx *ctx);
 #define RP_COLLISION_AUTO 0
 #define RP_COLLISION_EAGER 1
 #define RP_COLLISION_COST_ORDERED 2

@@ -6,6 +6,8 @@
 set -e
 WL=${1:-cfg5}; STEPS=${2:-6}; MODE=${3:-fused}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/fp64_${WL}_$MODE
+# <workload>rb: the workload with its road boundary (bench.py --road-boundary)
+BASE=$WL; RB=""; case $WL in *rb) BASE=${WL%rb}; RB=--road-boundary;; esac
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES --output-format csv -d $OUT/a -- python3 $ROOT/bench.py --workload $WL --mode $MODE --steps $STEPS --warmup 3 --min-seconds 0 --sequence 8 --main-only > $OUT.bench.json 2> $OUT.err
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVES --output-format csv -d $OUT/a -- python3 $ROOT/bench.py --workload $BASE $RB --mode $MODE --steps $STEPS --warmup 3 --min-seconds 0 --sequence 8 --main-only > $OUT.bench.json 2> $OUT.err
 cd $ROOT && python3 profiles/fp64_summary.py $WL $OUT $MODE $OUT.bench.json

@@ -9,20 +9,16 @@
 set -e
 WL=${1:-cfg3}; STEPS=${2:-20}; MODE=${3:-fused}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/lanes_${WL}_$MODE
+# <workload>rb: the workload with its road boundary (bench.py --road-boundary)
+BASE=$WL; RB=""; case $WL in *rb) BASE=${WL%rb}; RB=--road-boundary;; esac
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/a -- python3 $ROOT/bench.py --workload $WL --mode $MODE --steps $STEPS --warmup 3 --min-seconds 0 --sequence 8 --main-only > /dev/null 2> $OUT.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/a -- python3 $ROOT/bench.py --workload $BASE $RB --mode $MODE --steps $STEPS --warmup 3 --min-seconds 0 --sequence 8 --main-only > $OUT.bench.json 2> $OUT.err
 cd $ROOT && python3 - "$WL" "$MODE" "$OUT" <<'PY'
-import csv, glob, json, sys, collections
+import json, sys
+sys.path[:0] = ["profiles"]
+from _counters import by_kernel, main_kernel_of, rows_of
 wl, mode, out = sys.argv[1:4]
-vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{out}/a/*/*_counter_collection.csv"):
-    rows = [r for r in csv.DictReader(open(f)) if "rp_eval_kernel" in r["Kernel_Name"]]
-    if not rows:
-        continue
-    gmax = max(int(r["Grid_Size"]) for r in rows)
-    for r in rows:
-        if int(r["Grid_Size"]) == gmax:
-            vals[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+vals = by_kernel(rows_of(f"{out}/a/*/*_counter_collection.csv"), main_kernel_of(out + ".bench.json"))
 res = {}
 for k, d in vals.items():
     m = {c: sorted(v)[len(v) // 2] for c, v in d.items()}
@@ -31,9 +27,8 @@ for k, d in vals.items():
     if m.get("SQ_WAVES"):
         m["valu_insts_per_wave"] = round(m.get("SQ_INSTS_VALU", 0.0) / m["SQ_WAVES"], 1)
     res[k] = m
-import subprocess
 sys.path[:0] = [".", "commonroad-reactive-planner_amd"]
 from commonroad_rp_amd import _capi
 print(json.dumps({"workload": wl, "mode": mode, "source_hash": _capi.source_hash(), "kernels": res}, indent=1))
 PY
-rm -rf $OUT
+rm -rf $OUT $OUT.bench.json

@@ -8,16 +8,16 @@ ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 # counters first: the bench line below then carries `traffic` and the FP64 fraction of this very code (bench.py reports the
-# numbers of profiles/r03_*.json only when their source hash is the library's)
+# numbers of profiles/r04_*.json only when their source hash is the library's)
 if [ -z "$QUICK" ]; then
-for wl in cfg2 cfg3 cfg3f cfg4 cfg5; do
+for wl in cfg2 cfg2rb cfg3 cfg3f cfg3frb cfg4 cfg5; do
   steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8
   bash profiles/collect_pmc.sh $wl $steps draw > $OUT/pmc_${wl}_draw.json 2> $OUT/pmc_${wl}_draw.err
   bash profiles/collect_fp64.sh $wl $steps fused > $OUT/fp64_${wl}.json 2> $OUT/fp64_${wl}.err
   rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
   echo "$wl counters done"
 done
-cp profiles/r03_pmc_traffic.json profiles/r03_fp64_flops.json $OUT/
+cp profiles/r04_pmc_traffic.json profiles/r04_fp64_flops.json $OUT/
 fi
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 echo "bench done"

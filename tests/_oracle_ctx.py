@@ -94,6 +94,9 @@ class OracleContext:
     def last_path(self):
         return 0
 
+    def last_kernel(self):
+        return "rp_eval_kernel"
+
     def plan_coeffs(self, params, cost, lon_coeffs, lat_coeffs, lon_T, traj_len, want_best_states=True):
         self._run = oracle.plan_coeffs(params, cost, self._tables(), lon_coeffs, lat_coeffs, traj_len)
         self._range, self._N = (0, len(traj_len)), params.N
