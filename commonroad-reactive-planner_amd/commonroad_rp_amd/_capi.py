@@ -469,7 +469,7 @@ class RpContext:
         """``rp_last_kernel``: the kernel that evaluated the batch of the last plan -- "rp_eval_kernel" (lanes over time steps) or
         "rp_cost_kernel" (one lane per candidate; large batches that keep costs and labels only)."""
         fn = getattr(self._lib, "rp_last_kernel", None)
-        return "rp_cost_kernel" if fn is not None and int(fn(self._h)) == 1 else "rp_eval_kernel"
+        return ("rp_eval_kernel", "rp_cost_kernel")[int(fn(self._h))] if fn is not None else "rp_eval_kernel"
 
     def set_collision_path(self, mode: int):
         """``rp_set_collision_path``: how production-mode plans of large batches answer the collision query -- COLLISION_AUTO

@@ -321,6 +321,7 @@ struct ObsTables {
     double gx0, gy0, ginv;            // origin and 1 / cell size
     int32_t gnx, gny;
     int32_t n_sobb, n_tri, n_circ, n_dyn, n_steps, dyn_t0, n_clus, clus_per;   // clus_per: members per cluster (upper bound)
+    double dyn_rmax_all;              // largest bounding radius of any dynamic obstacle at any step (pose_collides: circle pre-test of a lane's mask)
 };
 // behind the seven planes of `dyn`: [n_dyn][n_steps][2] cx, cy interleaved (16-byte aligned), then [n_dyn] the largest r_bound of
 // each obstacle over the steps where it exists
@@ -403,6 +404,15 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 // clusters reads member rows from there (broadcast reads, tens of cycles) instead of through chained scalar loads from device
 // memory (cluster descriptor -> member rows: a few hundred cycles per cluster with nothing to overlap them with when a SIMD
 // holds one or two wavefronts -- that chain, not the tests, was the cost of a road boundary on a small batch).
+#ifndef RP_WALK_PRETEST
+#define RP_WALK_PRETEST 1        // batched circle pre-test of a lane's mask of dynamic obstacles (pose_collides)
+#endif
+#ifndef RP_WALK_PRETEST_BATCH
+#define RP_WALK_PRETEST_BATCH 4  // ... centres requested at a time (eight: 32 registers, the state-row variants spill 14 more -- cfg2 15.7 -> 17.6 us)
+#endif
+#ifndef RP_WALK_PRETEST_MIN
+#define RP_WALK_PRETEST_MIN 2    // ... for wavefronts with a lane whose mask holds more bits than this
+#endif
 #ifdef RP_WALK_COUNT
 static __device__ unsigned long long *rp_walk_dbg = nullptr;   // diagnostic: clusters walked / queries / exact tests of one wavefront
 #define RP_WSTAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
@@ -586,6 +596,39 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     RP_WSTAMP(10);
     const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
     m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
+    if (MASKED && RP_WALK_PRETEST && __any(__popcll((unsigned long long)m) > RP_WALK_PRETEST_MIN)) {
+        // The (pair, step) masks are exact to the lateral range of the pair's candidates only (~7 m): in traffic a lane's mask holds
+        // several obstacles, few of which its own pose comes near, and the walk below costs one memory round trip per bit of the
+        // fullest mask of the wavefront.  Here the bits are thinned first, ALL AT ONCE: the centres of up to eight obstacles of the
+        // mask requested together (one 16-byte load each, the table the masks were built from), tested against the ego's bounding
+        // circle with the largest obstacle radius of the scene -- a superset of the walk's own, exact circle test, so the walk
+        // visits the same obstacles it would have tested, and nothing else changes.  (cfg3: 4 - 8 bits per lane, 0 - 2 after this.)
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
+        const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
+        const double rr1 = ego_r + ob.dyn_rmax_all;
+        const double lim = rr1 * rr1 * 1.000001;
+        constexpr int kB = RP_WALK_PRETEST_BATCH;
+        uint64_t rest = m, keep = 0;
+        while (__any(rest != 0)) {
+            dbl2 oc[kB];
+            uint64_t r1 = rest;
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {   // (a lane with fewer bits repeats obstacle 0: tested, never kept)
+                const int j = r1 != 0 ? __ffsll((unsigned long long)r1) - 1 : 0;
+                r1 &= r1 - 1;
+                oc[u] = xy[(size_t)j * ob.n_steps + kc];
+            }
+#pragma unroll
+            for (int u = 0; u < kB; ++u) {
+                const uint64_t bit = rest & (0 - rest);   // lowest set bit (0 when none is left)
+                rest &= rest - 1;
+                const double dx = oc[u].x - ego.cx, dy = oc[u].y - ego.cy;
+                if (dx * dx + dy * dy <= lim) keep |= bit;   // false for NaN (absent)
+            }
+        }
+        m = keep;
+    }
     while (__any(m != 0)) {   // wave-uniform trip count = largest number of near obstacles among the lanes
         const bool act = m != 0;
         const int j = act ? __ffsll((unsigned long long)m) - 1 : 0;

@@ -1413,6 +1413,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
         }
     // the broad phase of rp_lon_kernel reads a circle per (obstacle, step): centre as one 16-byte pair, radius as the obstacle's
     // largest over its steps, a scalar -- one vector load per test instead of three (rp_kernels.h: near_mask_step)
+    double rmax_all = 0.0;
     {
         double *xy = &e[dyn_xy_offset(n_dyn, n_steps)], *rmax = &e[dyn_rmax_offset(n_dyn, n_steps)];
         for (int j = 0; j < n_dyn; ++j) {
@@ -1423,6 +1424,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
                 if (e[at] == e[at] && e[6 * plane + at] > r) r = e[6 * plane + at];   // (steps where the obstacle is absent do not count)
             }
             rmax[j] = r;
+            rmax_all = std::max(rmax_all, r);
         }
     }
     // clusters of consecutive static shapes of one kind (at most 63: one bit each in the (pair, step) masks)
@@ -1486,7 +1488,7 @@ int rp_set_obstacles(rp_ctx *c, int32_t n_sobb, const double *sobb, int32_t n_tr
     if ((rc = upload(c, c->d_dyn, e)) != RP_OK) return rc;
     c->obs.sobb = c->d_sobb; c->obs.tri = c->d_tri; c->obs.circ = c->d_circ; c->obs.dyn = c->d_dyn;
     c->obs.n_sobb = n_sobb; c->obs.n_tri = n_tri; c->obs.n_circ = n_circ;
-    c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0;
+    c->obs.n_dyn = n_dyn; c->obs.n_steps = n_steps; c->obs.dyn_t0 = dyn_t0; c->obs.dyn_rmax_all = rmax_all;
     c->obs.clus = c->d_clus; c->obs.clus_info = c->d_clus_info; c->obs.n_clus = n_clus; c->obs.clus_per = clus_per;
     c->obs.slot = c->d_slot;
     // (a replanning loop that brings new predictions of the dynamic obstacles every cycle keeps its static shapes: so does the grid)

@@ -2397,6 +2397,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                         ob.clus = al.obs.clus; ob.clus_info = al.obs.clus_info;
                         ob.n_sobb = al.obs.n_sobb; ob.n_tri = al.obs.n_tri; ob.n_circ = al.obs.n_circ; ob.n_dyn = al.obs.n_dyn;
                         ob.n_steps = al.obs.n_steps; ob.dyn_t0 = al.obs.dyn_t0; ob.n_clus = al.obs.n_clus; ob.clus_per = al.obs.clus_per;
+                        ob.dyn_rmax_all = al.obs.dyn_rmax_all;
                         const Obb ego = {ego_cx, ego_cy, cos_gl, sin_gl, al.half_length, al.half_width};
                         RP_STAMP(45);
                         hit = pose_collides<masked, COLL == 2, LON_FUSED && COLL == 2, true>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,

@@ -1,5 +1,5 @@
 """rp_cost_kernel (one lane per candidate) against rp_eval_kernel (16 lanes per candidate) on costs-only plans: the same status words
-and the same cost BITS, and the step time of both.   usage (GPU box): python profiles/probe_cost_kernel.py [cfg4 cfg5 cfg5obs cfg3]"""
+and the same cost BITS, and the step time of both.   usage (GPU box): python profiles/probe_cost_kernel.py [cfg4 cfg5 cfg5obs cfg3 cfg4rb]"""
 import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,8 @@ from commonroad_rp_amd._capi import RpContext, FLAG_SKIP_COLLISION, PlanInputs, 
 
 names = sys.argv[1:] or ["cfg4", "cfg5", "cfg5obs", "cfg3"]
 for name in names:
-    w = W.cfg5(obstacles=50) if name == "cfg5obs" else W.WORKLOADS[name]()
+    # (<name>rb: the workload with its road boundary)
+    w = W.cfg5(obstacles=50) if name == "cfg5obs" else (W.WORKLOADS[name[:-2]](road_boundary=True) if name.endswith("rb") else W.WORKLOADS[name]())
     ctx = RpContext(0)
     w.setup(ctx)
     got = {}
