@@ -420,6 +420,34 @@ def test_collision_broad_phase_at_workload_scale(ctx, name, lo, count, low_vel):
         _compare_collision_counts(out, orun.out, ctx)
 
 
+_MID_ORACLE = {}
+
+
+@pytest.mark.parametrize("lo,count", [(20000, 3000), (9000, 12000), (40000, 16384), (1000, 2560)])
+def test_state_rows_of_mid_sized_batches_at_n60(ctx, lo, count):
+    """Batches of 2 560 .. 16 384 candidates at the reference's default horizon (N = 60) take two step blocks of 32 lanes on the
+    default path (rp_host.hip: lanes_per_candidate; below, one wavefront per candidate; above, four blocks of 16): EVERY state row of
+    such a batch against the oracle's -- labels and costs alone (test_collision_broad_phase_at_workload_scale) would not see a
+    row stored to the wrong place.  cfg3 (DEU_Test, 51 obstacles), ranges of its grid, draw mode."""
+    from oracle import oracle
+    from commonroad_rp_amd import workloads as W
+    w = W.cfg3()
+    w.setup(ctx)
+    inp = _with_flags(w.inputs, FLAG_DRAW_ALL | FLAG_MATERIALIZE_ALL)
+    if (lo, count) not in _MID_ORACLE:   # (the same for every launch path: computed once)
+        tb = oracle.OracleTables.from_coordinate_system(w.coordinate_system, w.obstacles)
+        _MID_ORACLE[(lo, count)] = oracle.plan(inp, tb, lo, lo + count, want_states=True, nthreads=8)
+    orun = _MID_ORACLE[(lo, count)]
+    out = ctx.plan(inp, lo, lo + count)
+    status, cost = ctx.fetch_status()
+    _compare_status(status, cost, orun, ctx, out)
+    _compare_out(out, orun.out, ctx)
+    np.testing.assert_allclose(ctx.fetch_states(), orun.states, rtol=0, atol=STATE_ATOL)
+    k = int(np.argmax((orun.status & 3) == 1)) if np.any((orun.status & 3) == 1) else 0
+    st, s1, c1 = ctx.eval_one(lo + k)   # the re-evaluation of one candidate runs on the launch path of the batch: same bits
+    np.testing.assert_array_equal(st, ctx.fetch_states(k, 1)[0])
+
+
 def _dense_traffic(co, n_dyn, n_steps, seed=3, dt=0.1):
     """n_dyn constant-velocity boxes on and beside the route (some cross the ego's corridor)."""
     rng = np.random.default_rng(seed)
