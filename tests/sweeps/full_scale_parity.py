@@ -7,7 +7,7 @@ from commonroad_rp_amd import workloads as W
 from commonroad_rp_amd._capi import RpContext, PlanInputs, copy_params, FLAG_DRAW_ALL
 from oracle import oracle
 ctx = RpContext(0)
-cases = [("cfg2", {}), ("cfg2", {"road_boundary": True}), ("cfg3", {}), ("cfg3", {"road_boundary": True}), ("cfg3f", {}), ("cfg4", {}),
+cases = [("cfg2", {}), ("cfg2", {"road_boundary": True}), ("cfg3", {}), ("cfg3", {"road_boundary": True}), ("cfg3f", {}), ("cfg3f", {"road_boundary": True}), ("cfg4", {}),
          ("cfg4", {"road_boundary": True}), ("cfg5", {"obstacles": 50})]
 bad = 0
 for name, kw in cases:
@@ -43,7 +43,7 @@ for name, kw in cases:
                 out.n_collision_before_best == o.out.n_collision_before_best and out.n_feasible == o.out.n_feasible
             ok = lab_ok and cost_ok and win_ok
             bad += not ok
-            print(f"{name} {kw} draw={bool(extra)} path={('eager', 'cost-ordered', 'cost-ordered, then eager')[path]}: {inp.n_candidates} candidates, "
+            print(f"{name} {kw} draw={bool(extra)} path={('eager', 'cost-ordered', 'cost-ordered, then eager')[path]} ({ctx.last_kernel()}): {inp.n_candidates} candidates, "
                   f"colliding {o.out.n_collision} (found {out.n_collision}), winner {out.best_index}: "
                   f"{'OK' if ok else 'MISMATCH'} (labels {lab_ok}, costs {cost_ok}, winner/counters {win_ok}; oracle {t1 - t0:.1f} s)", flush=True)
             if extra or path == 0 and lazy == "0" and inp.n_candidates <= 16384:
