@@ -10,8 +10,8 @@ cd $ROOT
 # counters first: the bench line below then carries `traffic` and the FP64 fraction of this very code (bench.py reports the
 # numbers of profiles/r04_*.json only when their source hash is the library's)
 if [ -z "$QUICK" ]; then
-for wl in cfg2 cfg2rb cfg3 cfg3f cfg3frb cfg4 cfg5; do
-  steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8
+for wl in cfg1 cfg2 cfg2rb cfg3 cfg3rb cfg3f cfg3frb cfg4 cfg4rb cfg5; do
+  steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8; [ $wl = cfg4rb ] && steps=8
   bash profiles/collect_pmc.sh $wl $steps draw > $OUT/pmc_${wl}_draw.json 2> $OUT/pmc_${wl}_draw.err
   bash profiles/collect_fp64.sh $wl $steps fused > $OUT/fp64_${wl}.json 2> $OUT/fp64_${wl}.err
   rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
@@ -25,6 +25,12 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof.err
 cp $(ls $OUT/prof/*/*kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv
 python3 $ROOT/profiles/summarize_trace.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_kernel_trace_summary.txt
+rm -rf $OUT/prof
+# the headline alone (no side configurations: cfg3rb / cfg3frb launch the same kernel instance on the same grid as the headline, so
+# the averages of the full line's trace mix three workloads): the kernel durations bench.py's headline `kernel_ms` has to agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline --no-configs > $OUT/${TAG}_headline_bench_under_rocprof.json 2>> $OUT/prof.err
+python3 $ROOT/profiles/summarize_trace.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_headline_kernel_trace_summary.txt
+python3 $ROOT/profiles/step_timeline.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_headline_step_timeline.txt 2>&1 || true
 rm -rf $OUT/prof
 echo "trace done"
 cd $ROOT
