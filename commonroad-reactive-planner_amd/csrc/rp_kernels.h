@@ -376,7 +376,9 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 // coefficients, and write the whole result block to device memory AND to the pinned host mirror
 // (no separate memset / count / copy operations on the stream).
 // ------------------------------------------------------------------------------------------------
-#define RP_FIN_THREADS 256
+#ifndef RP_FIN_THREADS
+#define RP_FIN_THREADS 512   // (256: the count of colliding candidates before the winner took four dependent trips of eight loads on cfg2-sized batches; profiles/r04_fin_threads_ab.txt)
+#endif
 #define RP_FINALIZE_MAX (1 << 14)   // above: the count of colliding samples before the winner runs as its own many-workgroup
                                     // kernel (one workgroup walking 60 000 status words took 139 us on cfg3)
 
@@ -502,6 +504,17 @@ __device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, Finali
     }
 }
 
+// sum of a 32-bit value over the lanes of a wavefront (DPP adds), valid in lane 63
+__device__ __forceinline__ unsigned int wave_sum_u32_lane63(unsigned int t) {
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR1, 0xf, 0xf, true);
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR2, 0xf, 0xf, true);
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR4, 0xf, 0xf, true);
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_SHR8, 0xf, 0xf, true);      // lane 15 of every row: row total
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST15, 0xa, 0xf, true);   // rows 1, 3 += row 0, 2
+    t += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)t, DPP_ROW_BCAST31, 0xc, 0xf, true);   // lane 63: wavefront total
+    return t;
+}
+
 // Body of rp_finalize_kernel (blockDim.x == RP_FIN_THREADS).  One workgroup that lives a few microseconds: what it costs is
 // (a) memory round trips -- the winner's state rows are requested as soon as the winner is known and travel while the
 // colliding candidates before it are counted -- and (b) the LENGTH of its instruction chains (a lone wavefront issues an
@@ -588,7 +601,9 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
     if (ccount > 0 && (lazy || sh_c32[1] > 0)) {
         // status and cost of kUnroll candidates per lane are requested together (both unconditionally, 12 B per candidate):
         // one candidate per trip with the cost load behind the label test was a chain of dependent round trips
-        constexpr int kUnroll = 8;
+        // (sixteen: batches of up to 8 192 candidates in ONE trip -- a trip to words the evaluation kernel has just written is ~3 500
+        //  cycles, cfg2 + road boundary took two)
+        constexpr int kUnroll = 16;
         int nloc = 0;
         for (int i0 = tid; i0 < ccount; i0 += RP_FIN_THREADS * kUnroll) {
             uint32_t st[kUnroll];
@@ -610,7 +625,10 @@ __device__ __forceinline__ void finalize_body(const FinArgs &a) {
                 if (lazy && i < ccount && gi[u] == widx) sh_wslot = i;   // (list entries are distinct)
             }
         }
-        if (nloc) atomicAdd(&sh_before, (unsigned long long)nloc);
+        // (one LDS add per wavefront: adds from every lane to the one word serialise lane by lane -- in-kernel stamps on cfg1 / cfg2 +
+        //  road boundary, where most lanes have something to add: 9 400 / 7 000 cycles for this block, profiles/r04_finalize_stamps.txt)
+        const unsigned int nw = wave_sum_u32_lane63((unsigned int)nloc);
+        if ((tid & 63) == 63 && nw) atomicAdd(&sh_before, (unsigned long long)nw);
         __syncthreads();   // (uniform: sh_c32 is final)
     }
     __shared__ unsigned long long sh_extra[4];
@@ -805,7 +823,8 @@ __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs
             const double c = a.cost[i];
             nloc += (coll && (widx < 0 || c < wcost || (c == wcost && a.cand_begin + i < widx))) ? 1 : 0;
         }
-        if (nloc) atomicAdd(&sh_nb, (unsigned int)nloc);
+        const unsigned int nw = wave_sum_u32_lane63((unsigned int)nloc);   // (one LDS add per wavefront, as in finalize_body)
+        if ((tid & 63) == 63 && nw) atomicAdd(&sh_nb, nw);
     }
     __syncthreads();
     if (tid < RP_PARTIAL_CNT && sh_c32[tid])

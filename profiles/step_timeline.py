@@ -1,26 +1,28 @@
-"""GPU-side timeline of bench steps from a rocprofv3 kernel trace: span lon_start -> finalize_end per step,
-gaps between kernels inside a step, and idle gap between steps (host-side overhead).
-usage: python profiles/step_timeline.py <kernel_trace.csv>"""
-import csv, sys, numpy as np
+"""GPU-side timeline of bench steps from a rocprofv3 kernel trace: per step the kernels from the first one (rp_lon_kernel, or the
+evaluation kernel of the single-launch path) to the selection epilogue, the gaps between them, and the idle gap between steps
+(ticket -> host -> next launch -> first wavefront).   usage: python profiles/step_timeline.py <kernel_trace.csv>"""
+import csv, sys, collections, numpy as np
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-ev = [(r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
-       int(r["Grid_Size_X"])) for r in rows]
-steps, cur = [], None
-for name, s, e, g in ev:
-    if name == "rp_lon_kernel":
-        cur = {"lon": (s, e)}
-    elif cur is not None and name == "rp_eval_kernel" and "eval" not in cur:
-        cur["eval"] = (s, e)
-    elif cur is not None and name in ("rp_finalize_kernel", "rp_select_kernel"):
-        cur["fin"] = (s, e); steps.append(cur); cur = None
+ev = [(r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", ""), int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+steps, cur = [], []
+for name, s, e in ev:
+    cur.append((name, s, e))
+    if name in ("rp_finalize_kernel", "rp_select_kernel"):
+        steps.append(cur); cur = []
 steps = steps[len(steps) // 4:]   # drop warm-up
-def us(a): return np.median(a) / 1e3
-print("steps", len(steps))
-print("lon      %.2f us" % us([s["lon"][1] - s["lon"][0] for s in steps]))
-print("gap1     %.2f us" % us([s["eval"][0] - s["lon"][1] for s in steps]))
-print("eval     %.2f us" % us([s["eval"][1] - s["eval"][0] for s in steps]))
-print("gap2     %.2f us" % us([s["fin"][0] - s["eval"][1] for s in steps]))
-print("finalize %.2f us" % us([s["fin"][1] - s["fin"][0] for s in steps]))
-print("gpu span %.2f us" % us([s["fin"][1] - s["lon"][0] for s in steps]))
-print("between steps (finalize end -> next lon start) %.2f us" % us([b["lon"][0] - a["fin"][1] for a, b in zip(steps[:-1], steps[1:])]))
-print("period   %.2f us" % us([b["lon"][0] - a["lon"][0] for a, b in zip(steps[:-1], steps[1:])]))
+# the most common kernel sequence is the bench's step; others (winner re-evaluation, cost-ordered rounds) are reported by count
+shapes = collections.Counter(tuple(k[0] for k in st) for st in steps)
+shape, n = shapes.most_common(1)[0]
+sel = [st for st in steps if tuple(k[0] for k in st) == shape]
+us = lambda a: float(np.median(a)) / 1e3
+print(f"steps {len(steps)}, of which {n} are {' -> '.join(shape)}")
+for i, name in enumerate(shape):
+    print(f"  {name:24s} {us([st[i][2] - st[i][1] for st in sel]):8.2f} us")
+    if i + 1 < len(shape):
+        print(f"  {'(gap)':24s} {us([st[i + 1][1] - st[i][2] for st in sel]):8.2f} us")
+print(f"  gpu span                 {us([st[-1][2] - st[0][1] for st in sel]):8.2f} us")
+idx = [i for i, st in enumerate(steps) if tuple(k[0] for k in st) == shape]
+between = [steps[i + 1][0][1] - steps[i][-1][2] for i in idx if i + 1 < len(steps)]
+period = [steps[i + 1][0][1] - steps[i][0][1] for i in idx if i + 1 < len(steps)]
+print(f"  between steps            {us(between):8.2f} us   (epilogue end -> next step's first kernel)")
+print(f"  period                   {us(period):8.2f} us")
