@@ -698,8 +698,9 @@ __global__ __launch_bounds__(RP_FIN_THREADS) void rp_finalize_kernel(const FinAr
 // this thread's share of the lexicographic (cost, index) minimum over the block partials k = tid, tid + nthreads, ...: eight
 // partials' (cost, index) pairs are requested together -- one pair per trip, with the comparison between the trips, was a chain of
 // memory round trips (cfg3: 3 906 partials over 256 threads = 16 trips; rp_select_kernel 17 us against 10.6 us on cfg5's 256)
+// (sixteen at a time: cfg3's 3 906 partials over 256 threads in ONE trip)
 __device__ __forceinline__ void partials_min(const Partials &pp, int n_partials, int tid, int nthreads, double &bc, long long &bi) {
-    constexpr int kBatch = 8;
+    constexpr int kBatch = 16;
     for (int k0 = tid; k0 < n_partials; k0 += nthreads * kBatch) {
         double pc[kBatch];
         long long pi[kBatch];
