@@ -1381,6 +1381,9 @@ __device__ __forceinline__ bool static_shape_near(const ObsTables &ob, int kind,
 // f[PF_NEAR], f[PF_NEAR_S] of step i
 // `last`: the profile fields of the pair's last valid step L - 1 when the caller has them (rp_lon_kernel: handed on from the
 // lane that worked that step out); else they are worked out again for every extended step (lon_step is ~450 instructions).
+#ifndef RP_LON_BROAD_BATCH
+#define RP_LON_BROAD_BATCH 8
+#endif
 template <bool COEFFS_IN>
 __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt, const LonPair &lp, int i, double *f,
                                                const double *last = nullptr) {
@@ -1415,7 +1418,7 @@ __device__ __forceinline__ void near_mask_step(const KArgs &a, const RefTab &rt,
             typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
             const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
             const gcdouble rmax = dyn + dyn_rmax_offset(ob.n_dyn, ob.n_steps);
-            constexpr int kB = 8;
+            constexpr int kB = RP_LON_BROAD_BATCH;
             for (int j0 = 0; j0 < ob.n_dyn; j0 += kB) {
                 dbl2 oc[kB];
 #pragma unroll
@@ -1460,7 +1463,10 @@ __device__ __forceinline__ void copy16_to_lds(const double *src, double *dst_lds
 // One group of G lanes per (T, longitudinal sample) pair, lane = time step: the profile is written once
 // and shared by the nD candidates of the pair (the reference recomputes it nD times).
 template <int G, bool COEFFS_IN, bool LDS_TABLES>
-__global__ __launch_bounds__(RP_BLOCK) void rp_lon_kernel(const KArgsGL ag) {
+#ifndef RP_LON_WAVES
+#define RP_LON_WAVES 1
+#endif
+__global__ __launch_bounds__(RP_BLOCK, RP_LON_WAVES) void rp_lon_kernel(const KArgsGL ag) {
     const KArgs &a = ag.k;
     extern __shared__ double lds[];
     RP_LSTAMP(0);
