@@ -845,8 +845,9 @@ class ReactivePlanner(GpuBackendMixin):
         while level < stop and blk is None:
             # the levels of this call: all that are left, or the next one alone
             upto = stop if (whole or (policy == "adaptive" and level > first)) else level + 1
-            levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)]
-            many = len(levels) > 1
+            many = upto - level > 1
+            levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)] if many else \
+                (sp.grids_at_level(level, x_0_lon, x_0_lat, mode),)
             packed = getattr(ctx, "plan_levels_packed" if many else "plan_packed", None) if hook is None else None
             begin = getattr(ctx, "plan_levels_begin", None) if (hook is not None or (many and packed is None)) else None
             if packed is not None and many:
@@ -879,10 +880,10 @@ class ReactivePlanner(GpuBackendMixin):
             rd = self._infeasible_reason_dict
             self._infeasible_count_kinematics = res.n_candidates - res.n_feasible
             self._infeasible_count_collision = res.n_collision_before_best
-            rc = res.reason_counts
+            rc = res.reason_counts[:]   # (one conversion to a list: indexing a ctypes array costs a call per element)
             for k, name in _REASON_ITEMS:
                 if name in rd:
-                    rd[name] = int(rc[k])
+                    rd[name] = rc[k]
         if blk is None:
             return None
         if buf is None:   # output packing: positions, lon / lat samples, shifted orientations, steering angles and yaw rates in one pass in C
@@ -893,26 +894,27 @@ class ReactivePlanner(GpuBackendMixin):
         """(Cartesian trajectory, curvilinear trajectory, lon list, lat list) of reactive_planner.py:514-568 from the winner's state
         block [14, N + 1] and its packed form [N + 1, 13] (``rp_pack_trajectory``); state objects are built on access."""
         t0, factor, n = self.x_0.time_step, self.config.planning.factor, blk.shape[1]
-        theta, v, acc, kappa = blk[2], blk[3], blk[4], blk[5]
-        pos, sd, th_c, steer, yaw, yaw0 = buf[:, 0:2], buf[:, 2:4], buf[:, 10], buf[:, 11], buf[:, 12], self.x_0.yaw_rate
+        yaw0 = self.x_0.yaw_rate
         new_state, RS, CS = object.__new__, ReactivePlannerState, CustomState
+        # (rows of blk: x y theta v a kappa ...; columns of buf: x y | s d | s s' s'' | d d' d'' | theta shifted | steering angle | yaw
+        #  rate.  Nothing is sliced here: a cycle reads a state or two of the lists, the views are made where a state is built)
 
         def cart_state(i):
             st = new_state(RS)
-            st.__dict__ = {"time_step": t0 + factor * i, "position": pos[i], "orientation": float(th_c[i]), "velocity": float(v[i]),
-                           "steering_angle": float(steer[i]), "acceleration": float(acc[i]), "yaw_rate": float(yaw[i]) if i else yaw0}
+            row = buf[i]
+            st.__dict__ = {"time_step": t0 + factor * i, "position": row[0:2], "orientation": float(row[10]), "velocity": float(blk[3, i]),
+                           "steering_angle": float(row[11]), "acceleration": float(blk[4, i]), "yaw_rate": float(row[12]) if i else yaw0}
             return st
 
         def curv_state(i):
             sc = new_state(CS)
-            sc.__dict__ = {"time_step": t0 + factor * i, "position": sd[i], "orientation": float(theta[i]), "velocity": float(v[i]),
-                           "acceleration": float(acc[i]), "yaw_rate": float(kappa[i])}
+            sc.__dict__ = {"time_step": t0 + factor * i, "position": buf[i, 2:4], "orientation": float(blk[2, i]), "velocity": float(blk[3, i]),
+                           "acceleration": float(blk[4, i]), "yaw_rate": float(blk[5, i])}
             return sc
         # (the lon / lat lists -- [s, s', s''] and [d, d', d''] per step, reactive_planner.py:552-553 -- are lists whose rows are built
         #  on access as well: the loop reads one row of each per cycle, run_planner.py:84-85)
-        lon_rows, lat_rows = buf[:, 4:7], buf[:, 7:10]
         return (Trajectory(t0, LazyStateList(n, cart_state)), Trajectory(t0, LazyStateList(n, curv_state)),
-                LazyStateList(n, lambda i: lon_rows[i].tolist()), LazyStateList(n, lambda i: lat_rows[i].tolist()))
+                LazyStateList(n, lambda i: buf[i, 4:7].tolist()), LazyStateList(n, lambda i: buf[i, 7:10].tolist()))
 
     def _compute_standstill_trajectory(self) -> TrajectorySample:
         """reactive_planner.py:667-713 (arrays of length N, not N + 1, as in the reference)."""

@@ -41,6 +41,9 @@ class Sampling(ABC):
         return self._n_samples
 
 
+_EMPTY = {}
+
+
 class _LinspaceSampling(Sampling):
     """3, 5, 9, 17, ... equidistant samples per level (sampling.py:80-84, 95-99)."""
 
@@ -122,18 +125,26 @@ class FixedIntervalSampling(SamplingSpace):
         ``traj_len`` follows reactive_planner.py:733,748.  In stopping mode the longitudinal samples
         not ahead of the vehicle are dropped, which is what ``filter_goals_behind`` does to the list
         (trajectories.py:545-550, reactive_planner.py:1076-1077)."""
-        T, traj_len = self._cached_T(self.samples_t.samples_at_level(level_sampling))
-        lon_set = self._get_lon_samples(level_sampling, longitudinal_mode)
-        L = self._cached_array(lon_set)
-        if longitudinal_mode == "stopping":
-            L = L[L > x_0_lon[0]]
-        d_set = self.samples_d.samples_at_level(level_sampling)
+        # (the level's sets straight from the per-level dictionaries -- what samples_at_level returns; an unknown level raises KeyError
+        #  here instead of its AssertionError -- and the array forms from one cache per kind, looked up by the set's identity)
+        t_set = self.samples_t._dict_level_to_sample_set[level_sampling]
+        hit = self.__dict__.get("_t_cache", _EMPTY).get(id(t_set))
+        if hit is not None and hit[0] is t_set and len(hit[1]) == len(t_set):
+            T, traj_len = hit[1], hit[2]
+        else:
+            T, traj_len = self._cached_T(t_set)
+        if longitudinal_mode == "velocity_keeping":
+            L = self._cached_array(self.samples_v._dict_level_to_sample_set[level_sampling])
+        else:
+            L = self._cached_array(self._get_lon_samples(level_sampling, longitudinal_mode))
+            L = L[L > x_0_lon[0]]   # ("stopping": anything else has raised)
+        d_set = self.samples_d._dict_level_to_sample_set[level_sampling]
         d0 = x_0_lat[0]
         if d0 in d_set:
             D = self._cached_array(d_set)
         else:   # set.union({d0}) keeps the iteration order of the copy and appends / hashes d0 in
-            u = d_set.union({d0})
-            D = np.fromiter(u, dtype=np.float64, count=len(u))
+            u = d_set.union((d0,))
+            D = np.fromiter(u, np.float64, len(u))
         return T, traj_len, L, D
 
     # The sample sets only change when a set_*_sampling_parameters call replaces them, so their array form
