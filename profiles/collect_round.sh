@@ -20,6 +20,8 @@ done
 cp profiles/r04_pmc_traffic.json profiles/r04_fp64_flops.json $OUT/
 fi
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# cfg2 as the headline workload (the headline of rounds 1-2; carries plan() latency on cfg2)
+python3 bench.py --workload cfg2 --no-configs --no-cpu-baseline > $OUT/${TAG}_bench_cfg2.json 2>> $OUT/bench.err
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof.err

@@ -29,4 +29,4 @@ echo "fuzz done"
   python3 tests/sweeps/full_scale_parity.py 2>&1 | grep -v amdgpu.ids
 } > $OUT/${TAG}_full_scale_parity.txt 2>&1
 echo "full scale done"
-tail -3 $OUT/${TAG}_fuzz_parity.txt $OUT/${TAG}_full_scale_parity.txt
+tail -n 3 $OUT/${TAG}_fuzz_parity.txt; tail -n 3 $OUT/${TAG}_full_scale_parity.txt
