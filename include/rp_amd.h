@@ -189,9 +189,9 @@ int rp_plan(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_
 
 /* The same call in two halves.  rp_plan_begin validates, stages and puts the kernels of the plan on the context's stream and
  * returns; rp_plan_wait waits for the completion ticket the last kernel writes into pinned host memory and unpacks the result
- * (rp_plan = begin + wait).  Between the two the host is free -- the replanning loop packs the previous cycle's output, a
- * planner starts the next sampling level on a second context (plan() visits its levels one after the other,
- * reactive_planner.py:616-636: a level without a winner costs a whole round trip before the next can start).
+ * (rp_plan = begin + wait).  Between the two the host is free -- the replanning loop packs the previous cycle's output and does
+ * its bookkeeping.  (The levels of one cycle, which plan() visits one after the other -- reactive_planner.py:616-636 -- go onto the
+ * stream together through rp_plan_levels below.)
  * One plan in flight per context; the calls that read "the last plan" refer to the last COLLECTED one.  Plans whose chain needs
  * decisions of the host in between (the cost-ordered collision stage of large batches) run them inside rp_plan_begin. */
 int rp_plan_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids, int64_t cand_begin,
