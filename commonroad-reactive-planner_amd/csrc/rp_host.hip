@@ -719,6 +719,9 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* wor
         const unsigned long long feasible = ex[3];
         cnt[0] = (uint32_t)ex[0]; cnt[1] = (uint32_t)(ex[0] >> 32); cnt[2] = (uint32_t)ex[1];
         *rounds = l + 1;
+        if (std::getenv("RP_AMD_LAZY_TRACE"))   // (diagnostic: profiles/probe_lazy_trace.py)
+            std::fprintf(stderr, "cost-ordered stage, round %d: list sizes %u %u %u, overflow bits %x, checked %u of %llu feasible, winner %lld\n", l,
+                         cnt[0], cnt[1], cnt[2], overflow, checked, feasible, (long long)hrb_host->r.best_index);
         if (overflow & ((2u << l) - 1u)) return RP_OK;              // this round's list (or an earlier one) was incomplete: not conclusive
         if (hrb_host->r.best_index >= 0) { *done = true; return RP_OK; }
         if ((unsigned long long)checked >= feasible) { *done = true; return RP_OK; }   // every feasible candidate collides: no winner
