@@ -2120,168 +2120,180 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                 const double px = pf.f[PF_PX], py = pf.f[PF_PY], nx = pf.f[PF_NX], ny = pf.f[PF_NY];
                 const bool s_in_dom = pf.f[PF_INDOM] != 0.0;
 
-                // -- lateral polynomial, reactive_planner.py:756-777
-                const double t = (double)i * dt;
-                const double tau = low ? s - s0 : t;
-                double d = poly_pos(gs_poly, tau), dd = poly_vel(gs_poly, tau), ddd = poly_acc(gs_poly, tau);
-                if (fabs(dd) < RP_EPS) dd = 0.0;
-                // Rows stored straight to memory leave once per step block, behind the horizon extension (LATE_STORE): valid and
-                // extended steps of a row then share ONE store instruction, i.e. whole 64-byte lines -- stored separately, the
-                // 32-byte sector that holds the last valid step was written twice (+ 24 B per row on cfg2, PMC WRITE_SIZE).
-                if (!LATE_STORE && store_ok && act) {   // curvilinear rows of valid steps are final here
-                    const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S), s);
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DOT), sd);
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DDOT), sdd);
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D), d);
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DOT), dd);
-                    st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DDOT), ddd);
-                }
-                RP_STAMP(3);   // profile loads + polynomial evaluation
-
-                // -- d', d'' (:810-832)
-                const bool moving = inv_sd > 0.0;
-                double dp, dpp;
-                if (!low) {
-                    dp = dd * inv_sd;
-                    const double ddot = ddd - dp * sdd;
-                    dpp = ddot * inv_sd * inv_sd;
-                } else {
-                    dp = dd;
-                    dpp = ddd;
-                }
-
-                // -- orientations (:842-873) incl. the standstill carry of :866
-                const bool use_atan = moving || low;
-                double th_cl = rp_atan(dp);          // np.arctan2(dp, 1.0)
-                double th_gl = th_cl + th_ref;
-                // cos / sec / tan of theta_cl: algebraic on the atan branch
-                const double w2 = __builtin_fma(dp, dp, 1.0);
-                double cosT = rp_rsqrt(w2);
-                double secT = w2 * cosT;
-                double tanT = dp;
-                if (__any(act && !use_atan)) {   // standstill lanes: keep the orientation of the last moving step
-                    const uint64_t mv = group_ballot<G>(use_atan && act, gbase);
-                    const uint64_t below = mv & ((1ull << gl) - 1ull);
-                    const int src = below ? 63 - __clzll(below) : 0;
-                    const double th_from = group_bcast<G>(th_gl, src);
-                    if (!use_atan) {
-                        th_gl = below ? th_from : theta_carry;
-                        th_cl = th_gl - th_ref;
-                    }
-                    double sn, cs;
-                    rp_sincos(th_cl, &sn, &cs);
-                    const double sc = rp_rcp(cs);
-                    cosT = use_atan ? cosT : cs;
-                    secT = use_atan ? secT : sc;
-                    tanT = use_atan ? tanT : sn * sc;
-                }
-                // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref (variants with a
-                // collision query; the others need them for one lane per candidate only, where the extension starts)
-                const double sinT = tanT * cosT;
-                double cos_gl = heading_cos(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
-                double sin_gl = heading_sin(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
-                RP_STAMP(5);   // atan + carry
-
-                // -- curvature, velocity, acceleration (:883-896)
-                const double oneKrD = 1.0 - k_r * d;
-                const double q = cosT * rp_rcp(oneKrD);
-                const double kterm = frenet_kterm(k_r_d, d, k_r, dp);
-                double kappa = frenet_kappa(dpp, kterm, tanT, cosT, q, k_r);
-                const double f = oneKrD * secT;
-                double v = sd * f;
-                double acc = frenet_acc(sdd, f, sd, secT, oneKrD, tanT, kappa, k_r, kterm);
-
-                // -- previous-step values for the finite differences (DPP lane shift)
-                double th_prev = lane_prev(th_gl), ka_prev = lane_prev(kappa);
-                if (gl == 0) { th_prev = theta_carry; ka_prev = kappa_carry; }
-                const double dth = i > 0 ? th_gl - th_prev : 0.0;
-                double kdot = i > 0 ? kappa - ka_prev : 0.0;   // np.append([0], np.diff(kappa_gl)), :923
-                RP_STAMP(6);   // kappa, v, a + prev-step shifts
-
-                // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
-#if RP_BRANCHFREE_CONSTRAINTS
-                // (straight-line code: every lane evaluates the five tests and the first failing one in the reference's order is
-                //  picked by selects -- as an if / else-if chain the compiler emitted five nested exec-mask regions, each with its
-                //  own scalar loads of the limits and a wait on them)
-                uint32_t reason = RP_REASON_NONE;
-                {
-                    const double a_max = al.a_max, v_switch = al.v_switch, kappa_max = al.kappa_max;
-                    const double wk = al.wheelbase * kappa;
-                    // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
-                    const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > kappa_max * v * 1e5;
-                    // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
-                    const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
-                    // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
-                    const bool fast = v > v_switch;
-                    const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
-                    const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
-                    const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
-                    reason = (((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc) ? RP_REASON_ACCELERATION : reason;
-                    reason = (((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd) ? RP_REASON_KAPPA_DOT : reason;
-                    reason = (((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw) ? RP_REASON_YAW_RATE : reason;
-                    reason = (((cm & RP_CHECK_KAPPA) != 0) & bad_k) ? RP_REASON_KAPPA : reason;
-                    reason = (((cm & RP_CHECK_VELOCITY) != 0) & bad_v) ? RP_REASON_VELOCITY : reason;
-                    reason = act ? reason : RP_REASON_NONE;
-                }
-#else
-                uint32_t reason = RP_REASON_NONE;
-                if (act) {
-                    const double wk = al.wheelbase * kappa;
-                    // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
-                    const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > al.kappa_max * v * 1e5;
-                    // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
-                    const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
-                    // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
-                    const bool ok_acc = (-al.a_max <= acc) && (v > al.v_switch ? acc * v <= al.a_max * al.v_switch : acc <= al.a_max);
-                    if ((cm & RP_CHECK_VELOCITY) && v < -RP_EPS) reason = RP_REASON_VELOCITY;
-                    else if ((cm & RP_CHECK_KAPPA) && fabs(kappa) > al.kappa_max) reason = RP_REASON_KAPPA;
-                    else if ((cm & RP_CHECK_YAW_RATE) && bad_yaw) reason = RP_REASON_YAW_RATE;
-                    else if ((cm & RP_CHECK_KAPPA_DOT) && bad_kd) reason = RP_REASON_KAPPA_DOT;
-                    else if ((cm & RP_CHECK_ACCELERATION) && !ok_acc) reason = RP_REASON_ACCELERATION;
-                }
-#endif
-                if (__any(reason != RP_REASON_NONE)) {   // wave-uniform
-                    const uint64_t fm = group_ballot<G>(reason != RP_REASON_NONE, gbase);
-                    const int fl = fm ? __ffsll((unsigned long long)fm) - 1 : 0;
-                    const uint32_t r_first = (uint32_t)__shfl((int)reason, fl, G);
-                    if (fm && fail_step < 0) { fail_step = base + fl; fail_reason = r_first; }
-                    if (!draw && fail_step >= 0) alive = false;
-                    if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wave is decided
-                }
-                RP_STAMP(7);   // constraints + first-failure vote
-
-                // -- (s, d) -> (x, y) = foot point + d * unit normal, reactive_planner.py:908-917
-                const bool in_dom = s_in_dom && fabs(d) <= al.proj_d_limit;
-                double x = px + d * nx, y = py + d * ny;
-                if (__any(act && !in_dom) || ood_step >= 0) {   // wave-uniform ("ood_step" alone is group-uniform: harmless)
-                    const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
-                    if (om && ood_step < 0) ood_step = base + __ffsll((unsigned long long)om) - 1;
-                    if (ood_step >= 0 && i >= ood_step) { x = 0.0; y = 0.0; }   // x, y stay np.zeros past the break
-                }
-                if (act) {   // Cartesian rows of valid steps are final here
-                    if (!LATE_STORE && store_ok) {
-                        const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_X), x);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_Y), y);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA), th_gl);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_V), v);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_A), acc);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA), kappa);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA_DOT), kdot);
-                        st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA_CL), th_cl);
-                    }
-                    cost_acc += cost_terms(i, acc, v, s, d, th_cl);
-                }
-                // static shapes: the pose's cell of the grid over them (static_grid_mask) is requested here for the valid steps,
-                // whose pose is final, and behind the extension for the extended ones -- and waited for IN FRONT of the row stores.
-                // Loads and stores share one in-order counter (vmcnt): a load that is waited for behind the write-through stores
-                // of the rows is waited for together with their acknowledgements from memory (6 000 cycles per step block, measured).
+                // A step block that holds extended states only (i >= L in every lane: horizons longer than the trajectories, cfg3 one
+                // block in six, cfg5 every second) has nothing to evaluate -- its lanes take every value from the last valid state
+                // below.  (Wave-uniform: the lanes of a wavefront belong to one pair, rarely two.)  Same-box A/B, kernel time
+                // (profiles/r04_extended_guard_ab.txt): cfg3 draw 101.5 -> 98.8 us, cfg3 + road boundary 110.0 -> 107.0, cfg4 draw
+                // unchanged; cfg5 draw -- state rows, no collision query: all stores -- 2.137 -> 2.20 ms (the wavefronts of a
+                // workgroup then fall out of step with their row stores), so that variant evaluates every block as before.  Reading only
+                // the near mask of the profile in such a block was tried on top: slower everywhere (cfg3 draw 103.8 us).
+                constexpr bool SKIP_EXTENDED = !(MAT && COLL == 0);
+                double d = 0.0, dd = 0.0, ddd = 0.0, th_cl = 0.0, th_gl = 0.0, cos_gl = 1.0, sin_gl = 0.0;
+                double kappa = 0.0, v = 0.0, acc = 0.0, kdot = 0.0, x = 0.0, y = 0.0;
                 uint64_t near_sta_cell = 0;
+                if (!SKIP_EXTENDED || __any(act)) {
+                    // -- lateral polynomial, reactive_planner.py:756-777
+                    const double t = (double)i * dt;
+                    const double tau = low ? s - s0 : t;
+                    d = poly_pos(gs_poly, tau); dd = poly_vel(gs_poly, tau); ddd = poly_acc(gs_poly, tau);
+                    if (fabs(dd) < RP_EPS) dd = 0.0;
+                    // Rows stored straight to memory leave once per step block, behind the horizon extension (LATE_STORE): valid and
+                    // extended steps of a row then share ONE store instruction, i.e. whole 64-byte lines -- stored separately, the
+                    // 32-byte sector that holds the last valid step was written twice (+ 24 B per row on cfg2, PMC WRITE_SIZE).
+                    if (!LATE_STORE && store_ok && act) {   // curvilinear rows of valid steps are final here
+                        const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_S), s);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DOT), sd);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_S_DDOT), sdd);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_D), d);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DOT), dd);
+                        st_row<RP_WT, RP_NT>(row_at(off8, RP_D_DDOT), ddd);
+                    }
+                    RP_STAMP(3);   // profile loads + polynomial evaluation
+
+                    // -- d', d'' (:810-832)
+                    const bool moving = inv_sd > 0.0;
+                    double dp, dpp;
+                    if (!low) {
+                        dp = dd * inv_sd;
+                        const double ddot = ddd - dp * sdd;
+                        dpp = ddot * inv_sd * inv_sd;
+                    } else {
+                        dp = dd;
+                        dpp = ddd;
+                    }
+
+                    // -- orientations (:842-873) incl. the standstill carry of :866
+                    const bool use_atan = moving || low;
+                    th_cl = rp_atan(dp);          // np.arctan2(dp, 1.0)
+                    th_gl = th_cl + th_ref;
+                    // cos / sec / tan of theta_cl: algebraic on the atan branch
+                    const double w2 = __builtin_fma(dp, dp, 1.0);
+                    double cosT = rp_rsqrt(w2);
+                    double secT = w2 * cosT;
+                    double tanT = dp;
+                    if (__any(act && !use_atan)) {   // standstill lanes: keep the orientation of the last moving step
+                        const uint64_t mv = group_ballot<G>(use_atan && act, gbase);
+                        const uint64_t below = mv & ((1ull << gl) - 1ull);
+                        const int src = below ? 63 - __clzll(below) : 0;
+                        const double th_from = group_bcast<G>(th_gl, src);
+                        if (!use_atan) {
+                            th_gl = below ? th_from : theta_carry;
+                            th_cl = th_gl - th_ref;
+                        }
+                        double sn, cs;
+                        rp_sincos(th_cl, &sn, &cs);
+                        const double sc = rp_rcp(cs);
+                        cosT = use_atan ? cosT : cs;
+                        secT = use_atan ? secT : sc;
+                        tanT = use_atan ? tanT : sn * sc;
+                    }
+                    // cos / sin of the heading theta = theta_ref + theta_cl from the profile's cos / sin of theta_ref (variants with a
+                    // collision query; the others need them for one lane per candidate only, where the extension starts)
+                    const double sinT = tanT * cosT;
+                    cos_gl = heading_cos(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
+                    sin_gl = heading_sin(pf.f[PF_COS_REF], pf.f[PF_SIN_REF], cosT, sinT);
+                    RP_STAMP(5);   // atan + carry
+
+                    // -- curvature, velocity, acceleration (:883-896)
+                    const double oneKrD = 1.0 - k_r * d;
+                    const double q = cosT * rp_rcp(oneKrD);
+                    const double kterm = frenet_kterm(k_r_d, d, k_r, dp);
+                    kappa = frenet_kappa(dpp, kterm, tanT, cosT, q, k_r);
+                    const double f = oneKrD * secT;
+                    v = sd * f;
+                    acc = frenet_acc(sdd, f, sd, secT, oneKrD, tanT, kappa, k_r, kterm);
+
+                    // -- previous-step values for the finite differences (DPP lane shift)
+                    double th_prev = lane_prev(th_gl), ka_prev = lane_prev(kappa);
+                    if (gl == 0) { th_prev = theta_carry; ka_prev = kappa_carry; }
+                    const double dth = i > 0 ? th_gl - th_prev : 0.0;
+                    kdot = i > 0 ? kappa - ka_prev : 0.0;   // np.append([0], np.diff(kappa_gl)), :923
+                    RP_STAMP(6);   // kappa, v, a + prev-step shifts
+
+                    // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
+    #if RP_BRANCHFREE_CONSTRAINTS
+                    // (straight-line code: every lane evaluates the five tests and the first failing one in the reference's order is
+                    //  picked by selects -- as an if / else-if chain the compiler emitted five nested exec-mask regions, each with its
+                    //  own scalar loads of the limits and a wait on them)
+                    uint32_t reason = RP_REASON_NONE;
+                    {
+                        const double a_max = al.a_max, v_switch = al.v_switch, kappa_max = al.kappa_max;
+                        const double wk = al.wheelbase * kappa;
+                        // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
+                        const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > kappa_max * v * 1e5;
+                        // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
+                        const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
+                        // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
+                        const bool fast = v > v_switch;
+                        const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
+                        const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
+                        const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
+                        reason = (((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc) ? RP_REASON_ACCELERATION : reason;
+                        reason = (((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd) ? RP_REASON_KAPPA_DOT : reason;
+                        reason = (((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw) ? RP_REASON_YAW_RATE : reason;
+                        reason = (((cm & RP_CHECK_KAPPA) != 0) & bad_k) ? RP_REASON_KAPPA : reason;
+                        reason = (((cm & RP_CHECK_VELOCITY) != 0) & bad_v) ? RP_REASON_VELOCITY : reason;
+                        reason = act ? reason : RP_REASON_NONE;
+                    }
+    #else
+                    uint32_t reason = RP_REASON_NONE;
+                    if (act) {
+                        const double wk = al.wheelbase * kappa;
+                        // |round(yaw, 5)| > kappa_max v           with yaw = dth / dt           (:993-995)
+                        const bool bad_yaw = fabs(rint(dth * al.c_yaw)) > al.kappa_max * v * 1e5;
+                        // |dka / dt| > v_delta_max / (wb cos^2(atan(wb kappa)))                  (:1001-1005)
+                        const bool bad_kd = fabs(kdot) > al.c_kdot * __builtin_fma(wk, wk, 1.0);
+                        // a_min <= a <= a_max (v_switch / v above the switching velocity)        (:1011-1014)
+                        const bool ok_acc = (-al.a_max <= acc) && (v > al.v_switch ? acc * v <= al.a_max * al.v_switch : acc <= al.a_max);
+                        if ((cm & RP_CHECK_VELOCITY) && v < -RP_EPS) reason = RP_REASON_VELOCITY;
+                        else if ((cm & RP_CHECK_KAPPA) && fabs(kappa) > al.kappa_max) reason = RP_REASON_KAPPA;
+                        else if ((cm & RP_CHECK_YAW_RATE) && bad_yaw) reason = RP_REASON_YAW_RATE;
+                        else if ((cm & RP_CHECK_KAPPA_DOT) && bad_kd) reason = RP_REASON_KAPPA_DOT;
+                        else if ((cm & RP_CHECK_ACCELERATION) && !ok_acc) reason = RP_REASON_ACCELERATION;
+                    }
+    #endif
+                    if (__any(reason != RP_REASON_NONE)) {   // wave-uniform
+                        const uint64_t fm = group_ballot<G>(reason != RP_REASON_NONE, gbase);
+                        const int fl = fm ? __ffsll((unsigned long long)fm) - 1 : 0;
+                        const uint32_t r_first = (uint32_t)__shfl((int)reason, fl, G);
+                        if (fm && fail_step < 0) { fail_step = base + fl; fail_reason = r_first; }
+                        if (!draw && fail_step >= 0) alive = false;
+                        if (__ballot(alive) == 0) break;   // wave-uniform: every candidate of this wave is decided
+                    }
+                    RP_STAMP(7);   // constraints + first-failure vote
+
+                    // -- (s, d) -> (x, y) = foot point + d * unit normal, reactive_planner.py:908-917
+                    const bool in_dom = s_in_dom && fabs(d) <= al.proj_d_limit;
+                    x = px + d * nx; y = py + d * ny;
+                    if (__any(act && !in_dom) || ood_step >= 0) {   // wave-uniform ("ood_step" alone is group-uniform: harmless)
+                        const uint64_t om = group_ballot<G>(act && !in_dom, gbase);
+                        if (om && ood_step < 0) ood_step = base + __ffsll((unsigned long long)om) - 1;
+                        if (ood_step >= 0 && i >= ood_step) { x = 0.0; y = 0.0; }   // x, y stay np.zeros past the break
+                    }
+                    if (act) {   // Cartesian rows of valid steps are final here
+                        if (!LATE_STORE && store_ok) {
+                            const uint32_t off8 = lane_off8 + (uint32_t)i * 8u;
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_X), x);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_Y), y);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA), th_gl);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_V), v);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_A), acc);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA), kappa);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_KAPPA_DOT), kdot);
+                            st_row<RP_WT, RP_NT>(row_at(off8, RP_THETA_CL), th_cl);
+                        }
+                        cost_acc += cost_terms(i, acc, v, s, d, th_cl);
+                    }
+                    // static shapes: the pose's cell of the grid over them (static_grid_mask) is requested here for the valid steps,
+                    // whose pose is final, and behind the extension for the extended ones -- and waited for IN FRONT of the row stores.
+                    // Loads and stores share one in-order counter (vmcnt): a load that is waited for behind the write-through stores
+                    // of the rows is waited for together with their acknowledgements from memory (6 000 cycles per step block, measured).
+                    if (COLL == 2 && live && alive && fail_step < 0 && ood_step < 0 && !collide && act)   // (= cell_wanted below)
+                        near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
+                                                         x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
+                }
                 const bool cell_wanted = COLL == 2 && live && alive && fail_step < 0 && ood_step < 0 && !collide;
-                if (cell_wanted && act)
-                    near_sta_cell = static_grid_mask(al.obs.grid, al.obs.gx0, al.obs.gy0, al.obs.ginv, al.obs.gnx, al.obs.gny,
-                                                     x + al.wb_rear_axle * cos_gl, y + al.wb_rear_axle * sin_gl);
                 RP_STAMP(8);   // x, y + stores of valid steps
 
                 // -- horizon extension (trajectories.py:168-197, 302-332); only chunks that hold states >= L
