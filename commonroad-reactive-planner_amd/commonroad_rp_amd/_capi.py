@@ -514,6 +514,19 @@ class RpContext:
         self._last_count = res.n_candidates
         return self._output(res, best)
 
+    def _packed_out(self, n: int):
+        """Fresh output block of the packed calls, [14 + 13][n] doubles: (ctypes array -- what the call takes as its pointer --, the same
+        memory as a 2-D array).  ``np.empty(...).ctypes.data`` costs a microsecond per call; a ctypes array of a cached type and an
+        array over its buffer a third of that."""
+        types = self.__dict__.get("_out_types")
+        if types is None:
+            types = self._out_types = {}
+        t = types.get(n)
+        if t is None:
+            t = types[n] = C.c_double * ((N_ARRAYS + 13) * n)
+        raw = t()
+        return raw, np.ndarray((N_ARRAYS + 13, n), np.float64, raw)
+
     def plan_packed(self, params: RpParams, cost: RpCost, T, traj_len, L, D):
         """``rp_plan_packed``: one sampling level -> (the context's ``RpResult`` struct, state block [14, N + 1], packed output
         [N + 1, 13]) -- the last two ``None`` without a winner.  The grids go through the context's own buffer (four slice
@@ -543,18 +556,18 @@ class RpContext:
             f64v[nT + nL:nd] = D
         self._fast_last = ((nT, nL, nD), T, L, D, traj_len)
         n = params.N + 1
-        out = np.empty((N_ARRAYS + 13) * n)
+        raw, out = self._packed_out(n)
         res = self._res
-        rc = call(self._h, params, cost, nT, nL, nD, res, out.ctypes.data)
+        rc = call(self._h, params, cost, nT, nL, nD, res, raw)
         if rc != 0:
             self._check(rc, "rp_plan_packed")
-        self._N = params.N
+        self._N = n - 1
         self._last_count = res.n_candidates
         self._serial += 1
         self._last_best = None
         if res.best_index < 0:
             return res, None, None
-        return res, out[:N_ARRAYS * n].reshape(N_ARRAYS, n), out[N_ARRAYS * n:].reshape(n, 13)
+        return res, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
 
     def plan_levels_packed(self, params: RpParams, cost: RpCost, levels):
         """``rp_plan_levels_packed``: the level loop of ``plan()`` (reactive_planner.py:616-636) in one call and one device round
@@ -587,18 +600,18 @@ class RpContext:
             at += words
         self._fast_last = None   # (the buffer no longer holds what plan_packed left there)
         n = params.N + 1
-        out = np.empty((N_ARRAYS + 13) * n)
+        raw, out = self._packed_out(n)
         res, lvl = self._res, self._lvl_out
-        rc = self._lib.rp_plan_levels_packed(self._h, params, cost, nlev, dims, res, out.ctypes.data, lvl)
+        rc = self._lib.rp_plan_levels_packed(self._h, params, cost, nlev, dims, res, raw, lvl)
         if rc != 0:
             self._check(rc, "rp_plan_levels_packed")
-        self._N = params.N
+        self._N = n - 1
         self._last_count = res.n_candidates
         self._serial += 1
         self._last_best = None
         if res.best_index < 0:
             return res, lvl.value, None, None
-        return res, lvl.value, out[:N_ARRAYS * n].reshape(N_ARRAYS, n), out[N_ARRAYS * n:].reshape(n, 13)
+        return res, lvl.value, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
 
     def plan_levels_begin(self, params: RpParams, cost: RpCost, levels, want_best_states: bool = True):
         """First half of ``rp_plan_levels`` (collected by ``plan_wait``, which then also reports ``last_level()``)."""
