@@ -12,7 +12,7 @@ states), not one repeated input.  A timed region is exactly K steps; regions are
 ``--min-seconds`` of timed work has accumulated, ``ms_per_step`` is the median region, the spread is reported.
 
 N = 1 (default): headline = cfg3 (BASELINE.json configs[2], the largest configuration tagged 1 x MI355X) in draw mode, plus --
-in the same JSON line --
+in the detail file, their key numbers in the line --
   ``configs``          draw- and production-mode records of cfg1, cfg2, cfg3f (cfg3's grid in mostly-free traffic), <cfg>rb (cfg2, cfg3, cfg3f, cfg4 with the road boundary),
                        cfg4, cfg5, each with its own roofline
   ``fused_mode``       the headline workload in production mode (12 B per candidate leave the kernel)
@@ -27,7 +27,10 @@ N > 1: one process per GPU (the driver's ``python -m torch.distributed.run ... b
   512 064-candidate grid cut into N ranges, the same regions with the other exchange transport, the exchange time per step
   of both, rank 0 alone on the whole grid.  `--scaling strong` makes that record the headline.
 
-Prints ONE JSON line (rank 0).  Modes:
+Prints ONE JSON line (rank 0): the COMPACT record (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, p50 / p90 of plan(), one
+number pair per side configuration, the N > 1 exchange keys); the full record of the run (every side record with its spread, roofline
+and description) is written to `gpurun_out/bench_detail_n<N>.json` (the repo root without that directory) and named in the line's
+`detail`.  Modes:
   draw        every candidate fully evaluated (no pre-filter / early exit, the reference's draw_traj_set semantics)
               and all 14 state rows of every candidate written to HBM.  Default: work per candidate is data independent
               and the byte count is SURVEY 8(d)'s bytes = C*12 + C*112*(N+1) + 112*(N+1).
@@ -89,14 +92,17 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    import logging
+    logging.getLogger("RP_LOGGER").setLevel(logging.ERROR)   # (the all-levels-fail leg would warn once per cycle on stderr)
     try:
-        line = run(args)
+        result = run(args)
     finally:
         sys.stdout.flush()
+        sys.stderr.flush()
         os.dup2(real_stdout, 1)
         os.close(real_stdout)
-    if line is not None:
-        print(line, flush=True)
+    if result is not None:
+        print(emit(result, args), flush=True)
 
 
 def self_launch(args) -> int:
@@ -312,7 +318,101 @@ def run(args):
             from commonroad_rp_amd.distributed import close_exchanges
             close_exchanges()
             dist.destroy_process_group()
-    return json.dumps(result) if rank == 0 and result is not None else None
+    return result if rank == 0 else None
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The driver reads rank 0's line out of a 16-KB tail of stdout: the line is the COMPACT record (< 4 KB, tests/test_bench_line.py);
+# everything else the run measured goes to a file next to it, named in the line.
+LINE_LIMIT = 4096
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_launch", "flops_per_launch")
+
+
+def _r(v, digits=5):
+    """floats to ``digits`` significant digits (the line is read by people and parsed by json.loads)"""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _r(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, digits) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(full: dict, detail_path=None) -> dict:
+    """The record the driver parses: the contract's keys, ``roofline`` and ``cpu_baseline`` of the headline, p50 / p90 of plan(), one
+    number pair per side configuration, the N > 1 exchange keys -- nothing that grows with the number of side records' fields."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    out["config"] = _pick(full.get("config", {}), ("workload", "mode", "candidates_per_step", "candidates_per_gpu", "horizon_steps",
+                                                    "n_obstacles", "parallelism", "exchange"))
+    if len(out["config"].get("workload", "")) > 160:
+        out["config"]["workload"] = out["config"]["workload"][:157] + "..."
+    if "roofline" in full:
+        out["roofline"] = _pick(full["roofline"], ROOFLINE_KEYS)
+        if full["roofline"].get("stale_profile"):
+            out["roofline"]["stale_profile"] = True
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["sample"] = cb.get("sample_short") or cb.get("sample", "")[:120]
+        if "all_cores" in cb:
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores", "nproc"))
+        if "numpy_loop" in cb:
+            c["numpy_loop"] = _pick(cb["numpy_loop"], ("value", "cores", "ratio_to_reference", "reference_value"))
+        out["cpu_baseline"] = c
+    pl = full.get("plan_latency_ms")
+    if pl:
+        out["plan_latency_ms"] = _pick(pl, ("p50", "p90", "workload", "world", "error"))
+    fm = full.get("fused_mode")
+    if fm:   # the headline workload in production mode (12 B per candidate leave the kernel)
+        out["production_mode"] = dict(_pick(fm, ("ms_per_step", "value")), roofline=_pick(fm.get("roofline", {}), ("bound", "frac", "kernel", "kernel_ms")))
+    if "python_binding" in full:
+        out["python_binding_ms_per_step"] = full["python_binding"].get("ms_per_step")
+    side = {}
+    for name, rec in (full.get("configs") or {}).items():   # [draw ms, draw roofline frac, production ms, production roofline frac]
+        side[name] = [rec.get(m, {}).get(k) if k == "ms_per_step" else rec.get(m, {}).get("roofline", {}).get("frac")
+                      for m in ("draw", "fused") for k in ("ms_per_step", "frac")]
+    if side:
+        out["side_configs"] = dict(side, _cols="draw ms/step, draw roofline frac, production ms/step, production roofline frac")
+    ll = full.get("level_loop_latency_ms")
+    if isinstance(ll, dict) and "error" not in ll:
+        out["level_loop_p50_ms"] = {pol: {"closed_loop": rec.get("closed_loop", {}).get("p50"), "all_levels_fail": rec.get("all_levels_fail", {}).get("p50")}
+                                    for pol, rec in ll.items() if isinstance(rec, dict)}
+    for k in ("exchange", "exchange_ms_per_step", "ranks_seen_by_rccl", "other_transport", "one_gpu_same_grid", "strong_scaling", "rehearsal",
+              "wait_mode"):
+        if k in full:
+            out[k] = full[k]
+    if detail_path:
+        out["detail"] = detail_path
+    return _r(out)
+
+
+def emit(full: dict, args) -> str:
+    """Write the full record to ``bench_detail*.json`` (gpurun_out/ when it exists: that directory travels back from a GPU box) and
+    return the compact line.  Fields are dropped from the tail of the line, never the contract's, should it ever pass LINE_LIMIT."""
+    name = f"bench_detail_n{full.get('n_gpus', 1)}.json"
+    out_dir = os.path.join(REPO, "gpurun_out") if os.path.isdir(os.path.join(REPO, "gpurun_out")) else REPO
+    path = os.path.join(out_dir, name)
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        rel = os.path.relpath(path, REPO)
+    except OSError as e:
+        print(f"bench.py: cannot write {path}: {e}", file=sys.stderr)
+        rel = None
+    rec = compact_line(full, rel)
+    line = json.dumps(rec, separators=(",", ":"))
+    for k in ("level_loop_p50_ms", "side_configs", "python_binding_ms_per_step", "production_mode", "strong_scaling"):
+        if len(line) < LINE_LIMIT:
+            break
+        rec.pop(k, None)
+        line = json.dumps(rec, separators=(",", ":"))
+    return line
 
 
 def run_single(args, torch, device):
@@ -664,6 +764,20 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
         weak_other = sharded(ww, seq_w, args.mode, args.steps, other)
     except Exception as e:
         weak_other = {"error": f"{type(e).__name__}: {e}"}
+    # rank 0 alone on ONE shard's grid (the un-densified workload: exactly what `bench.py --gpus 1` times), in the same run
+    seq_1 = sequence(ww, min(args.sequence, 16))
+    alone_w = None
+    if rank == 0:
+        ww.setup(ctx)
+        alone_w = run_record(ctx, ww, seq_1, args.mode, args.steps, 3, args.min_seconds, sync, caller=args.caller)
+    dist.barrier()
+    # ranks RCCL itself carried data for: an all-reduce of ones over the nccl group (0 in a gloo rehearsal)
+    rccl_ranks = 0
+    if dist.get_backend() == "nccl":
+        ones = torch.ones(1, dtype=torch.int32, device=device)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+    ctx_wait_mode = ctx.wait_mode_name() if hasattr(ctx, "wait_mode_name") else "spin"
     ctx.close()
     # ---- ReactivePlanner.plan() with the planner's process group set: the sharding decision, the shard's rp_plan and the winner
     #      exchange all happen inside plan() (every rank drives the same closed loop on the strong-scaling workload)
@@ -675,6 +789,10 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     if rank != 0:
         return None
     head, hw, kind = (strong, ws, "strong") if args.scaling == "strong" else (weak, ww, "weak")
+    other_rec = strong_other if kind == "strong" else weak_other
+    alone_rec = alone if kind == "strong" else alone_w
+    brief = lambda r: ({k: r[k] for k in ("value", "ms_per_step", "exchange", "exchange_ms_per_step", "candidates_per_step", "error") if k in r}   # noqa: E731
+                       if isinstance(r, dict) else None)
     return {
         "metric": "candidate trajectories/sec (sample+cost+collision) per replan",
         "value": head["value"], "unit": "candidates/s", "n_gpus": world, "steps": head["steps"], "warmup": args.warmup,
@@ -687,8 +805,18 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
                    "parallelism": f"candidate-range sharding x{world}", "exchange": head["exchange"]},
         "timing": dict(head["spread_ms"], what="K-step regions bracketed by barrier + device sync, max over ranks, repeated until min-seconds; median region"),
         "roofline": head["roofline"],
+        # what a reader of a SCALE record needs beside the headline: how the winner messages travelled and what that cost per step,
+        # the same regions over the other transport, how many ranks RCCL itself saw (an all-reduce of ones over the nccl group; a
+        # rehearsal's gloo group reports 0), and rank 0 ALONE on one shard's grid in the same run (= `bench.py --gpus 1`'s workload
+        # for the weak headline: to be checked against the BENCH record)
+        "exchange": head["exchange"], "exchange_ms_per_step": head["exchange_ms_per_step"],
+        "other_transport": brief(other_rec),
+        "ranks_seen_by_rccl": rccl_ranks,
+        "one_gpu_same_grid": brief(alone_rec),
+        "strong_scaling": None if kind == "strong" else dict(brief(strong), one_gpu_same_grid_ms=alone["ms_per_step"] if alone else None),
+        "wait_mode": ctx_wait_mode,
         "strong": {"sharded": strong, "sharded_other_transport": strong_other, "one_gpu_same_grid": alone},
-        "weak": {"sharded": weak, "sharded_other_transport": weak_other},
+        "weak": {"sharded": weak, "sharded_other_transport": weak_other, "one_gpu_same_grid": alone_w},
         "plan_latency_ms": plan_lat,
         "rehearsal": bool(rehearse),
     }
@@ -753,6 +881,7 @@ def cpu_baseline(w, inp, budget_s: float):
         oracle.plan(inp, tb, 0, sample, want_states=True, scratch=keep)
     el = time.perf_counter() - t0
     out = {"value": sample * reps / el, "unit": "candidates/s", "cores": 1, "kind": "port",
+           "sample_short": f"first {sample} candidates of cycle 0, same mode, x{reps}, {el:.1f} s, C port on 1 of {os.cpu_count()} cores",
            "sample": f"first {sample} candidates of the first cycle of the same sequence and mode, {reps} repetitions, "
                      f"{el:.1f} s on 1 of {os.cpu_count()} host cores (C port; the Python reference itself ran "
                      f"~3.9e3 candidates/s/core in the build container, BASELINE.md)"}
@@ -790,6 +919,18 @@ def cpu_baseline(w, inp, budget_s: float):
     out["numpy_loop"] = {"value": n_py * reps_py / el_py, "unit": "candidates/s", "cores": 1, "kind": "port",
                          "sample": f"first {n_py} candidates, {reps_py} repetitions, {el_py:.1f} s: loop-faithful NumPy "
                                    f"restatement of the reference's per-candidate Python loop (lazy collision walk)"}
+    # B1 / B0: this restatement timed beside the imported reference on the same inputs in the build
+    # container (tests/golden/time_reference.py -> cpu_calibration.json: data only, the reference does not travel)
+    cal = load_json(os.path.join(REPO, "tests", "golden", "cpu_calibration.json"))
+    if cal.get("ratio_numpy_loop_to_reference"):
+        ratio = float(cal["ratio_numpy_loop_to_reference"])
+        out["numpy_loop"].update(ratio_to_reference=ratio, reference_value=out["numpy_loop"]["value"] / ratio,
+                                 calibration={"file": "tests/golden/cpu_calibration.json", "host_cpu": cal.get("host_cpu"),
+                                              "cases": {k: {"reference_candidates_per_s": v["reference_candidates_per_s"],
+                                                            "numpy_loop_candidates_per_s": v["numpy_loop_candidates_per_s"]}
+                                                        for k, v in cal.get("cases", {}).items()},
+                                              "what": "reference_value = this box's numpy_loop rate / (numpy_loop rate / reference rate measured "
+                                                      "in the build container on cfg1 level 3 and cfg2, one core)"})
     return out
 
 

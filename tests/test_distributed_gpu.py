@@ -79,5 +79,14 @@ def test_bench_two_ranks_rehearsal(dist_gpu_dir):
     r = json.loads(line)
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
     assert r["config"]["parallelism"] != "one GPU"
+    # the compact line (what a SCALE record of the driver holds): how the winner messages travelled, the other transport beside it,
+    # the ranks RCCL itself saw (0: a rehearsal runs on a gloo group), rank 0 alone on one shard's grid in the same run
+    assert len(line) < 4096, len(line)
+    for key in ("exchange", "exchange_ms_per_step", "other_transport", "ranks_seen_by_rccl", "one_gpu_same_grid", "strong_scaling",
+                "roofline", "wait_mode", "detail"):
+        assert key in r, (key, list(r))
+    assert r["exchange"] == r["config"]["exchange"] and r["rehearsal"] is True and r["ranks_seen_by_rccl"] == 0
+    assert r["one_gpu_same_grid"]["value"] > 0 and r["other_transport"].get("exchange") != r["exchange"]
+    full = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), r["detail"])))
     for key in ("weak", "strong"):
-        assert key in r, list(r)
+        assert key in full, list(full)
