@@ -26,6 +26,8 @@ LON_VELOCITY_KEEPING, LON_STOPPING = 0, 1
 COST_DEFAULT, COST_FAILSAFE, COST_EXTERNAL = 0, 1, 2
 FLAG_DRAW_ALL, FLAG_MATERIALIZE_ALL, FLAG_SKIP_COLLISION = 1, 2, 4
 COLLISION_AUTO, COLLISION_EAGER, COLLISION_COST_ORDERED, COLLISION_TIMED = 0, 1, 2, 3
+WAIT_SPIN, WAIT_YIELD, WAIT_EVENT = 0, 1, 2
+KERNEL_NAMES = ("rp_eval_kernel", "rp_cost_kernel", "rp_chunk_kernel")
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "librp_amd.so")
@@ -212,6 +214,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_destroy": (None, [ctx]),
         "rp_last_error": (C.c_char_p, [ctx]),
         "rp_set_profiling": (C.c_int, [ctx, C.c_int]),
+        "rp_set_wait_mode": (C.c_int, [ctx, C.c_int]),
+        "rp_get_wait_mode": (C.c_int, [ctx]),
+        "rp_set_option": (C.c_int, [ctx, C.c_char_p, C.c_int64]),
+        "rp_get_option": (C.c_int, [ctx, C.c_char_p, C.POINTER(C.c_int64)]),
         "rp_last_path": (C.c_int, [ctx]),
         "rp_last_kernel": (C.c_int, [ctx]),
         "rp_set_collision_path": (C.c_int, [ctx, C.c_int]),
@@ -275,10 +281,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_last_kernel", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+_OPTIONAL_IN_AB_BUILDS = ("rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_kernel", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
                           "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
                           "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
-EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_last_path", "rp_last_kernel", "rp_set_collision_path",
+EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_path", "rp_last_kernel", "rp_set_collision_path",
                     "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
@@ -422,16 +428,40 @@ def initial_state(ref_xy, ref_pos, ref_theta, ref_curv, ref_curv_d, x, y, orient
     return list(lon), list(lat)
 
 
+# Options every context of this process gets on top of the library's own defaults (tests and A/B measurements pin launch paths with
+# them: tests/_paths.py); ``set_default_options`` also applies them to the contexts that are alive.
+_default_options: dict = {}
+_live_contexts = None   # weakref.WeakSet of RpContext, created with the first context
+
+
+def set_default_options(options: Optional[dict]):
+    """Replace the process-wide option set: every live context goes back to the values it was created with and then takes
+    ``options`` (``rp_set_option`` names, include/rp_amd.h); contexts created later start with them."""
+    global _default_options
+    _default_options = dict(options or {})
+    for ctx in list(_live_contexts or ()):
+        if getattr(ctx, "_h", None):
+            ctx._apply_default_options()
+
+
 class RpContext:
     """Owner of one ``rp_ctx`` (device tables, work buffers, one HIP stream)."""
 
     def __init__(self, device: int = 0, library: Optional[str] = None):
+        global _live_contexts
         self._lib = load_library(library)
         self._h = C.c_void_p()
         rc = self._lib.rp_create(C.byref(self._h), int(device))
         if rc != 0:
             msg = self._lib.rp_last_error(self._h) if self._h else b"rp_create failed"
             raise RpError(f"rp_create(device={device}) -> {rc}: {(msg or b'').decode()}")
+        self._created_options = {}   # option -> the value rp_create gave it (restored when the process-wide set drops the option)
+        if _live_contexts is None:
+            import weakref
+            _live_contexts = weakref.WeakSet()
+        _live_contexts.add(self)
+        if _default_options:
+            self._apply_default_options()
         self.device = device
         self._N = None
         self._last_count = 0
@@ -455,6 +485,34 @@ class RpContext:
         if rc != 0:
             raise RpError(f"{what} -> {rc}: {(self._lib.rp_last_error(self._h) or b'').decode()}")
 
+    def set_option(self, key: str, value: int):
+        """``rp_set_option``: a launch-policy switch of this context by name (include/rp_amd.h lists them)."""
+        self._check(self._lib.rp_set_option(self._h, key.encode(), int(value)), f"rp_set_option({key!r}, {value})")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        self._check(self._lib.rp_get_option(self._h, key.encode(), C.byref(v)), f"rp_get_option({key!r})")
+        return int(v.value)
+
+    def _apply_default_options(self):
+        for k, v in self._created_options.items():
+            if k not in _default_options:
+                self.set_option(k, v)
+        for k, v in _default_options.items():
+            if k not in self._created_options:
+                self._created_options[k] = self.get_option(k)
+            self.set_option(k, v)
+
+    def set_wait_mode(self, mode: int):
+        """``rp_set_wait_mode``: WAIT_SPIN (default), WAIT_YIELD (poll + sched_yield), WAIT_EVENT (sleep on a HIP event)."""
+        self._check(self._lib.rp_set_wait_mode(self._h, int(mode)), "rp_set_wait_mode")
+
+    def wait_mode(self) -> int:
+        return int(self._lib.rp_get_wait_mode(self._h))
+
+    def wait_mode_name(self) -> str:
+        return ("spin", "yield", "event")[self.wait_mode()]
+
     def set_profiling(self, every: int):
         """Time the evaluation kernel of every ``every``-th plan with HIP events (0 / False = off)."""
         self._check(self._lib.rp_set_profiling(self._h, int(every)), "rp_set_profiling")
@@ -467,9 +525,10 @@ class RpContext:
 
     def last_kernel(self) -> str:
         """``rp_last_kernel``: the kernel that evaluated the batch of the last plan -- "rp_eval_kernel" (lanes over time steps) or
-        "rp_cost_kernel" (one lane per candidate; large batches that keep costs and labels only)."""
+        "rp_cost_kernel" (one lane per candidate; large batches that keep costs and labels only) or "rp_chunk_kernel" (one lane per candidate
+        and step block of 16; mid-sized batches that keep costs and labels only)."""
         fn = getattr(self._lib, "rp_last_kernel", None)
-        return ("rp_eval_kernel", "rp_cost_kernel")[int(fn(self._h))] if fn is not None else "rp_eval_kernel"
+        return KERNEL_NAMES[int(fn(self._h))] if fn is not None else "rp_eval_kernel"
 
     def set_collision_path(self, mode: int):
         """``rp_set_collision_path``: how production-mode plans of large batches answer the collision query -- COLLISION_AUTO

@@ -9,6 +9,7 @@
 // across the ABI, no CPU fallback: if HIP fails the call returns RP_EHIP.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -37,6 +38,10 @@ constexpr int kFoldThreshold = 8192;      // (RP_AMD_FOLD_THRESHOLD overrides) e
 constexpr size_t kAutoMaterializeBytes = 64u << 20;   // fused mode: up to this many bytes of state rows replace the winner pass
                                           // (measured: pays off from the first obstacle on, cfg4 with 5: 1.22 -> 0.89 ms)
 constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS up to this many bytes
+// costs-only launches without the collision query (profiles/probe_chunk_threshold.py): rp_chunk_kernel from this many wavefronts per CU
+// on, rp_cost_kernel from this many candidates per CU on
+constexpr int kChunkMinWavesPerCU = 7;
+constexpr int kCostMinPerCU = 832;
 // cost-ordered collision stage: capacity of the candidate lists of the three rounds and their places in d_lazy_lists
 constexpr int kLazyCap[RP_LAZY_LEVELS] = {1024, 4096, 16384};
 constexpr int kLazyOff[RP_LAZY_LEVELS] = {0, 1024, 5120};
@@ -45,9 +50,77 @@ constexpr uint32_t kLazyTarget[RP_LAZY_LEVELS] = {128, 1024, 8192};   // candida
 
 using ResultBlock = FinalizeOut;   // device -> host result block (rp_kernels.h)
 
+// Per-context options (rp_set_option / rp_get_option; include/rp_amd.h lists them).  The environment variable of an option is read
+// ONCE, in rp_create, as the context's default: no entry point that plans reads the environment.
+struct Options {
+    int lanes = 0;               // lanes per candidate of rp_eval_kernel: 0 = by batch (lanes_per_candidate), 16 | 32 | 64
+    int eval_block = 0;          // threads per workgroup of the batch's rp_eval_kernel launch: 0 = by batch (eval_block), 64 | 256
+    int cost_kernel = -1;        // rp_cost_kernel (one lane per candidate): -1 = by batch, 0 never, 1 whenever it applies
+    int chunk_kernel = -1;       // rp_chunk_kernel (one lane per candidate and step block): -1 = by batch, 0 never, 1 whenever it applies
+    int lazy = -1;               // cost-ordered collision stage: -1 = by the context's collision path, 0 never, 1 whenever the launch path allows it
+    int fused_lon = 1;           // single-launch variant for small batches
+    int fused_lon_blocks = -1;   // ... up to this many workgroups (-1: 4 per CU)
+    int auto_materialize = 1;    // small batches whose winner rows are wanted write every candidate's rows
+    int stage_out = 1, row_padding = 1, row_align = 0, tail_split = 1;   // layout of the state rows in device memory
+    int table_window = 1;        // single-launch variant stages only the part of the reference tables a plan can touch
+    int fold_threshold = kFoldThreshold;
+    int lon_publish = 1, inline_grids = 1, event_bracket = 0, winner_lanes_as_batch = 0, zero_copy = 1, coeff_groups = 1;
+    int lazy_trace = 0, print_stamps = 0, timing = 0;   // diagnostics on stderr
+    int wait_mode = RP_WAIT_SPIN;   // how the host waits for a plan's completion ticket (rp_set_wait_mode)
+};
+struct OptionDesc {
+    const char *key;
+    int Options::*field;
+    const char *env;     // environment variable read by rp_create (nullptr: none)
+    bool env_negates;    // the variable's presence means 0 (RP_AMD_NO_*); else its integer value
+    int lo, hi;          // accepted range
+};
+const OptionDesc kOptionTable[] = {
+    {"lanes", &Options::lanes, "RP_AMD_G", false, 0, 64},
+    {"eval_block", &Options::eval_block, "RP_AMD_EVAL_BLOCK", false, 0, 256},
+    {"cost_kernel", &Options::cost_kernel, "RP_AMD_COST_KERNEL", false, -1, 1},
+    {"chunk_kernel", &Options::chunk_kernel, "RP_AMD_CHUNK_KERNEL", false, -1, 1},
+    {"lazy", &Options::lazy, "RP_AMD_LAZY", false, -1, 1},
+    {"fused_lon", &Options::fused_lon, "RP_AMD_NO_FUSED_LON", true, 0, 1},
+    {"fused_lon_blocks", &Options::fused_lon_blocks, "RP_AMD_FUSED_LON_BLOCKS", false, -1, 1 << 20},
+    {"auto_materialize", &Options::auto_materialize, "RP_AMD_NO_AUTO_MATERIALIZE", true, 0, 1},
+    {"stage_out", &Options::stage_out, "RP_AMD_NO_STAGE_OUT", true, 0, 1},
+    {"row_padding", &Options::row_padding, "RP_AMD_NO_ROW_PADDING", true, 0, 1},
+    {"row_align", &Options::row_align, "RP_AMD_ROW_ALIGN", false, 0, 16},
+    {"tail_split", &Options::tail_split, "RP_AMD_NO_TAIL_SPLIT", true, 0, 1},
+    {"table_window", &Options::table_window, "RP_AMD_NO_TABLE_WINDOW", true, 0, 1},
+    {"fold_threshold", &Options::fold_threshold, "RP_AMD_FOLD_THRESHOLD", false, 1, 1 << 30},
+    {"lon_publish", &Options::lon_publish, "RP_AMD_NO_LON_PUBLISH", true, 0, 1},
+    {"inline_grids", &Options::inline_grids, "RP_AMD_NO_INLINE_GRIDS", true, 0, 1},
+    {"event_bracket", &Options::event_bracket, "RP_AMD_EVENT_BRACKET", false, 0, 1},
+    {"winner_lanes_as_batch", &Options::winner_lanes_as_batch, "RP_AMD_WINNER_G_AS_BATCH", false, 0, 1},
+    {"zero_copy", &Options::zero_copy, "RP_AMD_NO_ZERO_COPY", true, 0, 1},
+    {"coeff_groups", &Options::coeff_groups, "RP_AMD_NO_COEFF_GROUPS", true, 0, 1},
+    {"lazy_trace", &Options::lazy_trace, "RP_AMD_LAZY_TRACE", false, 0, 1},
+    {"print_stamps", &Options::print_stamps, "RP_AMD_PRINT_STAMPS", false, 0, 1},
+    {"timing", &Options::timing, "RP_AMD_TIMING", false, 0, 1},
+    {"wait_mode", &Options::wait_mode, "RP_AMD_WAIT_MODE", false, RP_WAIT_SPIN, RP_WAIT_EVENT},
+};
+const OptionDesc *find_option(const char *key) {
+    if (!key) return nullptr;
+    for (const OptionDesc &d : kOptionTable)
+        if (std::strcmp(d.key, key) == 0) return &d;
+    return nullptr;
+}
+// the environment's defaults (rp_create only)
+void options_from_environment(Options &o) {
+    for (const OptionDesc &d : kOptionTable) {
+        const char *e = d.env ? std::getenv(d.env) : nullptr;
+        if (!e) continue;
+        const int v = d.env_negates ? 0 : std::atoi(e);
+        if (v >= d.lo && v <= d.hi) o.*(d.field) = v;
+    }
+}
+
 }  // namespace
 
 struct rp_ctx {
+    Options opt;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
@@ -132,7 +205,7 @@ struct rp_ctx {
         Pending pending;
         std::vector<char> staged;
         bool staged_on_device = false, last_rows_on_device = false;
-        int last_G = 0, last_block = 0;
+        int last_G = 0, last_block = 0, last_kernel = 0, last_lazy = 0;
         size_t last_fused_lds = 0;
         int grid_index = 0;   // index of the level in the caller's array
     };
@@ -149,13 +222,14 @@ struct rp_ctx {
     int64_t *d_single = nullptr, *h_single = nullptr;
     unsigned long long *d_debug = nullptr;   // diagnostic build only
     unsigned long long seq = 0;              // completion tickets handed to the kernels
-    bool spin_wait = true;                   // wait for the ticket in the pinned result block instead of hipStreamSynchronize
+    bool spin_wait = true;                   // the kernels hand a completion ticket over in the pinned result block (off: RP_WAIT_EVENT)
+    hipEvent_t ev_done = nullptr;            // RP_WAIT_EVENT: recorded behind a plan's last launch; the host thread sleeps on it
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
     std::unordered_map<const void *, hipFunction_t> functions;   // kernel symbol -> function handle (launch_kargs)
     std::vector<double> fast_buf;   // rp_fast_buffer: grids of rp_plan_packed, written by the caller ([T | L | D | traj_len int32])
-    // RP_AMD_TIMING=1: host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
+    // option "timing": host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
     bool timing = false;
     double t_sum[6] = {0, 0, 0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack | evaluation launch | epilogue launch
     unsigned long long t_calls = 0;
@@ -284,6 +358,12 @@ int collision_level(const KArgs &ka) {
     return (ka.obs.n_sobb + ka.obs.n_tri + ka.obs.n_circ) > 0 ? 2 : 1;
 }
 
+// rp_chunk_kernel<LOW, COLL> by run-time (low-velocity mode, collision level)
+const void *chunk_kernel_fn(bool low, int coll) {
+    if (low) return coll == 2 ? (const void *)rp_chunk_kernel<true, 2> : (coll == 1 ? (const void *)rp_chunk_kernel<true, 1> : (const void *)rp_chunk_kernel<true, 0>);
+    return coll == 2 ? (const void *)rp_chunk_kernel<false, 2> : (coll == 1 ? (const void *)rp_chunk_kernel<false, 1> : (const void *)rp_chunk_kernel<false, 0>);
+}
+
 template <int G, bool MAT, bool CIN, int COLL, bool STAGE>
 void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int block = RP_BLOCK) {
     if constexpr (G == 16 && !STAGE) {   // one wavefront per workgroup (large batches of the two-kernel path: eval_block)
@@ -301,7 +381,7 @@ void launch_eval_tcs(rp_ctx *c, const KArgs &ka, int grid, size_t lds, int block
 constexpr int kFusedLonG = 16;                 // lanes per candidate of the single-launch variant
 constexpr size_t kFusedLonLdsLimit = 61440;    // LDS bytes per workgroup it may use (tables + profile rows)
 int fused_lon_max_blocks(const rp_ctx *c) {    // batches up to this many workgroups (16 candidates each) take it
-    if (const char *e = std::getenv("RP_AMD_FUSED_LON_BLOCKS")) return std::atoi(e);
+    if (c->opt.fused_lon_blocks >= 0) return c->opt.fused_lon_blocks;
     return c->num_cus * 4;
 }
 
@@ -353,28 +433,28 @@ void launch_eval_fused(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin,
 }
 
 // State rows leave through LDS as one linear stream (STAGE_OUT) for whole-wavefront candidates of the two-kernel path.
-inline bool stage_out_applies(const KArgs &ka, int G, bool mat) {
+inline bool stage_out_applies(const rp_ctx *c, const KArgs &ka, int G, bool mat) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
-    return mat && !ka.single_index && !ka.index_list && G == 64 && tile <= kStageOutLimit && !std::getenv("RP_AMD_NO_STAGE_OUT");
+    return mat && !ka.single_index && !ka.index_list && G == 64 && tile <= kStageOutLimit && c->opt.stage_out;
 }
 
 // Doubles between two rows of a state block in device memory.  Rows stored directly (every variant but STAGE_OUT) start on
 // 128-byte lines -- the line size of the L2: N + 1 rounded up to a multiple of 16, so that the 128-byte run of a group of 16
 // lanes never straddles two lines (a multiple of 8 only: 200 000 candidates at N = 100 38 % of the HBM peak instead of 55 %).
 // rp_fetch_states hands out compact [14][N + 1] blocks either way.
-inline int state_row_stride(int n, bool staged) {
-    if (staged || std::getenv("RP_AMD_NO_ROW_PADDING")) return n;
-    if (const char *e = std::getenv("RP_AMD_ROW_ALIGN")) { const int al = std::atoi(e); if (al == 8 || al == 16) return (n + al - 1) & ~(al - 1); }
+inline int state_row_stride(const rp_ctx *c, int n, bool staged) {
+    if (staged || !c->opt.row_padding) return n;
+    if (c->opt.row_align == 8 || c->opt.row_align == 16) return (n + c->opt.row_align - 1) & ~(c->opt.row_align - 1);
     return (n + 15) & ~15;
 }
 // Split tail (rp_kernels.h: state_offset): when the last step block of 16 holds at most 8 steps (N = 100: 5 of 16), the rows keep
 // the full step blocks only and the partial one is stored two rows to a 128-byte line -- whole-line stores as before, without
 // 11 doubles of padding per row (cfg4 / cfg5: 12.8 GB written for 11.5 GB of rows).  Two-kernel path, 16 lanes per candidate.
 // Returns M (0: padded rows) and sets *ns.
-inline int state_layout(int n, int G, bool fused, bool staged, int *ns) {
-    *ns = state_row_stride(n, staged);
+inline int state_layout(const rp_ctx *c, int n, int G, bool fused, bool staged, int *ns) {
+    *ns = state_row_stride(c, n, staged);
     const int r = n & 15, M = n - r;
-    if (staged || fused || G != 16 || r == 0 || r > 8 || M < 16 || *ns != ((n + 15) & ~15) || std::getenv("RP_AMD_NO_TAIL_SPLIT")) return 0;
+    if (staged || fused || G != 16 || r == 0 || r > 8 || M < 16 || *ns != ((n + 15) & ~15) || !c->opt.tail_split) return 0;
     *ns = M;
     return M;
 }
@@ -382,7 +462,7 @@ inline int state_layout(int n, int G, bool fused, bool staged, int *ns) {
 template <int G, bool MAT, bool CIN, int COLL>
 void launch_eval_tc(rp_ctx *c, const KArgs &ka, int grid, int block) {
     const size_t tile = (size_t)(RP_BLOCK / G) * RP_N_ARRAYS * (size_t)(ka.N + 1) * sizeof(double);
-    const bool stage = stage_out_applies(ka, G, MAT);
+    const bool stage = stage_out_applies(c, ka, G, MAT);
     if (MAT && stage) launch_eval_tcs<G, MAT, CIN, COLL, true>(c, ka, grid, tile);
     else launch_eval_tcs<G, MAT, CIN, COLL, false>(c, ka, grid, 0, block);
 }
@@ -399,10 +479,7 @@ void launch_eval_t(rp_ctx *c, const KArgs &ka, int grid, int block) {
 // mean more candidates per wavefront (fewer wavefronts for a batch that would otherwise need more
 // than one residency round) at the price of a longer dependent chain per wavefront.
 int lanes_per_candidate(const rp_ctx *c, int N, int64_t count, bool mat) {
-    if (const char *e = std::getenv("RP_AMD_G")) {
-        int g = std::atoi(e);
-        if (g == 16 || g == 32 || g == 64) return g;
-    }
+    if (c->opt.lanes == 16 || c->opt.lanes == 32 || c->opt.lanes == 64) return c->opt.lanes;
     // horizons of 33 .. 64 steps (the reference's default N = 60), mid-sized batches: two step blocks of 32 lanes -- half the chain of
     // four blocks of 16, twice the wavefronts -- win between the one-wavefront-per-candidate range and the batches that fill the chip
     // anyway (profiles/probe_small_n60.py, end of round 3, 32 vs 16 lanes, production / draw: 6 000 candidates 51.6 vs 57.1 / 52.0 vs
@@ -450,9 +527,8 @@ void launch_eval(rp_ctx *c, const KArgs &ka, int grid, bool mat, bool cin, int G
 // 256-thread grid would stay under the fold threshold pays a fold kernel for them (cfg3: +5 us for -2).  So: one wavefront per
 // workgroup for costs-only plans of batches that fold anyway.  RP_AMD_EVAL_BLOCK=64|256 pins the choice.
 int eval_block(const rp_ctx *c, const KArgs &ka, int64_t count, int G, bool mat) {
-    (void)c;
-    if (G != 16 || stage_out_applies(ka, G, mat) || ka.single_index || ka.index_list) return RP_BLOCK;
-    if (const char *e = std::getenv("RP_AMD_EVAL_BLOCK")) { const int b = std::atoi(e); if (b == 64 || b == RP_BLOCK) return b; }
+    if (G != 16 || stage_out_applies(c, ka, G, mat) || ka.single_index || ka.index_list) return RP_BLOCK;
+    if (c->opt.eval_block == 64 || c->opt.eval_block == RP_BLOCK) return c->opt.eval_block;
     return (!mat && count > (int64_t)kFoldThreshold * (RP_BLOCK / 16)) ? 64 : RP_BLOCK;
 }
 
@@ -530,7 +606,7 @@ void fill_common(const rp_ctx *c, const rp_params *p, const rp_cost *cost, KArgs
 void table_window(const rp_ctx *c, const rp_params *p, const rp_grids *g, KArgs &ka) {
     ka.win_n = 0;   // whole block
     const int n = c->n_ref;
-    if (n < 96 || c->n_buckets <= 0 || g->nT <= 0 || g->nL <= 0 || std::getenv("RP_AMD_NO_TABLE_WINDOW")) return;
+    if (n < 96 || c->n_buckets <= 0 || g->nT <= 0 || g->nL <= 0 || !c->opt.table_window) return;
     double Tmax = g->T[0], Lmin = g->L[0], Lmax = g->L[0];
     for (int i = 1; i < g->nT; ++i) Tmax = std::max(Tmax, g->T[i]);
     for (int i = 1; i < g->nL; ++i) { Lmin = std::min(Lmin, g->L[i]); Lmax = std::max(Lmax, g->L[i]); }
@@ -626,14 +702,35 @@ void host_winner_coeffs(const rp_ctx *c, const KArgs &ka, bool cin, rp_result *r
     r->best_lat_T = lat_T;
 }
 
-// Host wait for a completion ticket in the pinned result block (falls back to a stream sync after 200 ms)
-int wait_ticket(rp_ctx *c, unsigned long long seq) {
+// Host wait for the completion ticket `seq` in the pinned result block, by the context's wait mode (rp_set_wait_mode):
+//   RP_WAIT_SPIN   poll + pause            RP_WAIT_YIELD   poll + sched_yield
+//   RP_WAIT_EVENT  (plans: no ticket -- see wait_plan) here as YIELD
+// true: the ticket is there; false: 200 ms have passed (the caller synchronises the stream)
+bool poll_ticket(const rp_ctx *c, unsigned long long seq) {
     const volatile unsigned long long *flag = &reinterpret_cast<ResultBlock *>(c->h_result)->seq;
+    const bool yield = c->opt.wait_mode != RP_WAIT_SPIN;
     const auto t_start = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return RP_OK;
-        if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
-        __builtin_ia32_pause();
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+        if ((spins & (yield ? 0x3Fu : 0x3FFu)) == (yield ? 0x3Fu : 0x3FFu) &&
+            std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) return false;
+        if (yield) sched_yield();
+        else __builtin_ia32_pause();
+    }
+}
+int wait_ticket(rp_ctx *c, unsigned long long seq, hipStream_t stream = nullptr) {
+    if (poll_ticket(c, seq)) return RP_OK;
+    HIP_TRY(c, hipStreamSynchronize(stream ? stream : c->stream));
+    return RP_OK;
+}
+// End of a plan whose kernels are on the stream: with a ticket, wait for it; without (RP_WAIT_EVENT: c->spin_wait off when the plan
+// was launched) sleep on the event recorded behind the last launch
+int wait_plan(rp_ctx *c, bool ticket, unsigned long long seq) {
+    if (ticket) return wait_ticket(c, seq);
+    if (c->ev_done) {
+        HIP_TRY(c, hipEventRecord(c->ev_done, c->stream));
+        HIP_TRY(c, hipEventSynchronize(c->ev_done));
+        return RP_OK;
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RP_OK;
@@ -662,7 +759,7 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* wor
     k1.states = nullptr;
     if ((rc = launch_main_eval(k1, false)) != RP_OK) return rc;
     int n_partials = grid, p_first = 0;
-    static const int fold_threshold = std::getenv("RP_AMD_FOLD_THRESHOLD") ? std::atoi(std::getenv("RP_AMD_FOLD_THRESHOLD")) : kFoldThreshold;
+    const int fold_threshold = c->opt.fold_threshold;
     if (n_partials > fold_threshold) {
         hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, ka.partials_cap, n_partials,
                            c->cap_partials);
@@ -680,7 +777,7 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* wor
     launch_block(c, (const void *)rp_lazy_hist_kernel, ggrid, RP_GATHER_THREADS, 0, &ga, sizeof(ga));
     launch_block(c, (const void *)rp_lazy_gather_kernel, ggrid, RP_GATHER_THREADS, 0, &ga, sizeof(ga));
     // -- rounds
-    const int ns = state_row_stride(n, false);
+    const int ns = state_row_stride(c, n, false);
     uint32_t cnt[RP_LAZY_LEVELS] = {(uint32_t)kLazyCap[0], 0, 0};   // (round 0 is launched for a full list: its size is on the device only)
     for (int l = 0; l < RP_LAZY_LEVELS; ++l) {
         if (l > 0 && cnt[l] == 0) continue;
@@ -719,7 +816,7 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* wor
         const unsigned long long feasible = ex[3];
         cnt[0] = (uint32_t)ex[0]; cnt[1] = (uint32_t)(ex[0] >> 32); cnt[2] = (uint32_t)ex[1];
         *rounds = l + 1;
-        if (std::getenv("RP_AMD_LAZY_TRACE"))   // (diagnostic: profiles/probe_lazy_trace.py)
+        if (c->opt.lazy_trace)   // (diagnostic: profiles/probe_lazy_trace.py)
             std::fprintf(stderr, "cost-ordered stage, round %d: list sizes %u %u %u, overflow bits %x, checked %u of %llu feasible, winner %lld\n", l,
                          cnt[0], cnt[1], cnt[2], overflow, checked, feasible, (long long)hrb_host->r.best_index);
         if (overflow & ((2u << l) - 1u)) return RP_OK;              // this round's list (or an earlier one) was incomplete: not conclusive
@@ -755,21 +852,22 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         if (c->last_G) G = c->last_G;
     } else {
         // (grouped explicit polynomials: the two-kernel path -- the single-launch prologue counts one pair per candidate there)
-        if (!std::getenv("RP_AMD_NO_FUSED_LON") && !(cin && ka.pair_of)) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
+        if (c->opt.fused_lon && !(cin && ka.pair_of)) fused_lds = fused_lon_lds(c, ka, count, G, cin, mat, &fused_pairs);
     }
     ka.lds_pairs = fused_pairs;
     if (!skip_eval) {
         c->last_fused_lds = fused_lds; c->last_G = G;
-        ka.tail_split = state_layout(n, G, fused_lds != 0, !fused_lds && stage_out_applies(ka, G, mat), &ka.row_stride);   // (rp_select keeps the plan's)
+        ka.tail_split = state_layout(c, n, G, fused_lds != 0, !fused_lds && stage_out_applies(c, ka, G, mat), &ka.row_stride);   // (rp_select keeps the plan's)
     }
     int block = c->last_block ? c->last_block : RP_BLOCK;   // (rp_select: nothing of the batch is launched again)
     if (!skip_eval) { block = fused_lds ? RP_BLOCK : eval_block(c, ka, count, G, mat); c->last_block = block; }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G, block);
-    if (std::max(grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
+    const int part_grid = grid;   // (rp_cost_kernel / rp_chunk_kernel: one partial per 64 candidates, fewer than the 16-lane kernel's)
+    if (std::max(part_grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
         c->cap_partials = 0;
-        int want = std::max(std::max(grid + grid / 4, c->num_cus * kBlocksPerCU), kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64));
+        int want = std::max(std::max(part_grid + part_grid / 4, c->num_cus * kBlocksPerCU), kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64));
         HIP_TRY(c, hipMalloc((void **)&c->d_partials, (size_t)RP_PARTIAL_BYTES * ((size_t)want + kFoldPartials)));
         c->cap_partials = want;
     }
@@ -806,7 +904,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         bool lon_inline = ka.grids_inline != 0, lon_publish = false;
         if (c->grids_pending) {
             const size_t sbytes = c->staged.size();
-            if (count > 0 && !fused_lds && !cin && sbytes + 8 <= sizeof(c->kargs_gl.grid) && !std::getenv("RP_AMD_NO_LON_PUBLISH")) {
+            if (count > 0 && !fused_lds && !cin && sbytes + 8 <= sizeof(c->kargs_gl.grid) && c->opt.lon_publish) {
                 std::memcpy(c->kargs_gl.grid, c->staged.data(), sbytes);
                 lon_inline = lon_publish = true;
             } else {
@@ -833,37 +931,61 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         }
         // the evaluation kernel's duration: events attached to the launch itself (hipExtModuleLaunchKernel; RP_AMD_EVENT_BRACKET=1:
         // two hipEventRecord around it, which adds the dispatch and completion handling of the bracket -- ~2.5 us on a 14-us kernel)
-        const bool by_launch = timed && count > 0 && !std::getenv("RP_AMD_EVENT_BRACKET");
-        // Launches of large grid batches that keep no state rows -- production-mode plans, the first pass of the cost-ordered stage --
-        // take rp_cost_kernel: one lane per candidate, the lane walks the steps (rp_kernels.h).  It needs about one wavefront of 64
-        // candidates per SIMD to beat the 16-lane kernel (profiles/probe_cost_threshold.py: N = 60, 62 496 candidates 1.10 x;
-        // N = 100, 65 024: 0.90 x, 130 048: 1.23 x, 512 064: 1.62 x): from 61 440 candidates on for horizons of up to 64 steps,
-        // 98 304 beyond.  RP_AMD_COST_KERNEL=0 / 1: never / whenever the variant applies (tests).
-        // (WITH the eager collision query the walk over the obstacles is a chain of round trips per step: the 16-lane kernel, which
-        //  asks for sixteen steps of four candidates at a time, stays ahead until the batch fills the chip several times over --
-        //  profiles/probe_cost_kernel.py: cfg3 140 vs 195 us, cfg3f 165 vs 235 us, cfg5 + 50 obstacles 1 735 vs 1 147 us: from 262 144 candidates)
-        bool cost_kernel_big = false;
-        bool cost_kernel_ok = count > 0 && !fused_lds && !cin && !(ka.flags & RP_FLAG_DRAW_ALL) && !ka.single_index && !ka.index_list &&
-                              ka.cost_kind != RP_COST_EXTERNAL;
-        if (cost_kernel_ok) {
-            const char *e = std::getenv("RP_AMD_COST_KERNEL");
-            const int ev = e ? std::atoi(e) : -1;
-            cost_kernel_ok = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * (ka.N + 1 <= 64 ? 240 : 384));
-            cost_kernel_big = ev == 1 || (ev != 0 && count >= (int64_t)c->num_cus * 1024);
-        }
+        const bool by_launch = timed && count > 0 && !c->opt.event_bracket;
+        // Launches of grid batches that keep no state rows -- production-mode plans, the first pass of the cost-ordered stage -- have
+        // the time axis INSIDE the lane (rp_kernels.h):
+        //   rp_cost_kernel   one lane per candidate, the lane walks the steps.  Needs wavefronts of 64 candidates for every SIMD, four
+        //                    each to hide its own latency: from 262 144 candidates on (1 024 per CU).  (Round 4 took it from 61 440 on,
+        //                    one wavefront per SIMD, where it was 1.1 x the 16-lane kernel: profiles/probe_cost_threshold.py.)
+        //   rp_chunk_kernel  one lane per candidate and step block of 16, one wavefront per 64 candidates and step block (2 .. 7 blocks:
+        //                    horizons of 17 .. 112 steps), so that a batch the size of cfg3 (62 496 candidates, N = 60: 3 906 wavefronts
+        //                    of 17 iterations) fills the chip -- every batch of the two-kernel path below the cost kernel's range.
+        // Options "cost_kernel" / "chunk_kernel" = 0 / 1: never / whenever the variant applies (tests, A/B); -1: by batch, as above.
+        // WITH the eager collision query (no cost-ordered stage: back-off after an exhausted stage, RP_COLLISION_EAGER) the same rule:
+        // thresholds from profiles/probe_chunk_threshold.py.
+        const int n_steps = ka.N + 1;
+        const int chunk_nb = (n_steps + RP_CHUNK_STEPS - 1) / RP_CHUNK_STEPS;   // step blocks of a candidate = wavefronts of a workgroup
+        const int chunk_G = (chunk_nb >= 2 && chunk_nb <= RP_CHUNK_MAX_BLOCKS) ? chunk_nb : 0;
+        const bool lane_kernel_ok = count > 0 && !fused_lds && !cin && !(ka.flags & RP_FLAG_DRAW_ALL) && !ka.single_index && !ka.index_list &&
+                                    ka.cost_kind != RP_COST_EXTERNAL;
+        const bool cost_big = count >= (int64_t)c->num_cus * 1024;
+        // 0: rp_eval_kernel, 1: rp_cost_kernel, 2: rp_chunk_kernel -- for a launch with collision level `coll`
+        auto lane_kernel_for = [&](int coll) -> int {
+            if (!lane_kernel_ok) return 0;
+            if (c->opt.chunk_kernel == 1 && chunk_G) return 2;
+            if (c->opt.cost_kernel == 1) return 1;
+            // WITH the eager query inside the kernel the step blocks of a candidate want to run one after the other -- a candidate that has
+            // collided is not asked again, and in traffic most collide early: the 16-lane kernel (cfg3 95 us, chunk 126 us, lane 152 us;
+            // cfg3 in mostly-free traffic 113 / 128 / 182 us: profiles/probe_chunk_kernel.py), from 262 144 candidates on the lane kernel
+            if (coll > 0) return (c->opt.cost_kernel != 0 && cost_big) ? 1 : 0;
+            // without the query (profiles/probe_chunk_threshold.py, r05, kernel us 16-lane / lane / chunk):
+            //   N = 60 (4 blocks)  24 192: 22.7 / 52.6 / 24.1   32 256: 28.7 / 52.6 / 25.0   62 496: 49.9 / 53.0 / 34.0   124 992: 97 / 78 / 59
+            //                     187 488: 133 / 93 / 81       249 984: 175 / 99 / 101
+            //   N = 30 (2 blocks)  29 760: 21.3 / 31.3 / 22.4   59 520: 36.0 / 32.8 / 26.9
+            //   N = 100 (7 blocks) 65 024: 59 / 85 / 60        130 048: 108 / 101 / 112     512 064: 369 / 250 / 368  (no range where chunk wins)
+            const int64_t chunk_waves = ((count + RP_CHUNK_BLOCK - 1) / RP_CHUNK_BLOCK) * chunk_G;
+            const bool chunk_ok = c->opt.chunk_kernel != 0 && chunk_G && chunk_G <= 4 && chunk_waves >= (int64_t)c->num_cus * kChunkMinWavesPerCU;
+            if (c->opt.cost_kernel != 0 && count >= (int64_t)c->num_cus * (chunk_ok ? kCostMinPerCU : (ka.N + 1 <= 64 ? 240 : 448))) return 1;
+            return chunk_ok ? 2 : 0;
+        };
         auto launch_main_eval = [&](const KArgs &k, bool mat_) -> int {   // the batch's evaluation kernel, timed if this step is
             c->timed_by_launch = false;
             c->time_next_launch = by_launch;
             if (timed && !by_launch) HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             const auto te0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-            if (cost_kernel_ok && !mat_ && (collision_level(k) == 0 || cost_kernel_big)) {
+            const int coll = collision_level(k);
+            const int which = mat_ ? 0 : lane_kernel_for(coll);
+            if (which == 1) {
                 main_grid = (int)((count + RP_COST_BLOCK - 1) / RP_COST_BLOCK);
                 c->last_kernel = RP_KERNEL_COST;
-                const int coll = collision_level(k);
                 const void *fn = k.low_vel_mode
                     ? (coll == 2 ? (const void *)rp_cost_kernel<true, 2> : coll == 1 ? (const void *)rp_cost_kernel<true, 1> : (const void *)rp_cost_kernel<true, 0>)
                     : (coll == 2 ? (const void *)rp_cost_kernel<false, 2> : coll == 1 ? (const void *)rp_cost_kernel<false, 1> : (const void *)rp_cost_kernel<false, 0>);
                 launch_kargs(c, fn, main_grid, RP_COST_BLOCK, 0, k);
+            } else if (which == 2) {
+                main_grid = (int)((count + RP_CHUNK_BLOCK - 1) / RP_CHUNK_BLOCK);   // 64 candidates per workgroup, one wavefront per step block
+                c->last_kernel = RP_KERNEL_CHUNK;
+                launch_kargs(c, chunk_kernel_fn(k.low_vel_mode != 0, coll), main_grid, RP_CHUNK_BLOCK * chunk_G, rp_chunk_lds_bytes(chunk_G), k);
             } else {
                 main_grid = grid;
                 c->last_kernel = RP_KERNEL_EVAL;
@@ -882,8 +1004,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         // attempts had to fall back to the eager kernel (a scene where nearly everything collides).
         bool lazy_possible = count > 0 && !mat && !fused_lds && collision_level(ka) > 0 && !(ka.flags & RP_FLAG_DRAW_ALL) &&
                              ka.cost_kind != RP_COST_EXTERNAL && !ka.single_index && !ka.gate;   // (a chain of levels has no host in between)
-        const char *lazy_e = lazy_possible ? std::getenv("RP_AMD_LAZY") : nullptr;   // (read per plan: the tests switch paths)
-        const int lazy_env = lazy_e ? std::atoi(lazy_e) : -1;
+        const int lazy_env = c->opt.lazy;   // (option "lazy": the tests switch paths)
         lazy_possible = lazy_possible && lazy_env != 0 && (c->collision_mode != RP_COLLISION_EAGER || lazy_env == 1);
         const bool always = lazy_env == 1 || (lazy_env == -1 && c->collision_mode == RP_COLLISION_COST_ORDERED);
         bool lazy_try = lazy_possible && (always || (!small && c->lazy_skip == 0));
@@ -943,7 +1064,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     }
     if (!lazy_done) {
         int fin_first = 0;
-        static const int fold_threshold = std::getenv("RP_AMD_FOLD_THRESHOLD") ? std::atoi(std::getenv("RP_AMD_FOLD_THRESHOLD")) : kFoldThreshold;
+        const int fold_threshold = c->opt.fold_threshold;
         if (n_partials > fold_threshold) {   // one partial per workgroup of a very large batch: fold before the epilogue
             hipLaunchKernelGGL(rp_fold_partials_kernel, dim3(kFoldPartials), dim3(64), 0, c->stream, c->d_partials, ka.partials_cap, n_partials,
                                c->cap_partials);
@@ -991,7 +1112,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         // (two-kernel path: one candidate is one workgroup whatever the lanes -- a whole wavefront per candidate makes its chain
         //  of step blocks four times shorter than the batch's 16 lanes: cfg3 19 -> ~10 us.  Nothing was materialised that these
         //  rows could disagree with in their last bits.)
-        else launch_eval(c, kw, 1, true, cin, std::getenv("RP_AMD_WINNER_G_AS_BATCH") ? G : 64);
+        else launch_eval(c, kw, 1, true, cin, c->opt.winner_lanes_as_batch ? G : 64);
     }
     HIP_TRY(c, hipGetLastError());
     rp_ctx::Pending &pd = c->pending;
@@ -1013,18 +1134,12 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     (void)grid;
     ResultBlock *hrb_host = reinterpret_cast<ResultBlock *>(c->h_result);
     const auto tp0 = pd.tp0, tp1 = pd.tp1;
-    bool done = pd.done;
-    if (ticket && !done) {   // spin on the ticket: the result block arrives ahead of the driver's completion signal
-        const volatile unsigned long long *flag = &hrb_host->seq;
-        const auto t_start = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
-            if ((spins & 0x3FF) == 0x3FF &&
-                std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;   // fall back
-            __builtin_ia32_pause();
-        }
+    const bool done = pd.done;
+    if (!done) {   // (with a ticket: the result block arrives ahead of the driver's completion signal)
+        const int wrc = wait_plan(c, ticket, seq);
+        if (wrc != RP_OK) return wrc;
     }
-    if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hrb_host;
     const auto tp2 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
 
     c->epilogue_dirty = false;   // the chain ran through: its epilogues have left their scratch words at zero
@@ -1036,7 +1151,7 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     if (result->best_index >= 0 && best_states)
         std::memcpy(best_states, c->h_result + sizeof(ResultBlock), sizeof(double) * (size_t)RP_N_ARRAYS * (size_t)n);
 #ifdef RP_STAMPS
-    if (std::getenv("RP_AMD_PRINT_STAMPS")) {
+    if (c->opt.print_stamps) {
         unsigned long long st[32];
         HIP_TRY(c, hipMemcpy(st, c->d_debug, sizeof(st), hipMemcpyDeviceToHost));
         std::fprintf(stderr, "stamps (cycles since kernel start, batch kernel, one block):");
@@ -1069,7 +1184,7 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
     }
 #endif
 #ifdef RP_TIMELINE
-    if (std::getenv("RP_AMD_PRINT_STAMPS")) {
+    if (c->opt.print_stamps) {
         std::vector<unsigned long long> tl(2 * 4096);
         HIP_TRY(c, hipMemcpy(tl.data(), c->d_debug + 32, tl.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t1 = 0;
@@ -1162,6 +1277,7 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->ev_done, hipEventBlockingSync | hipEventDisableTiming));
     HIP_TRY(c, hipMalloc((void **)&c->d_single, sizeof(int64_t)));
     HIP_TRY(c, hipMalloc((void **)&c->d_pair_hdr_one, sizeof(PairHdr)));
     HIP_TRY(c, hipMalloc((void **)&c->d_sel_scratch, RP_SEL_SCRATCH * sizeof(unsigned long long)));
@@ -1176,7 +1292,9 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipMemset(c->d_debug, 0, (32 + 2 * 4096) * sizeof(unsigned long long)));
 #endif
     HIP_TRY(c, hipHostMalloc((void **)&c->h_single, sizeof(int64_t), hipHostMallocDefault));
-    c->timing = std::getenv("RP_AMD_TIMING") != nullptr;
+    options_from_environment(c->opt);   // (the only place the library reads RP_AMD_* switches of the plan path: defaults of this context)
+    c->timing = c->opt.timing != 0;
+    c->spin_wait = c->opt.wait_mode != RP_WAIT_EVENT;
     return RP_OK;
 }
 
@@ -1190,7 +1308,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_grid, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
-                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_sel_scratch, c->d_lazy_ctl, c->d_lazy_lists, c->d_lazy_hist, c->d_lazy_states};
+                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_sel_scratch, c->d_lazy_ctl, c->d_lazy_lists, c->d_lazy_hist, c->d_lazy_states, c->d_gate};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1199,6 +1317,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->h_single) (void)hipHostFree(c->h_single);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1221,6 +1340,31 @@ int rp_set_profiling(rp_ctx *c, int enable) {
     c->profiling = enable < 0 ? 0 : enable;   // k: every k-th call is timed (1 = every call)
     return RP_OK;
 }
+
+int rp_set_option(rp_ctx *c, const char *key, int64_t value) {
+    if (!c) return RP_EINVAL;
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_set_option: a plan is in flight on this context (rp_plan_wait first)");
+    const OptionDesc *d = find_option(key);
+    if (!d) return fail(c, RP_EINVAL, std::string("rp_set_option: unknown option '") + (key ? key : "(null)") + "'");
+    if (value < d->lo || value > d->hi) return fail(c, RP_EINVAL, std::string("rp_set_option: value out of range for '") + key + "'");
+    c->opt.*(d->field) = (int)value;
+    c->timing = c->opt.timing != 0;
+    c->spin_wait = c->opt.wait_mode != RP_WAIT_EVENT;
+    // (a change of the launch policy starts the collision-path rules over: what the earlier plans learnt belongs to the other policy)
+    c->lazy_skip = c->lazy_penalty = 0; c->path_regime = -1;
+    return RP_OK;
+}
+
+int rp_get_option(const rp_ctx *c, const char *key, int64_t *value) {
+    if (!c || !value) return RP_EINVAL;
+    const OptionDesc *d = find_option(key);
+    if (!d) return RP_EINVAL;
+    *value = c->opt.*(d->field);
+    return RP_OK;
+}
+
+int rp_set_wait_mode(rp_ctx *c, int mode) { return rp_set_option(c, "wait_mode", mode); }
+int rp_get_wait_mode(const rp_ctx *c) { return c ? c->opt.wait_mode : RP_WAIT_SPIN; }
 
 int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *ref_theta, const double *ref_curv,
                      const double *ref_curv_d, const double *ref_x, const double *ref_y, double proj_domain_d_limit) {
@@ -1537,7 +1681,7 @@ int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->chain.size() > 1) {
         // a chain of levels: one ticket; the result block names the level it belongs to, whose launch state becomes the context's
-        int rc = wait_ticket(c, c->chain.front().pending.seq);
+        int rc = wait_plan(c, c->chain.front().pending.ticket, c->chain.front().pending.seq);   // (RP_WAIT_EVENT: no ticket was asked for)
         if (rc != RP_OK) { c->pending.active = false; c->chain.clear(); return rc; }
         const int tag = (int)reinterpret_cast<const ResultBlock *>(c->h_result)->pad_;
         if (tag < 1 || tag > (int)c->chain.size()) { c->pending.active = false; c->chain.clear(); return fail(c, RP_EHIP, "rp_plan_wait: result block of a level chain without its level"); }
@@ -1546,6 +1690,7 @@ int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
         c->pending.done = true;   // (the ticket has arrived)
         c->staged = st.staged; c->staged_on_device = false; c->last_rows_on_device = st.last_rows_on_device;
         c->last_G = st.last_G; c->last_block = st.last_block; c->last_fused_lds = st.last_fused_lds;
+        c->last_kernel = st.last_kernel; c->last_lazy = st.last_lazy;   // (rp_last_kernel / rp_last_path: of the level the result belongs to)
         // the grids of that level are what later launches on this context (winner re-evaluation, rp_eval_one) find in their launch blocks
         if (!c->staged.empty() && c->staged.size() <= sizeof(c->kargs_g.grid)) {
             std::memcpy(c->kargs_g.grid, c->staged.data(), c->staged.size());
@@ -1612,7 +1757,7 @@ int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp
     // Small batches whose winner block is wanted: write every candidate's state rows anyway.  The alternative -- a
     // second launch that re-evaluates the winner -- costs 12.6 us on cfg2, the rows of 7 440 candidates 2-3 us.
     if (!mat && best_states && (size_t)count * RP_N_ARRAYS * (size_t)n * sizeof(double) <= kAutoMaterializeBytes &&
-        !std::getenv("RP_AMD_NO_AUTO_MATERIALIZE"))
+        c->opt.auto_materialize)
         mat = true;
     HIP_TRY(c, hipSetDevice(c->device));
 
@@ -1626,7 +1771,7 @@ int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp
     std::memcpy(hs + g->nT, g->L, sizeof(double) * g->nL);
     std::memcpy(hs + g->nT + g->nL, g->D, sizeof(double) * g->nD);
     std::memcpy(hs + nd, g->traj_len, sizeof(int32_t) * g->nT);
-    const bool grids_inline = sbytes <= sizeof(c->kargs_g.grid) && !std::getenv("RP_AMD_NO_INLINE_GRIDS");
+    const bool grids_inline = sbytes <= sizeof(c->kargs_g.grid) && c->opt.inline_grids;
     c->grids_pending = false;
     if (grids_inline) {   // the grids ride in the kernarg segment of the launches: no copy on the stream
         std::memcpy(c->kargs_g.grid, c->h_stage, sbytes);
@@ -1677,13 +1822,12 @@ int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp
 // Can this level ride in a chain?  Its grids travel in the launches' kernarg segments (the staging buffer is one per context), its
 // epilogue is the one-workgroup kernel, and the plan needs no decision of the host between its kernels.
 bool level_chainable(const rp_ctx *c, const rp_params *p, const rp_grids *g) {
-    (void)c;
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return false;
     const int64_t total = (int64_t)g->nT * g->nL * g->nD;
     const size_t sbytes = ((size_t)g->nT + g->nL + g->nD) * sizeof(double) + (size_t)g->nT * sizeof(int32_t);
-    if (total > RP_FINALIZE_MAX || sbytes > sizeof(((KArgsG *)nullptr)->grid) || std::getenv("RP_AMD_NO_INLINE_GRIDS")) return false;
+    if (total > RP_FINALIZE_MAX || sbytes > sizeof(((KArgsG *)nullptr)->grid) || !c->opt.inline_grids) return false;
     // (plans of this size that want the winner's rows write every candidate's: no winner re-evaluation, no cost-ordered stage)
-    return (size_t)total * RP_N_ARRAYS * (size_t)(p->N + 1) * sizeof(double) <= kAutoMaterializeBytes;
+    return c->opt.auto_materialize && (size_t)total * RP_N_ARRAYS * (size_t)(p->N + 1) * sizeof(double) <= kAutoMaterializeBytes;
 }
 }  // namespace
 
@@ -1759,6 +1903,7 @@ int rp_plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int
         rp_ctx::LevelState st;
         st.pending = c->pending; st.staged = c->staged; st.staged_on_device = c->staged_on_device; st.last_rows_on_device = c->last_rows_on_device;
         st.last_G = c->last_G; st.last_block = c->last_block; st.last_fused_lds = c->last_fused_lds; st.grid_index = k;
+        st.last_kernel = c->last_kernel; st.last_lazy = c->last_lazy;
         c->chain.push_back(std::move(st));
         ++launched;
     }
@@ -1853,7 +1998,7 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
     // else is copied into the pinned staging buffer first (2.4 MB at 25 536 candidates: a quarter of a millisecond of memcpy)
     const double *d_lon = nullptr, *d_lat = nullptr;
     const int32_t *d_tl = nullptr;
-    static const bool no_zero_copy = std::getenv("RP_AMD_NO_ZERO_COPY") != nullptr;   // (A/B: arena rows through the staging copy)
+    const bool no_zero_copy = !c->opt.zero_copy;   // (A/B: arena rows through the staging copy)
     const bool in_arena = !no_zero_copy && c->h_arena && C <= c->arena_cap && lon_coeffs == reinterpret_cast<const double *>(c->h_arena) &&
                           lat_coeffs == reinterpret_cast<const double *>(c->h_arena) + 6 * c->arena_cap &&
                           traj_len == reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena) + 12 * c->arena_cap);
@@ -1896,10 +2041,10 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
     // candidates in groups with a common longitudinal polynomial: one profile per group (pair = group).  Out of the arena only -- the
     // kernels read the group tables where the sampling space wrote them, as they read the polynomials.
     c->cin_groups = 0; c->cin_group_of = nullptr;
-    static const bool no_groups = std::getenv("RP_AMD_NO_COEFF_GROUPS") != nullptr;   // (A/B: one profile per candidate)
+    const bool no_groups = !c->opt.coeff_groups;   // (A/B: one profile per candidate)
     // (a level small enough for the single-launch variant keeps one pair per candidate: one launch less beats the shared profiles there)
     int fused_pairs_q = 0;
-    const bool single_launch = !std::getenv("RP_AMD_NO_FUSED_LON") &&
+    const bool single_launch = c->opt.fused_lon &&
                                fused_lon_lds(c, ka, C, lanes_per_candidate(c, ka.N, C, mat), true, mat, &fused_pairs_q) != 0;
     if (n_groups > 0 && group && group_first && !no_zero_copy) {   // (RP_AMD_NO_ZERO_COPY: the A/B path copies the rows, the group tables stay behind)
         int32_t *tl_h = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(c->h_arena) + 12 * c->arena_cap);
@@ -2103,17 +2248,8 @@ int rp_combine_results(rp_ctx *c, const void *d_msgs, int32_t world, void *strea
     hipLaunchKernelGGL(rp_combine_kernel, dim3(1), dim3(RP_COMBINE_THREADS), 0, st, reinterpret_cast<const char *>(d_msgs), (int)world,
                        msg_bytes, n, reinterpret_cast<ResultBlock *>(c->h_result_dev), seq);
     HIP_TRY(c, hipGetLastError());
-    bool done = false;
-    {   // the all-gather ahead of the kernel can take a while on a cold communicator: spin with a generous fall-back
-        const volatile unsigned long long *flag = &hrb_host->seq;
-        const auto t_start = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
-            if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
-            __builtin_ia32_pause();
-        }
-    }
-    if (!done) {
+    // (the all-gather ahead of the kernel can take a while on a cold communicator: poll with a generous fall-back)
+    if (!poll_ticket(c, seq)) {
         HIP_TRY(c, hipStreamSynchronize(st));
         if (__atomic_load_n(&hrb_host->seq, __ATOMIC_ACQUIRE) != seq) return fail(c, RP_EHIP, "rp_combine_results: no completion ticket");
     }
@@ -2187,17 +2323,7 @@ int rp_check_swept(rp_ctx *c, const rp_params *p, int32_t n_poses, const double 
     hipLaunchKernelGGL(rp_swept_kernel, dim3(1), dim3(RP_SWEPT_THREADS), 0, c->stream, c->obs, (int)n_poses, p->wb_rear_axle, 0.5 * p->length,
                        0.5 * p->width, (int)p->time_step0, reinterpret_cast<ResultBlock *>(c->h_result_dev), boxes ? 1 : 0, seq);
     HIP_TRY(c, hipGetLastError());
-    bool done = false;
-    if (c->spin_wait) {
-        const volatile unsigned long long *flag = &hrb_host->seq;
-        const auto t_start = std::chrono::steady_clock::now();
-        for (unsigned spins = 0;; ++spins) {
-            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) { done = true; break; }
-            if ((spins & 0x3FF) == 0x3FF && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(200)) break;
-            __builtin_ia32_pause();
-        }
-    }
-    if (!done) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->opt.wait_mode == RP_WAIT_EVENT || !poll_ticket(c, seq)) HIP_TRY(c, hipStreamSynchronize(c->stream));
     const unsigned int hit = (unsigned int)hrb_host->n_before;
     *first_hit = hit < (unsigned int)(n_poses - 1) ? (int32_t)hit : -1;
     if (boxes) std::memcpy(boxes, h_poses + 3 * n, sizeof(double) * 6 * (n - 1));

@@ -2624,10 +2624,13 @@ __global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_W
         // last valid state (step L - 1) for the horizon extension (trajectories.py:168-197, 302-332)
         double l_v = 0.0, l_acc = 0.0, l_s = 0.0, l_d = 0.0, l_thcl = 0.0, l_sd = 0.0, l_dd = 0.0;
         double l_x = 0.0, l_y = 0.0, l_cos = 1.0, l_sin = 0.0, cumx = 0.0, cumy = 0.0;   // (COLL: poses of the extended steps)
-        // profile rows: wave-uniform row bases (scalar registers) + one 32-bit byte offset per lane (its pair's block)
-        const uint32_t voff = (uint32_t)pair_slot * (uint32_t)PF_FIELDS * (uint32_t)n * 8u;
-        const char *const pb = reinterpret_cast<const char *>(a.profile);
+        // profile rows: wave-uniform row bases (scalar registers; the block of the wavefront's FIRST pair) + one 32-bit byte offset per
+        // lane (its pair's block behind that one: a wavefront spans at most 64 pairs -- an offset from the batch's first pair would wrap
+        // at 4 GiB of profile rows, 8 192 pairs at N = 4 094)
         const size_t n8 = (size_t)n * 8;
+        const int32_t pair_w = __builtin_amdgcn_readfirstlane((int32_t)pair_slot);
+        const uint32_t voff = (uint32_t)((int32_t)pair_slot - pair_w) * (uint32_t)PF_FIELDS * (uint32_t)n8;
+        const char *const pb = reinterpret_cast<const char *>(a.profile) + (size_t)pair_w * PF_FIELDS * n8;
 #pragma nounroll
         for (int i = 0; i <= N; ++i) {   // wave-uniform
             const bool act = i < L;
@@ -2802,6 +2805,366 @@ __global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_W
         const unsigned int n_coll = (unsigned int)__popcll(__ballot(valid && lab == RP_LABEL_INFEASIBLE_COLLISION));
         mine = lane == 1 ? n_coll : mine;
         if (lane < RP_PARTIAL_CNT) bp.cnt[lane] = mine;
+        if (lane == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rp_chunk_kernel -- costs-only evaluation of MID-SIZED grid batches: ONE LANE PER (CANDIDATE, STEP BLOCK OF 16 STEPS), one WAVEFRONT
+// per (64 candidates, step block).
+//
+// rp_cost_kernel (one lane per candidate) needs a wavefront of 64 candidates per SIMD -- four to hide its own instruction latency:
+// 262 144 candidates -- before it beats the lanes-over-steps kernel; a batch the size of cfg3 (62 496 candidates, N = 60) leaves it
+// one wavefront per SIMD, issuing an instruction every ten cycles.  This kernel keeps its instruction stream -- the time axis inside
+// the lane: the previous step is a register, the first failure is the step the loop is at, the extension reads registers; what is
+// uniform over a (T, longitudinal sample) pair is uniform over the wavefront -- and cuts the time axis of a candidate into its step
+// blocks of sixteen (the blocks rp_eval_kernel's sixteen lanes walk one after the other): a workgroup of NB = ceil((N + 1) / 16)
+// wavefronts evaluates 64 candidates, wavefront q their step block q, and cfg3 fills the chip with 3 906 wavefronts of seventeen
+// iterations.
+// (All lanes of a wavefront at the SAME step: a block of extended states runs the few instructions of the extension only, the (pair,
+// step) masks of the collision query and the obstacle rows are wave-uniform.  Measured first, and dropped: the G blocks of a candidate
+// in the lanes of ONE wavefront -- every iteration then runs the valid-step code AND the extension, the query walks the obstacles
+// near four different time steps: cfg3 46 us without / 156 us with the eager query, against 52 / 95 us of the 16-lane kernel.)
+// What crosses a block boundary:
+//   * theta and kappa of the step in front of the block (yaw rate and kappa_dot are first differences, reactive_planner.py:923,993)
+//     and the last valid state (step L - 1) for a block of extended states (trajectories.py:168-197, 302-332): every wavefront but the
+//     first runs ONE iteration ahead of its block -- step min(16 q - 1, L - 1) without constraints, cost or collision query;
+//     the standstill carry of the orientation (:866: a chain over the steps) is resolved there by looking the last moving step
+//     up in the profile (whether a step moves depends on the pair alone);
+//   * the first failing step, the first step out of the projection domain, "some pose collides": through LDS behind the loop, the
+//     first block that has one / any block;
+//   * the cost: rp_eval_kernel sums it as sixteen partial sums by step mod 16, each over the step blocks in ascending order, then the
+//     tree of group_sum_last<16> -- here every lane leaves ITS block's sixteen terms in LDS and the workgroup's first wavefront forms
+//     the partial sums over the blocks in ascending order: the same additions in the same order, the same bits (rp_cost_kernel does
+//     the same inside a lane).
+// Arithmetic: expression for expression that of rp_eval_kernel / rp_cost_kernel (same labels, reasons, first failing steps, costs).
+// Grid plans, no state rows, two-kernel path (profiles from rp_lon_kernel), 17 <= N + 1 <= 112 (two to seven step blocks).
+// ------------------------------------------------------------------------------------------------
+#define RP_CHUNK_BLOCK 64    // candidates per workgroup (one wavefront per step block of theirs: G * 64 threads)
+#define RP_CHUNK_STEPS 16
+#define RP_CHUNK_MAX_BLOCKS 7   // step blocks (= wavefronts of a workgroup): 7 * (8 KB of cost terms + 768 B of keys) < 64 KB of LDS; N + 1 <= 112
+__host__ __device__ constexpr size_t rp_chunk_lds_bytes(int nb) { return (size_t)nb * (RP_CHUNK_STEPS * RP_CHUNK_BLOCK * sizeof(double) + 3 * RP_CHUNK_BLOCK * sizeof(int)); }
+template <bool LOW, int COLL>
+#ifndef RP_CHUNK_WAVES
+#define RP_CHUNK_WAVES RP_COST_WAVES
+#endif
+__global__ __launch_bounds__(RP_CHUNK_BLOCK * RP_CHUNK_MAX_BLOCKS, COLL ? RP_WAVES_PER_SIMD : RP_CHUNK_WAVES) void rp_chunk_kernel(const KArgsG ag) {
+    const KArgs &a = ag.k;
+    extern __shared__ double lds_chunk[];   // [NB][16][64] cost terms | [3][NB][64] int keys (rp_chunk_lds_bytes)
+    const int NB = (int)(blockDim.x >> 6);  // step blocks per candidate = wavefronts of this workgroup (2 .. RP_CHUNK_MAX_BLOCKS)
+    touch_kernargs<10>();
+    if (level_gate_closed(a.gate, a.gate_seq, a.gate_level)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;                // this lane's candidate inside the workgroup
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);   // this wavefront's step block (wave-uniform)
+    const int64_t count = a.count;
+    const int64_t w0 = (int64_t)blockIdx.x * RP_CHUNK_BLOCK;
+    if (a.lazy_ctl && blockIdx.x == 0 && tid < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
+        reinterpret_cast<unsigned long long *>(a.lazy_ctl)[tid] = 0ull;
+    const int64_t slot = w0 + lane;
+    const bool valid = slot < count;
+    const int64_t gidx = a.cand_begin + (valid ? slot : w0);   // (lanes behind the batch shadow the wavefront's first candidate)
+    // ---- candidate: lateral sample, pair header, lateral polynomial (sampling.py:226-238, 268-270)
+    const uint32_t g32 = (uint32_t)gidx, nd = (uint32_t)a.nD;
+    const uint32_t p32 = g32 / nd;
+    const double d_target = grid_base(a)[a.nT + a.nL + (int)(g32 - p32 * nd)];
+    const int32_t pair_slot = (int32_t)((int64_t)p32 - a.pair_begin);
+    const int32_t pair_w = __builtin_amdgcn_readfirstlane(pair_slot);   // pair of the wavefront's first candidate: wave-uniform base
+    const PairHdr h = a.pair_hdr[pair_slot];
+    const int L = h.L;
+    const double s0 = h.s0;
+    const uint32_t pre_reason = (uint32_t)h.pre_reason;
+    const Poly lat = quintic_coeffs(a.x0_lat[0], a.x0_lat[1], a.x0_lat[2], d_target, 0.0, 0.0, h.lat_T);
+    double P[16];
+    park_poly(P, lat);
+    const int N = a.N, n = N + 1;
+    const double dt = a.dt;
+    constexpr bool low = LOW;
+    const uint32_t cm = a.constraint_mask;
+    const int mid = n / 2;
+    auto p_pos = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(rp_fma3(rp_fma3(P[5], t, P[4]), t, P[3]), t, P[2]), t, P[1]), t, P[0]); };
+    auto p_vel = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(rp_fma3(P[10], t, P[9]), t, P[8]), t, P[7]), t, P[6]); };
+    auto p_acc = [&](double t) { return rp_fma3(rp_fma3(rp_fma3(P[14], t, P[13]), t, P[12]), t, P[11]); };
+
+    auto cost_terms = [&](int i, double acc, double v, double s, double d, double th_cl) -> double {   // (rp_eval_kernel's, word for word)
+        double e, cst;
+        e = a.w_a * acc; cst = e * e;
+        e = 0.25 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+        e = 0.25 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+        if (a.has_speed) { e = 5.0 * (v - a.desired_speed); cst = __builtin_fma(e, e, cst); }
+        if (a.has_s) { e = 0.25 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        if (i == N) {
+            e = 20.0 * (a.desired_d - d); cst = __builtin_fma(e, e, cst);
+            e = 5.0 * fabs(th_cl); cst = __builtin_fma(e, e, cst);
+            if (a.has_speed) { e = v - a.desired_speed; cst += 50.0 * (e * e); }
+            if (a.has_s) { e = 20.0 * (a.desired_s - s); cst = __builtin_fma(e, e, cst); }
+        }
+        if (i == mid && a.has_speed) { e = v - a.desired_speed; cst += 100.0 * (e * e); }
+        return cst;
+    };
+
+    int fail_step = -1, ood_step = -1;
+    uint32_t fail_reason = RP_REASON_NONE;
+    bool collide = false;
+    // this lane's sixteen cost terms (one per step of its block), [block][j][candidate]: summed over the blocks behind the loop
+    typedef double __attribute__((address_space(3))) *lds_double;
+    typedef int __attribute__((address_space(3))) *lds_int;
+    const lds_double csum = (lds_double)(lds_chunk + ((size_t)q * RP_CHUNK_STEPS) * RP_CHUNK_BLOCK + lane);
+    const lds_int keys = (lds_int) reinterpret_cast<int *>(lds_chunk + (size_t)NB * RP_CHUNK_STEPS * RP_CHUNK_BLOCK);   // [3][NB][64]: fail, ood, collide
+#pragma unroll
+    for (int k = 0; k < RP_CHUNK_STEPS; ++k) csum[k * RP_CHUNK_BLOCK] = 0.0;
+    const int i_first = q * RP_CHUNK_STEPS;          // first step of this wavefront's block
+    const bool has_block = i_first <= N;             // (the host launches ceil((N + 1) / 16) wavefronts: every one has a step)
+    bool alive = valid && pre_reason == RP_REASON_NONE && has_block;
+    if (__ballot(alive) != 0) {   // wave-uniform
+        double th_prev = a.x0_orientation, ka_prev = 0.0;
+        // last valid state (step L - 1) for the horizon extension (trajectories.py:168-197, 302-332)
+        double l_v = 0.0, l_acc = 0.0, l_s = 0.0, l_d = 0.0, l_thcl = 0.0, l_sd = 0.0, l_dd = 0.0;
+        double l_x = 0.0, l_y = 0.0, l_cos = 1.0, l_sin = 0.0, cumx = 0.0, cumy = 0.0;   // (COLL: poses of the extended steps)
+        // profile rows: wave-uniform row bases (the block of the wavefront's first pair) + one 32-bit byte offset per lane
+        const size_t n8 = (size_t)n * 8;
+        const char *const pb = reinterpret_cast<const char *>(a.profile) + (size_t)pair_w * PF_FIELDS * n8;
+        const uint32_t voff = (uint32_t)(pair_slot - pair_w) * (uint32_t)PF_FIELDS * (uint32_t)n8;
+        // iteration -1: the step in front of the block (or the last valid step, if that comes first) -- see the header
+        const int i_pre = i_first - 1 < L - 1 ? i_first - 1 : L - 1;
+#pragma nounroll
+        for (int j = -1; j < RP_CHUNK_STEPS; ++j) {   // wave-uniform
+            const bool pre = j < 0;
+            const int i = pre ? i_pre : i_first + j;
+            const bool live = pre ? (q > 0 && has_block) : i <= N;   // (q > 0: i_pre >= 0, since L >= 1)
+            const bool act = live && i < L;
+            const uint32_t ioff = voff + (uint32_t)(live ? i : 0) * 8u;
+            auto fld = [&](int k) -> double { return *reinterpret_cast<const double *>(pb + (size_t)k * n8 + ioff); };
+            double pose_x = 0.0, pose_y = 0.0, pose_cos = 1.0, pose_sin = 0.0;   // (COLL) rear-axle pose of this lane at step i
+            if (__any(act)) {   // (wave-uniform) some lane's step is a valid one
+                // -- the pair's profile at this step
+                double s = fld(PF_S), sd = fld(PF_SD), sdd = fld(PF_SDD);
+                const double inv_sd = fld(PF_INV_SD), th_ref = fld(PF_TH_REF);
+                const double k_r = fld(PF_KR), k_r_d = fld(PF_KRD);
+                const bool s_in_dom = fld(PF_INDOM) != 0.0;
+                // -- lateral polynomial, reactive_planner.py:756-777
+                const double t = (double)i * dt;
+                const double tau = low ? s - s0 : t;
+                double d = p_pos(tau), dd = p_vel(tau), ddd = p_acc(tau);
+                if (fabs(dd) < RP_EPS) dd = 0.0;
+                // -- d', d'' (:810-832)
+                const bool moving = inv_sd > 0.0;
+                double dp, dpp;
+                if (!low) {
+                    dp = dd * inv_sd;
+                    const double ddot = ddd - dp * sdd;
+                    dpp = ddot * inv_sd * inv_sd;
+                } else {
+                    dp = dd;
+                    dpp = ddd;
+                }
+                // -- orientations (:842-873) incl. the standstill carry of :866
+                const bool use_atan = moving || low;
+                double th_cl = rp_atan(dp);
+                double th_gl = th_cl + th_ref;
+                const double w2 = __builtin_fma(dp, dp, 1.0);
+                double cosT = rp_rsqrt(w2);
+                double secT = w2 * cosT;
+                double tanT = dp;
+                if (!low && __any(act && !use_atan)) {   // standstill lanes keep the orientation of the step before (:866)
+                    if (pre && act && !use_atan) {
+                        // the step before is not this lane's: the orientation it carries is that of the last MOVING step in front of
+                        // step i (x_0's when there is none) -- theta_cl + theta_ref there, with theta_cl = atan(d' / s')
+                        int m = i - 1;
+                        double inv_m = 0.0;
+                        while (m >= 0) {
+                            inv_m = *reinterpret_cast<const double *>(pb + (size_t)PF_INV_SD * n8 + voff + (uint32_t)m * 8u);
+                            if (inv_m > 0.0) break;
+                            --m;
+                        }
+                        th_prev = a.x0_orientation;
+                        if (m >= 0) {
+                            double ddm = p_vel((double)m * dt);
+                            if (fabs(ddm) < RP_EPS) ddm = 0.0;
+                            th_prev = rp_atan(ddm * inv_m) + *reinterpret_cast<const double *>(pb + (size_t)PF_TH_REF * n8 + voff + (uint32_t)m * 8u);
+                        }
+                    }
+                    if (!use_atan) {
+                        th_gl = th_prev;
+                        th_cl = th_gl - th_ref;
+                    }
+                    double sn, cs;
+                    rp_sincos(th_cl, &sn, &cs);
+                    const double sc = rp_rcp(cs);
+                    cosT = use_atan ? cosT : cs;
+                    secT = use_atan ? secT : sc;
+                    tanT = use_atan ? tanT : sn * sc;
+                }
+                // -- curvature, velocity, acceleration (:883-896)
+                const double oneKrD = 1.0 - k_r * d;
+                const double qk = cosT * rp_rcp(oneKrD);
+                const double kterm = frenet_kterm(k_r_d, d, k_r, dp);
+                double kappa = frenet_kappa(dpp, kterm, tanT, cosT, qk, k_r);
+                const double f = oneKrD * secT;
+                double v = sd * f;
+                double acc = frenet_acc(sdd, f, sd, secT, oneKrD, tanT, kappa, k_r, kterm);
+                const double dth = i > 0 ? th_gl - th_prev : 0.0;
+                const double kdot = i > 0 ? kappa - ka_prev : 0.0;
+                // -- _check_constraints, reactive_planner.py:971-1017 (order: velocity, kappa, yaw, kappa_dot, acc)
+                uint32_t reason = RP_REASON_NONE;
+                {
+                    const double a_max = a.a_max, v_switch = a.v_switch, kappa_max = a.kappa_max;
+                    const double wk = a.wheelbase * kappa;
+                    const bool bad_yaw = fabs(rint(dth * a.c_yaw)) > kappa_max * v * 1e5;
+                    const bool bad_kd = fabs(kdot) > a.c_kdot * __builtin_fma(wk, wk, 1.0);
+                    const bool fast = v > v_switch;
+                    const double acc_l = fast ? acc * v : acc, acc_r = fast ? a_max * v_switch : a_max;
+                    const bool bad_acc = !((-a_max <= acc) & (acc_l <= acc_r));
+                    const bool bad_v = v < -RP_EPS, bad_k = fabs(kappa) > kappa_max;
+                    reason = (((cm & RP_CHECK_ACCELERATION) != 0) & bad_acc) ? RP_REASON_ACCELERATION : reason;
+                    reason = (((cm & RP_CHECK_KAPPA_DOT) != 0) & bad_kd) ? RP_REASON_KAPPA_DOT : reason;
+                    reason = (((cm & RP_CHECK_YAW_RATE) != 0) & bad_yaw) ? RP_REASON_YAW_RATE : reason;
+                    reason = (((cm & RP_CHECK_KAPPA) != 0) & bad_k) ? RP_REASON_KAPPA : reason;
+                    reason = (((cm & RP_CHECK_VELOCITY) != 0) & bad_v) ? RP_REASON_VELOCITY : reason;
+                    reason = (act && !pre) ? reason : RP_REASON_NONE;   // (the step in front of the block is judged by the lane that owns it)
+                }
+                if (reason != RP_REASON_NONE && fail_step < 0) { fail_step = i; fail_reason = reason; alive = false; }
+                // -- out of the projection domain (:908-917): no reason counter, the kinematic verdict of a later step still counts
+                const bool in_dom = s_in_dom && fabs(d) <= a.proj_d_limit;
+                if (act && !pre && !in_dom && ood_step < 0) ood_step = i;
+                if (COLL) {   // (s, d) -> (x, y) = foot point + d * unit normal (:908-917); heading from cos / sin of theta_ref and theta_cl
+                    const double sinT = tanT * cosT;
+                    pose_x = fld(PF_PX) + d * fld(PF_NX);
+                    pose_y = fld(PF_PY) + d * fld(PF_NY);
+                    pose_cos = heading_cos(fld(PF_COS_REF), fld(PF_SIN_REF), cosT, sinT);
+                    pose_sin = heading_sin(fld(PF_COS_REF), fld(PF_SIN_REF), cosT, sinT);
+                }
+                if (act) {
+                    if (!pre) csum[j * RP_CHUNK_BLOCK] = cost_terms(i, acc, v, s, d, th_cl);
+                    th_prev = th_gl;
+                    ka_prev = kappa;
+                }
+                if (__any(act && i == L - 1)) {   // (wave-uniform) the last valid state: in its own block, and ahead of every block of extended states
+                    const bool lastv = act && i == L - 1;
+                    l_v = lastv ? v : l_v; l_acc = lastv ? acc : l_acc; l_s = lastv ? s : l_s; l_d = lastv ? d : l_d;
+                    l_thcl = lastv ? th_cl : l_thcl; l_sd = lastv ? sd : l_sd; l_dd = lastv ? dd : l_dd;
+                    if (COLL) { l_x = lastv ? pose_x : l_x; l_y = lastv ? pose_y : l_y; l_cos = lastv ? pose_cos : l_cos; l_sin = lastv ? pose_sin : l_sin; }
+                }
+                if (__ballot(alive) == 0) break;   // wave-uniform: every candidate has failed in this block
+            }
+            if (pre) {
+                // (COLL) the extended steps in front of this lane's block, L .. i_first - 1: x[L:] = x[last] + cumsum(dt * v_tmp * cos(theta[last])) (:195-196)
+                if (COLL && __any(live && i_first > L)) {
+                    for (int k = 0; __any(live && L + k < i_first); ++k) {
+                        if (live && L + k < i_first) {
+                            const double tk = (double)(k + 1) * dt;
+                            double vt = l_v + tk * l_acc;
+                            vt = vt * (vt >= 0.0 ? 1.0 : 0.0);
+                            cumx += dt * vt * l_cos;
+                            cumy += dt * vt * l_sin;
+                        }
+                    }
+                }
+                continue;
+            }
+            if (live && !act) {   // i >= L: extended state (cost_function.py sums over the extended arrays)
+                const double tk = (double)(i - L + 1) * dt;   // np.arange(1, steps + 1) * dt
+                double vt = l_v + tk * l_acc;                 // :182
+                vt = vt * (vt >= 0.0 ? 1.0 : 0.0);            // :184
+                const double e_s = l_s + tk * l_sd;           // :330
+                const double e_d = l_d + tk * l_dd;           // :331
+                csum[j * RP_CHUNK_BLOCK] = cost_terms(i, l_acc, vt, e_s, e_d, l_thcl);
+                if (COLL) {   // heading held (:188)
+                    cumx += dt * vt * l_cos;
+                    cumy += dt * vt * l_sin;
+                    pose_x = l_x + cumx; pose_y = l_y + cumy; pose_cos = l_cos; pose_sin = l_sin;
+                }
+            }
+            // -- eager collision query for this pose, reactive_planner.py:1033-1046
+            if (COLL) {
+                const bool want = live && alive && fail_step < 0 && ood_step < 0 && !collide;
+                const double ego_cx = pose_x + a.wb_rear_axle * pose_cos, ego_cy = pose_y + a.wb_rear_axle * pose_sin;
+                const uint64_t near_dyn = want ? double_as_mask(fld(PF_NEAR)) : 0;
+                uint64_t near_sta = 0;
+                if (COLL == 2 && want)
+                    near_sta = static_grid_mask(a.obs.grid, a.obs.gx0, a.obs.gy0, a.obs.ginv, a.obs.gnx, a.obs.gny, ego_cx, ego_cy);
+                const bool ask = want && (near_dyn | near_sta) != 0;
+                if (__any(ask)) {   // wave-uniform; every lane runs the query code (wave-level culling inside)
+                    const Obb ego = {ego_cx, ego_cy, pose_cos, pose_sin, a.half_length, a.half_width};
+                    collide |= pose_collides<true, COLL == 2, false, true>(a.obs, ego, a.ego_radius, a.time_step0 + i * a.factor, ask, near_dyn, near_sta) && ask;
+                }
+            }
+        }
+    }
+    // ---- the candidate's verdict over its G blocks: the first block that failed / left the domain, any pose that collides.  Blocks are
+    //      in step order, so the smallest step is the first block's: minima of (step, reason) keys, through LDS; the workgroup's first
+    //      wavefront does the bookkeeping of the 64 candidates.
+    keys[(0 * NB + q) * RP_CHUNK_BLOCK + lane] = fail_step >= 0 ? (fail_step << 3) | (int)fail_reason : 0x7fffffff;
+    keys[(1 * NB + q) * RP_CHUNK_BLOCK + lane] = ood_step >= 0 ? ood_step : 0x7fffffff;
+    keys[(2 * NB + q) * RP_CHUNK_BLOCK + lane] = collide ? 1 : 0;
+    __syncthreads();
+    if (q != 0) return;   // (wave-uniform)
+    {
+        int fkey = 0x7fffffff, okey = 0x7fffffff, ckey = 0;
+        for (int b = 0; b < NB; ++b) {
+            const int f2 = keys[(0 * NB + b) * RP_CHUNK_BLOCK + lane], o2 = keys[(1 * NB + b) * RP_CHUNK_BLOCK + lane];
+            fkey = f2 < fkey ? f2 : fkey;
+            okey = o2 < okey ? o2 : okey;
+            ckey |= keys[(2 * NB + b) * RP_CHUNK_BLOCK + lane];
+        }
+        fail_step = fkey == 0x7fffffff ? -1 : fkey >> 3;
+        fail_reason = fkey == 0x7fffffff ? RP_REASON_NONE : (uint32_t)(fkey & 7);
+        ood_step = okey == 0x7fffffff ? -1 : okey;
+        collide = ckey != 0;
+    }
+    // ---- label, reason, cost
+    uint32_t status;
+    const bool decided_bad = pre_reason != RP_REASON_NONE || fail_step >= 0 || ood_step >= 0;
+    if (pre_reason != RP_REASON_NONE) status = RP_LABEL_NONE | (pre_reason << 4);
+    else if (fail_step >= 0) status = RP_LABEL_INFEASIBLE_KINEMATIC | (fail_reason << 4) | ((uint32_t)fail_step << 8);
+    else if (ood_step >= 0) status = RP_LABEL_NONE | (RP_REASON_OUT_OF_DOMAIN << 4) | ((uint32_t)ood_step << 8);
+    else status = collide ? RP_LABEL_INFEASIBLE_COLLISION : RP_LABEL_FEASIBLE;
+    // sixteen partial sums by step mod 16, each over the step blocks (= the workgroup's wavefronts) in ascending order, then the tree of
+    // group_sum_last<16> (lane 15's: ror 8, 4, 2, 1) -- rp_eval_kernel's order of additions
+    double cost;
+    {
+        const lds_double gsum = (lds_double)(lds_chunk + lane);
+        const int nblocks = NB;
+        double pj[RP_CHUNK_STEPS];
+#pragma unroll
+        for (int k = 0; k < RP_CHUNK_STEPS; ++k) pj[k] = gsum[k * RP_CHUNK_BLOCK];   // (0.0 + the first block's term: the term itself)
+        for (int b = 1; b < nblocks; ++b) {
+#pragma unroll
+            for (int k = 0; k < RP_CHUNK_STEPS; ++k) pj[k] += gsum[(b * RP_CHUNK_STEPS + k) * RP_CHUNK_BLOCK];
+        }
+        double s8[8], s4[4], s2[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s8[k] = pj[8 + k] + pj[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] = s8[4 + k] + s8[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) s2[k] = s4[2 + k] + s4[k];
+        cost = s2[1] + s2[0];
+    }
+    if (decided_bad) cost = __builtin_nan("");
+    const bool mine = valid;   // (the workgroup's first wavefront: one lane per candidate)
+    if (mine) {
+        a.status[slot] = status;
+        a.cost[slot] = cost;
+    }
+    // ---- block partial: lexicographic (cost, index) min + counters of this wavefront
+    if (a.partials) {
+        const uint32_t lab = RP_STATUS_LABEL(status), rs = RP_STATUS_REASON(status);
+        double bc = (mine && lab == RP_LABEL_FEASIBLE && cost == cost) ? cost : 0.0;
+        long long bi = (mine && lab == RP_LABEL_FEASIBLE && cost == cost) ? (long long)gidx : -1;
+        wave_min_pair(bc, bi);
+        const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+        const unsigned int n_feas = (unsigned int)__popcll(__ballot(mine && (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION)));
+        unsigned int cnt_mine = 0;
+#pragma unroll
+        for (uint32_t r = 1; r < 8; ++r) {
+            const unsigned int cnt = (unsigned int)__popcll(__ballot(mine && rs == r));
+            cnt_mine = lane == (int)(2 + r) ? cnt : cnt_mine;
+        }
+        cnt_mine = lane == 0 ? n_feas : cnt_mine;   // [0] n_feasible, [1] n_collision, [2 + r] reasons
+        const unsigned int n_coll = (unsigned int)__popcll(__ballot(mine && lab == RP_LABEL_INFEASIBLE_COLLISION));
+        cnt_mine = lane == 1 ? n_coll : cnt_mine;
+        if (lane < RP_PARTIAL_CNT) bp.cnt[lane] = cnt_mine;
         if (lane == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
     }
 }

@@ -168,6 +168,38 @@ const char *rp_last_error(const rp_ctx *ctx);
 /* enable = k > 0: record HIP events around the evaluation kernel of every k-th rp_plan on this ctx
  * (rp_result.kernel_ms; 0 for the calls in between); 0 = off */
 int rp_set_profiling(rp_ctx *ctx, int enable);
+/* How the host thread waits for a plan's result (the kernels write it, and a completion ticket behind it, into pinned host memory):
+ *   RP_WAIT_SPIN   (default) poll the ticket with `pause` in between: the result is seen ~1 us after it lands, one host core is busy
+ *                  for the length of the plan;
+ *   RP_WAIT_YIELD  poll, but give the core away between polls (sched_yield): for more ranks than cores -- eight ranks under a
+ *                  16-CPU quota leave the binding's own work little else (commonroad_rp_amd.distributed picks it when
+ *                  cpu quota < 2 x local world size);
+ *   RP_WAIT_EVENT  no ticket: an event behind the plan's last launch, the thread sleeps in hipEventSynchronize (the driver's
+ *                  interrupt path: some 10 us later than the ticket, no core burnt).
+ * Every mode falls back to a stream synchronisation after 200 ms without a ticket.  Results are the same in every mode. */
+#define RP_WAIT_SPIN 0
+#define RP_WAIT_YIELD 1
+#define RP_WAIT_EVENT 2
+int rp_set_wait_mode(rp_ctx *ctx, int mode);
+int rp_get_wait_mode(const rp_ctx *ctx);
+/* Launch-policy switches of a context, by name (tests, A/B measurements; a planner has no need for them).  The environment variable
+ * named with each key is read ONCE, by rp_create, as the context's default; no call that plans reads the environment.
+ *   "lanes"             RP_AMD_G                    0 by batch | 16 | 32 | 64 lanes per candidate of rp_eval_kernel
+ *   "eval_block"        RP_AMD_EVAL_BLOCK           0 by batch | 64 | 256 threads per workgroup of the batch's rp_eval_kernel launch
+ *   "cost_kernel"       RP_AMD_COST_KERNEL          -1 by batch | 0 never | 1 whenever rp_cost_kernel applies
+ *   "chunk_kernel"      RP_AMD_CHUNK_KERNEL         -1 by batch | 0 never | 1 whenever rp_chunk_kernel applies
+ *   "lazy"              RP_AMD_LAZY                 -1 by rp_set_collision_path | 0 never | 1 cost-ordered stage whenever the launch path allows
+ *   "fused_lon"         RP_AMD_NO_FUSED_LON         1 | 0: single-launch variant of small batches
+ *   "fused_lon_blocks"  RP_AMD_FUSED_LON_BLOCKS     -1 (4 workgroups per CU) | largest grid that takes it
+ *   "auto_materialize"  RP_AMD_NO_AUTO_MATERIALIZE  1 | 0: small batches whose winner rows are wanted write every candidate's rows
+ *   "stage_out", "row_padding", "row_align" (0 | 8 | 16), "tail_split"   RP_AMD_NO_STAGE_OUT, _NO_ROW_PADDING, _ROW_ALIGN, _NO_TAIL_SPLIT
+ *   "table_window", "lon_publish", "inline_grids", "zero_copy", "coeff_groups"   RP_AMD_NO_<NAME>: 1 | 0
+ *   "fold_threshold"    RP_AMD_FOLD_THRESHOLD       block partials beyond which they are folded before the epilogue
+ *   "event_bracket", "winner_lanes_as_batch", "lazy_trace", "print_stamps", "timing"   RP_AMD_<NAME>: 0 | 1 (measurement variants, diagnostics on stderr)
+ *   "wait_mode"         RP_AMD_WAIT_MODE            RP_WAIT_* (as rp_set_wait_mode)
+ * RP_EINVAL: unknown key or value out of range; RP_ESTATE: a plan is in flight. */
+int rp_set_option(rp_ctx *ctx, const char *key, int64_t value);
+int rp_get_option(const rp_ctx *ctx, const char *key, int64_t *value);
 
 /* ---- tables (once per reset / reference path) -------------------------------------------------- */
 /* CoordinateSystem tables (utils_coordinate_system.py:114-118) + polyline vertices (.reference). */
@@ -266,7 +298,7 @@ int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *
  *                              rp_plan_coeffs) per path, takes the faster one and measures the other again every 64th plan.
  *                              Fastest on average; which candidates behind the winner carry a collision label then depends on
  *                              earlier timings -- read rp_last_path() before interpreting them.
- * RP_AMD_LAZY=0 / 1 in the environment pins the choice for every context (tests, measurements). */
+ * The option "lazy" = 0 / 1 (rp_set_option; RP_AMD_LAZY as a context's default) pins the choice (tests, measurements). */
 #define RP_PATH_EAGER 0
 #define RP_PATH_LAZY 1
 #define RP_PATH_LAZY_FALLBACK 2
@@ -277,6 +309,7 @@ int rp_last_path(const rp_ctx *ctx);
  * Results are the same bits either way. */
 #define RP_KERNEL_EVAL 0
 #define RP_KERNEL_COST 1
+#define RP_KERNEL_CHUNK 2   /* rp_chunk_kernel: one lane per candidate and step block of 16 steps (mid-sized batches that keep costs and labels only) */
 int rp_last_kernel(const rp_ctx *ctx);
 #define RP_COLLISION_AUTO 0
 #define RP_COLLISION_EAGER 1

@@ -1,4 +1,4 @@
-"""The launch paths of the library that the GPU tests run on (the environment switches are read per plan call):
+"""The launch paths of the library that the GPU tests run on (options of the contexts: rp_set_option):
   single_launch  small batches: one kernel computes the longitudinal profiles in LDS and evaluates (default)
   two_kernel     rp_lon_kernel + rp_eval_kernel (what large batches take), 16 lanes per candidate
   g32 / g64      two-kernel path with 32 / 64 lanes per candidate (g64: LDS-staged linear copy-out of state rows)
@@ -8,31 +8,40 @@
                  cost-ordered stage) through rp_cost_kernel: one lane per candidate, the lane walks the time steps (what such plans
                  take from 131 072 candidates on)
   wave_wg        two-kernel path, 16 lanes per candidate, ONE wavefront per workgroup of the evaluation kernel (what costs-only plans
-                 of batches beyond 131 072 candidates take: rp_host.hip eval_block)"""
+                 of batches beyond 131 072 candidates take: rp_host.hip eval_block)
+  lane_chunk     two-kernel path; costs-only launches through rp_chunk_kernel: one lane per candidate and step block of 16 steps
+                 (what such plans take between 4 096 and 262 144 candidates at horizons of 17 .. 128 steps)"""
 import contextlib
-import os
 
+from commonroad_rp_amd import _capi
+
+# option sets of rp_set_option (include/rp_amd.h), applied to every context of the process for the duration of a test
 LAUNCH_PATHS = {
     "single_launch": {},
-    "two_kernel": {"RP_AMD_NO_FUSED_LON": "1"},
-    "g32": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "32"},
-    "g64": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "64"},
-    "lazy": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_LAZY": "1", "RP_AMD_NO_AUTO_MATERIALIZE": "1"},
-    "wave_wg": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_G": "16", "RP_AMD_EVAL_BLOCK": "64"},
-    "lane_cand": {"RP_AMD_NO_FUSED_LON": "1", "RP_AMD_COST_KERNEL": "1", "RP_AMD_NO_AUTO_MATERIALIZE": "1"},
+    "two_kernel": {"fused_lon": 0},
+    "g32": {"fused_lon": 0, "lanes": 32},
+    "g64": {"fused_lon": 0, "lanes": 64},
+    "lazy": {"fused_lon": 0, "lazy": 1, "auto_materialize": 0},
+    "wave_wg": {"fused_lon": 0, "lanes": 16, "eval_block": 64, "chunk_kernel": 0},
+    "lane_cand": {"fused_lon": 0, "cost_kernel": 1, "chunk_kernel": 0, "auto_materialize": 0},
+    "lane_chunk": {"fused_lon": 0, "chunk_kernel": 1, "auto_materialize": 0},
 }
 
 
 @contextlib.contextmanager
 def launch_path_env(name):
-    saved = {k: os.environ.get(k) for k in ("RP_AMD_NO_FUSED_LON", "RP_AMD_G", "RP_AMD_LAZY", "RP_AMD_NO_AUTO_MATERIALIZE", "RP_AMD_EVAL_BLOCK", "RP_AMD_COST_KERNEL")}
-    for k in saved:
-        os.environ.pop(k, None)
-    os.environ.update(LAUNCH_PATHS[name])
+    """(the name is from the rounds when these were environment variables read per plan: they are options of the contexts now)"""
+    _capi.set_default_options(LAUNCH_PATHS[name])
     try:
         yield
     finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+        _capi.set_default_options(None)
+
+
+@contextlib.contextmanager
+def options(**opts):
+    _capi.set_default_options(opts)
+    try:
+        yield
+    finally:
+        _capi.set_default_options(None)

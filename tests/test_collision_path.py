@@ -16,9 +16,8 @@ def _draw(inp: PlanInputs) -> PlanInputs:
 
 
 @pytest.fixture(autouse=True)
-def _no_path_switches(monkeypatch):
-    for k in ("RP_AMD_LAZY", "RP_AMD_COST_KERNEL", "RP_AMD_NO_FUSED_LON", "RP_AMD_G", "RP_AMD_EVAL_BLOCK", "RP_AMD_NO_AUTO_MATERIALIZE"):
-        monkeypatch.delenv(k, raising=False)
+def _no_path_switches():
+    _capi.set_default_options(None)   # (the library's own launch policy: no option pinned by an earlier test)
 
 
 def test_collision_path_is_a_setting_of_the_context():

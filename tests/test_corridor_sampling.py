@@ -357,11 +357,11 @@ def test_grouped_plan_equals_ungrouped_on_a_large_corridor():
         prm = copy_params(rp._gpu_params(x0_lon, x0_lat, flags))
         res = {}
         for key, g in (("plain", None), ("grouped", groups)):
-            os.environ["RP_AMD_LAZY"] = "0"      # (labels of both runs from the eager query: comparable one by one)
+            ctx.set_option("lazy", 0)      # (labels of both runs from the eager query: comparable one by one)
             try:
                 out = ctx.plan_coeffs(prm, cost, lon, lat, T, tl, groups=g)
             finally:
-                os.environ.pop("RP_AMD_LAZY", None)
+                ctx.set_option("lazy", -1)
             status, c = ctx.fetch_status()
             res[key] = (out, status.copy(), c.copy(), ctx.fetch_states().copy() if flags else None)
         a, b = res["plain"], res["grouped"]
