@@ -241,7 +241,7 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
     "c": a compiled host loop over the C ABI (csrc/rp_hostloop.c), "python": the ctypes binding, one ``ctx.plan`` per step."""
     from commonroad_rp_amd._capi import HostLoop
     inputs = with_mode(seq, mode)
-    kms, feas, paths = [], [], [0, 0, 0]
+    kms, feas, paths = [], [], [0, 0, 0, 0]
     ctx.set_profiling(profile_every)   # HIP events around the evaluation kernel of every 8th step (a bracket costs ~8 us of stream time)
 
     def step(k):
@@ -258,7 +258,7 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
         def region(k0, n):
             st = loop.run(k0, n)
             tot["kms"] += st.kernel_ms_sum; tot["kn"] += st.kernel_ms_n; tot["feas"] += st.feasible_sum; tot["n"] += n
-            for i in range(3):
+            for i in range(4):
                 paths[i] += st.paths[i]
     regions = measure(step, len(inputs), steps, warmup, min_seconds, sync, region=region)
     ctx.set_profiling(0)
@@ -273,7 +273,7 @@ def run_record(ctx, w, seq, mode, steps, warmup, min_seconds, sync, name=None, p
            "unit": "candidates/s", "steps": steps, "spread_ms": sp, "kernel_ms": kernel_ms, "sequence": len(inputs),
            "caller": "compiled host loop over the C ABI (rp_hostloop.c)" if region is not None else "Python binding (ctypes), one call per step",
            # how the steps answered the collision query: eager (every pose of every candidate), cost-ordered stage, stage + eager fallback
-           "collision_path_steps": {"eager": paths[0], "cost_ordered": paths[1], "cost_ordered_then_eager": paths[2]},
+           "collision_path_steps": {"eager": paths[0], "cost_ordered": paths[1], "cost_ordered_then_eager": paths[2], "cost_ordered_sweep": paths[3]},
            "roofline": roofline_record(name or w.name, mode, n1, cand, float(np.mean(feas)) if feas else 0.0, kernel_ms,
                                        kernel=ctx.last_kernel())}
     return rec

@@ -41,36 +41,49 @@ class RpError(RuntimeError):
     pass
 
 
-class RpParams(C.Structure):
+ABI_VERSION = 2
+E_ABI = -7
+PLAN_BEGIN, PLAN_ROWS, PLAN_PACKED = 1, 2, 4
+
+
+class _Sized(C.Structure):
+    """the structs of include/rp_amd.h start with their own size (checked by every entry: RP_EABI)"""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(type(self))
+
+
+class RpParams(_Sized):
     _fields_ = [
-        ("dt", C.c_double), ("N", C.c_int32), ("factor", C.c_int32), ("time_step0", C.c_int32),
+        ("struct_size", C.c_uint32), ("N", C.c_int32), ("factor", C.c_int32), ("time_step0", C.c_int32),
         ("low_vel_mode", C.c_int32), ("lon_mode", C.c_int32), ("constraint_mask", C.c_uint32),
-        ("flags", C.c_uint32), ("reserved_", C.c_int32),
+        ("flags", C.c_uint32), ("dt", C.c_double),
         ("x0_lon", C.c_double * 3), ("x0_lat", C.c_double * 3), ("x0_orientation", C.c_double),
         ("wheelbase", C.c_double), ("wb_rear_axle", C.c_double), ("length", C.c_double), ("width", C.c_double),
         ("a_max", C.c_double), ("v_switch", C.c_double), ("delta_max", C.c_double), ("v_delta_max", C.c_double),
     ]
 
 
-class RpCost(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved_", C.c_int32), ("w_a", C.c_double), ("desired_speed", C.c_double),
+class RpCost(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_int32), ("w_a", C.c_double), ("desired_speed", C.c_double),
                 ("desired_d", C.c_double), ("desired_s", C.c_double)]
 
 
-class RpGrids(C.Structure):
-    _fields_ = [("nT", C.c_int32), ("nL", C.c_int32), ("nD", C.c_int32), ("reserved_", C.c_int32),
+class RpGrids(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("nT", C.c_int32), ("nL", C.c_int32), ("nD", C.c_int32),
                 ("T", C.POINTER(C.c_double)), ("traj_len", C.POINTER(C.c_int32)),
                 ("L", C.POINTER(C.c_double)), ("D", C.POINTER(C.c_double))]
 
 
-class RpResult(C.Structure):
-    _fields_ = [("best_index", C.c_int64), ("best_cost", C.c_double), ("n_candidates", C.c_int64),
+class RpResult(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved_", C.c_uint32), ("best_index", C.c_int64), ("best_cost", C.c_double), ("n_candidates", C.c_int64),
                 ("n_feasible", C.c_int64), ("n_collision_before_best", C.c_int64), ("n_collision", C.c_int64),
                 ("reason_counts", C.c_int64 * 8), ("best_lon_coeffs", C.c_double * 6),
                 ("best_lat_coeffs", C.c_double * 6), ("best_lat_T", C.c_double), ("kernel_ms", C.c_double)]
 
 
-assert C.sizeof(RpResult) == 28 * 8
+assert C.sizeof(RpResult) == 29 * 8 and RpResult.best_index.offset == 8
 _DP = C.POINTER(C.c_double)
 
 
@@ -114,7 +127,7 @@ class PlanInputs:
     def grids(self) -> RpGrids:
         g = getattr(self, "_grids", None)
         if g is None:
-            g = self._grids = RpGrids(len(self.T), len(self.L), len(self.D), 0, dptr(self.T),
+            g = self._grids = RpGrids(0, len(self.T), len(self.L), len(self.D), dptr(self.T),
                                       self.traj_len.ctypes.data_as(C.POINTER(C.c_int32)), dptr(self.L), dptr(self.D))
         return g
 
@@ -138,7 +151,7 @@ class PlanOutput:
     @classmethod
     def from_c(cls, r: RpResult, best_states):
         # one copy of the 28 eight-byte words of rp_result, read as doubles and as integers
-        f = np.frombuffer(r, dtype=np.float64, count=28).copy()
+        f = np.frombuffer(r, dtype=np.float64, count=28, offset=8).copy()   # (behind the struct_size header)
         i = f.view(np.int64)
         bi = int(i[0])
         return cls(bi, float(f[1]), int(i[2]), int(i[3]), int(i[4]), int(i[5]), i[6:14], f[14:20], f[20:26], float(f[26]),
@@ -169,7 +182,7 @@ def make_params(*, dt: float, N: int, x0_lon: Sequence[float], x0_lat: Sequence[
 def make_cost(kind: int = COST_DEFAULT, w_a: float = 5.0, desired_speed: Optional[float] = None,
               desired_d: float = 0.0, desired_s: Optional[float] = None) -> RpCost:
     nan = float("nan")
-    return RpCost(int(kind), 0, float(w_a), nan if desired_speed is None else float(desired_speed), float(desired_d),
+    return RpCost(0, int(kind), float(w_a), nan if desired_speed is None else float(desired_speed), float(desired_d),
                   nan if desired_s is None else float(desired_s))
 
 
@@ -224,23 +237,19 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_set_reference": (C.c_int, [ctx, C.c_int32, dp, dp, dp, dp, dp, dp, C.c_double]),
         "rp_set_obstacles": (C.c_int, [ctx, C.c_int32, dp, C.c_int32, dp, C.c_int32, dp, C.c_int32, C.c_int32,
                                        C.c_int32, dp]),
-        "rp_plan": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64,
-                              C.POINTER(RpResult), dp]),
-        "rp_plan_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64, C.c_int32]),
+        # (out: void pointer -- a NumPy buffer or a ctypes array of the packed calls)
+        "rp_plan": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.POINTER(RpGrids), C.c_int64, C.c_int64, C.c_uint32,
+                              C.POINTER(RpResult), C.c_void_p]),
         "rp_plan_wait": (C.c_int, [ctx, C.POINTER(RpResult), dp]),
-        "rp_plan_levels": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.POINTER(RpResult), dp, ip]),
-        "rp_plan_levels_begin": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.c_int32]),
-        "rp_plan_levels_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, ip, C.POINTER(RpResult), C.c_void_p, ip]),
+        "rp_plan_levels": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.c_uint32, C.POINTER(RpResult),
+                                     C.c_void_p, ip]),
         "rp_last_level": (C.c_int, [ctx]),
         "rp_pack_trajectory": (C.c_int, [C.c_int32, dp, C.c_double, C.c_double, C.c_double, dp]),
         "rp_fast_buffer": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
-        "rp_plan_packed": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.c_int32, C.c_int32, C.POINTER(RpResult), C.c_void_p]),
-        "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip,
+        "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip, C.c_int64, ip, ip,
                                      C.POINTER(RpResult), dp]),
         "rp_coeffs_arena": (C.c_int, [ctx, C.c_int64, C.POINTER(dp), C.POINTER(dp), C.POINTER(ip)]),
         "rp_coeffs_arena_groups": (C.c_int, [ctx, C.POINTER(ip), C.POINTER(ip)]),
-        "rp_plan_coeffs_grouped": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip, C.c_int64, ip, ip,
-                                             C.POINTER(RpResult), dp]),
         "rp_fetch_status": (C.c_int, [ctx, C.c_int64, C.c_int64, up, dp]),
         "rp_fetch_states": (C.c_int, [ctx, C.c_int64, C.c_int64, dp]),
         "rp_eval_one": (C.c_int, [ctx, C.c_int64, dp, up, dp]),
@@ -274,18 +283,18 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                 raise
             continue                  # (an older build named by RP_AMD_LIBRARY for an A/B run: entries added since are absent)
         fn.restype, fn.argtypes = res, args
-    if lib.rp_abi_version() != 1:
-        raise RpError(f"librp_amd.so ABI version {lib.rp_abi_version()} != 1")
+    if lib.rp_abi_version() != ABI_VERSION:
+        raise RpError(f"librp_amd.so ABI version {lib.rp_abi_version()} != {ABI_VERSION}")
     if path == LIB_PATH or _lib is None:
         _lib = lib
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_kernel", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_begin", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
-                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_plan_packed", "rp_coeffs_arena", "rp_coeffs_arena_groups",
-                          "rp_plan_coeffs_grouped", "rp_corridor_coeffs_grouped")
+_OPTIONAL_IN_AB_BUILDS = ("rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_kernel", "rp_plan_levels", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+                          "rp_corridor_coeffs", "rp_fast_buffer", "rp_coeffs_arena", "rp_coeffs_arena_groups",
+                          "rp_corridor_coeffs_grouped")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_path", "rp_last_kernel", "rp_set_collision_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_begin", "rp_plan_wait", "rp_plan_levels", "rp_plan_levels_begin", "rp_plan_levels_packed", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_packed", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_plan_coeffs_grouped", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_wait", "rp_plan_levels", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -565,8 +574,8 @@ class RpContext:
         n = inp.params.N + 1
         best = np.empty((N_ARRAYS, n)) if want_best_states else None
         g = inp.grids()
-        rc = self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end,
-                               C.byref(res), best.ctypes.data_as(_DP) if best is not None else None)
+        rc = self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end, 0,
+                               C.byref(res), best.ctypes.data if best is not None else None)
         if rc != 0:
             self._check(rc, "rp_plan")
         self._N = inp.params.N
@@ -587,7 +596,7 @@ class RpContext:
         return raw, np.ndarray((N_ARRAYS + 13, n), np.float64, raw)
 
     def plan_packed(self, params: RpParams, cost: RpCost, T, traj_len, L, D):
-        """``rp_plan_packed``: one sampling level -> (the context's ``RpResult`` struct, state block [14, N + 1], packed output
+        """``rp_plan`` with ``RP_PLAN_PACKED``: one sampling level -> (the context's ``RpResult`` struct, state block [14, N + 1], packed output
         [N + 1, 13]) -- the last two ``None`` without a winner.  The grids go through the context's own buffer (four slice
         assignments instead of a struct of four array pointers built per call) and the result comes back as the C struct."""
         fb = getattr(self, "_fast", None)
@@ -595,7 +604,8 @@ class RpContext:
             ptr, nbytes = C.c_void_p(), C.c_size_t()
             self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
             raw = (C.c_char * nbytes.value).from_address(ptr.value)
-            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan_packed)
+            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan)
+            self._fast_dims = RpGrids()   # (sizes only: the arrays are in the buffer)
         f64v, i32v, call = fb
         nT, nL, nD = len(T), len(L), len(D)
         nd = nT + nL + nD
@@ -617,9 +627,12 @@ class RpContext:
         n = params.N + 1
         raw, out = self._packed_out(n)
         res = self._res
-        rc = call(self._h, params, cost, nT, nL, nD, res, raw)
+        gd = self._fast_dims
+        if not same:
+            gd.nT, gd.nL, gd.nD = nT, nL, nD
+        rc = call(self._h, params, cost, gd, 0, -1, PLAN_PACKED, res, raw)
         if rc != 0:
-            self._check(rc, "rp_plan_packed")
+            self._check(rc, "rp_plan (packed)")
         self._N = n - 1
         self._last_count = res.n_candidates
         self._serial += 1
@@ -629,7 +642,7 @@ class RpContext:
         return res, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
 
     def plan_levels_packed(self, params: RpParams, cost: RpCost, levels):
-        """``rp_plan_levels_packed``: the level loop of ``plan()`` (reactive_planner.py:616-636) in one call and one device round
+        """``rp_plan_levels`` with ``RP_PLAN_PACKED``: the level loop of ``plan()`` (reactive_planner.py:616-636) in one call and one device round
         trip.  ``levels``: [(T, traj_len, L, D), ...] in the order the loop would visit them -> (result struct, index of the level
         the result belongs to, state block [14, N + 1], packed output [N + 1, 13]); the last two ``None`` without a winner."""
         fb = getattr(self, "_fast", None)
@@ -637,12 +650,15 @@ class RpContext:
             ptr, nbytes = C.c_void_p(), C.c_size_t()
             self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
             raw = (C.c_char * nbytes.value).from_address(ptr.value)
-            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan_packed)
+            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan)
+            self._fast_dims = RpGrids()
         f64v, i32v = fb[0], fb[1]
         nlev = len(levels)
         dims = getattr(self, "_lvl_dims", None)
-        if dims is None or len(dims) < 3 * nlev:
-            dims = self._lvl_dims = (C.c_int32 * (3 * max(nlev, 8)))()
+        if dims is None or len(dims) < nlev:
+            dims = self._lvl_dims = (RpGrids * max(nlev, 8))()
+            for g_ in dims:
+                g_.struct_size = C.sizeof(RpGrids)
             self._lvl_out = C.c_int32(0)
         at = 0
         for k, (T, traj_len, L, D) in enumerate(levels):
@@ -655,15 +671,16 @@ class RpContext:
             f64v[at + nT:at + nT + nL] = L
             f64v[at + nT + nL:at + nd] = D
             i32v[2 * (at + nd):2 * (at + nd) + nT] = traj_len
-            dims[3 * k], dims[3 * k + 1], dims[3 * k + 2] = nT, nL, nD
+            gk = dims[k]
+            gk.nT, gk.nL, gk.nD = nT, nL, nD
             at += words
         self._fast_last = None   # (the buffer no longer holds what plan_packed left there)
         n = params.N + 1
         raw, out = self._packed_out(n)
         res, lvl = self._res, self._lvl_out
-        rc = self._lib.rp_plan_levels_packed(self._h, params, cost, nlev, dims, res, raw, lvl)
+        rc = self._lib.rp_plan_levels(self._h, params, cost, nlev, dims, PLAN_PACKED, res, raw, lvl)
         if rc != 0:
-            self._check(rc, "rp_plan_levels_packed")
+            self._check(rc, "rp_plan_levels (packed)")
         self._N = n - 1
         self._last_count = res.n_candidates
         self._serial += 1
@@ -677,9 +694,10 @@ class RpContext:
         nlev = len(levels)
         inputs = [PlanInputs.trusted(params, cost, T, tl, L, D) for (T, tl, L, D) in levels]
         arr = (RpGrids * nlev)(*[q.grids() for q in inputs])
-        rc = self._lib.rp_plan_levels_begin(self._h, C.byref(params), C.byref(cost), nlev, arr, 1 if want_best_states else 0)
+        rc = self._lib.rp_plan_levels(self._h, C.byref(params), C.byref(cost), nlev, arr, PLAN_BEGIN | (PLAN_ROWS if want_best_states else 0),
+                                      None, None, None)
         if rc != 0:
-            self._check(rc, "rp_plan_levels_begin")
+            self._check(rc, "rp_plan_levels (begin)")
         self._inflight = (inputs[0], want_best_states)
 
     def last_level(self) -> int:
@@ -689,10 +707,10 @@ class RpContext:
         """First half of ``plan``: the kernels of the plan go onto the context's stream and the call returns; ``plan_wait``
         collects the result.  One plan in flight per context; ``inp`` must stay as it is until then."""
         g = inp.grids()
-        rc = self._lib.rp_plan_begin(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end,
-                                     1 if want_best_states else 0)
+        rc = self._lib.rp_plan(self._h, C.byref(inp.params), C.byref(inp.cost), C.byref(g), cand_begin, cand_end,
+                               PLAN_BEGIN | (PLAN_ROWS if want_best_states else 0), None, None)
         if rc != 0:
-            self._check(rc, "rp_plan_begin")
+            self._check(rc, "rp_plan (begin)")
         self._inflight = (inp, want_best_states)
 
     def plan_wait(self) -> PlanOutput:
@@ -740,7 +758,7 @@ class RpContext:
     def plan_coeffs(self, params: RpParams, cost: RpCost, lon_coeffs, lat_coeffs, lon_T, traj_len,
                     want_best_states: bool = True, groups=None) -> PlanOutput:
         """``groups``: (n_groups, group [C], group_first [n_groups]) -- candidates that share their longitudinal polynomial, as
-        ``rp_corridor_coeffs_grouped`` reports them; arena arrays only (``rp_plan_coeffs_grouped``)."""
+        ``rp_corridor_coeffs_grouped`` reports them; arena arrays only (``rp_plan_coeffs`` with ``n_groups`` > 0)."""
         lon_coeffs, lat_coeffs, lon_T = f64(lon_coeffs), f64(lat_coeffs), f64(lon_T)
         traj_len = np.ascontiguousarray(traj_len, dtype=np.int32)
         cnt = len(traj_len)
@@ -748,16 +766,11 @@ class RpContext:
         res = self._res
         best = np.empty((N_ARRAYS, params.N + 1)) if want_best_states else None
         ipt = C.POINTER(C.c_int32)
-        if groups is not None and groups[0] > 0 and getattr(self._lib, "rp_plan_coeffs_grouped", None) is not None:
-            self._check(self._lib.rp_plan_coeffs_grouped(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs), dptr(lat_coeffs),
-                                                         dptr(lon_T), traj_len.ctypes.data_as(ipt), int(groups[0]),
-                                                         groups[1].ctypes.data_as(ipt), groups[2].ctypes.data_as(ipt), C.byref(res), dptr(best)),
-                        "rp_plan_coeffs_grouped")
-        else:
-            self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs),
-                                                 dptr(lat_coeffs), dptr(lon_T),
-                                                 traj_len.ctypes.data_as(ipt), C.byref(res), dptr(best)),
-                        "rp_plan_coeffs")
+        grouped = groups is not None and groups[0] > 0
+        self._check(self._lib.rp_plan_coeffs(self._h, C.byref(params), C.byref(cost), cnt, dptr(lon_coeffs), dptr(lat_coeffs), dptr(lon_T),
+                                             traj_len.ctypes.data_as(ipt), int(groups[0]) if grouped else 0,
+                                             groups[1].ctypes.data_as(ipt) if grouped else None, groups[2].ctypes.data_as(ipt) if grouped else None,
+                                             C.byref(res), dptr(best)), "rp_plan_coeffs")
         self._N = params.N
         self._last_count = cnt
         return self._output(res, best)

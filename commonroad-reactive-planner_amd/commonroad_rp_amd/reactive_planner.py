@@ -857,7 +857,12 @@ class ReactivePlanner(GpuBackendMixin):
                 T, traj_len, L, D = levels[0]
                 if len(T) * len(L) * len(D):
                     res, blk, buf = packed(params, cost, T, traj_len, L, D)
+                else:
+                    res = None   # (an empty bundle: the reference's loop visits it and leaves the counters at zero)
                 decided = level
+            elif begin is not None and not any(len(T) * len(L) * len(D) for (T, _tl, L, D) in levels):
+                res = None       # (nothing to launch at these levels)
+                decided = upto - 1
             elif begin is not None:
                 # the same in two halves: the caller's own work (harness: the last cycle's bookkeeping) runs while the device is busy
                 begin(params, cost, levels)
@@ -872,6 +877,8 @@ class ReactivePlanner(GpuBackendMixin):
                 if len(T) * len(L) * len(D):
                     res = ctx.plan(PlanInputs.trusted(params, cost, T, traj_len, L, D))
                     blk = res.best_states if res.best_index >= 0 else None
+                else:
+                    res = None
                 decided = level
             level = upto
         if not single_level and policy == "adaptive":

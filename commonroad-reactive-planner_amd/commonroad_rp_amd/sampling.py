@@ -127,6 +127,11 @@ class FixedIntervalSampling(SamplingSpace):
         (trajectories.py:545-550, reactive_planner.py:1076-1077)."""
         # (the level's sets straight from the per-level dictionaries -- what samples_at_level returns; an unknown level raises KeyError
         #  here instead of its AssertionError -- and the array forms from one cache per kind, looked up by the set's identity)
+        st, sv, sd = self.samples_t, self.samples_v, self.samples_d
+        if not (type(st) is TimeSampling and type(sv) is VelocitySampling and type(sd) is PositionSampling):
+            # a replacement of one of the 1-D sample sets (a subclass that overrides samples_at_level, an object without the private
+            # dictionary): through the plug-in interface, as generate_trajectories_at_level does
+            return self._grids_via_interface(level_sampling, x_0_lon, x_0_lat, longitudinal_mode)
         t_set = self.samples_t._dict_level_to_sample_set[level_sampling]
         hit = self.__dict__.get("_t_cache", _EMPTY).get(id(t_set))
         if hit is not None and hit[0] is t_set and len(hit[1]) == len(t_set):
@@ -146,6 +151,18 @@ class FixedIntervalSampling(SamplingSpace):
             u = d_set.union((d0,))
             D = np.fromiter(u, np.float64, len(u))
         return T, traj_len, L, D
+
+    def _grids_via_interface(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str):
+        """``grids_at_level`` through ``samples_at_level()`` of whatever objects hold the 1-D sample sets (no caches, no private fields)."""
+        t_set = self.samples_t.samples_at_level(level_sampling)
+        T = np.array([float(t) for t in t_set], dtype=np.float64)
+        traj_len = np.array([len(np.arange(0, np.round(t + self.dt, 5), self.dt)) for t in T], dtype=np.int32)
+        lon = self._get_lon_samples(level_sampling, longitudinal_mode)
+        L = np.fromiter(lon, np.float64, len(lon))
+        if longitudinal_mode != "velocity_keeping":
+            L = L[L > x_0_lon[0]]
+        u = self.samples_d.samples_at_level(level_sampling).union({x_0_lat[0]})
+        return T, traj_len, L, np.fromiter(u, np.float64, len(u))
 
     # The sample sets only change when a set_*_sampling_parameters call replaces them, so their array form
     # (in set-iteration order) is cached per set object; the set is kept alive next to it, hence ids are unique.

@@ -42,6 +42,7 @@ constexpr size_t kLdsTableLimit = 65536;  // stage the reference tables in LDS u
 // on, rp_cost_kernel from this many candidates per CU on
 constexpr int kChunkMinWavesPerCU = 7;
 constexpr int kCostMinPerCU = 832;
+constexpr int kSweepMinPerCU = 512;   // candidates per CU from which a bounded sweep, not the eager kernel, takes over from exhausted list rounds
 // cost-ordered collision stage: capacity of the candidate lists of the three rounds and their places in d_lazy_lists
 constexpr int kLazyCap[RP_LAZY_LEVELS] = {1024, 4096, 16384};
 constexpr int kLazyOff[RP_LAZY_LEVELS] = {0, 1024, 5120};
@@ -58,6 +59,7 @@ struct Options {
     int cost_kernel = -1;        // rp_cost_kernel (one lane per candidate): -1 = by batch, 0 never, 1 whenever it applies
     int chunk_kernel = -1;       // rp_chunk_kernel (one lane per candidate and step block): -1 = by batch, 0 never, 1 whenever it applies
     int lazy = -1;               // cost-ordered collision stage: -1 = by the context's collision path, 0 never, 1 whenever the launch path allows it
+    int sweep = -1;              // ... as a bounded sweep over the batch instead of list rounds: -1 = by batch, 0 never, 1 whenever a cost-ordered stage runs
     int fused_lon = 1;           // single-launch variant for small batches
     int fused_lon_blocks = -1;   // ... up to this many workgroups (-1: 4 per CU)
     int auto_materialize = 1;    // small batches whose winner rows are wanted write every candidate's rows
@@ -81,6 +83,7 @@ const OptionDesc kOptionTable[] = {
     {"cost_kernel", &Options::cost_kernel, "RP_AMD_COST_KERNEL", false, -1, 1},
     {"chunk_kernel", &Options::chunk_kernel, "RP_AMD_CHUNK_KERNEL", false, -1, 1},
     {"lazy", &Options::lazy, "RP_AMD_LAZY", false, -1, 1},
+    {"sweep", &Options::sweep, "RP_AMD_SWEEP", false, -1, 1},
     {"fused_lon", &Options::fused_lon, "RP_AMD_NO_FUSED_LON", true, 0, 1},
     {"fused_lon_blocks", &Options::fused_lon_blocks, "RP_AMD_FUSED_LON_BLOCKS", false, -1, 1 << 20},
     {"auto_materialize", &Options::auto_materialize, "RP_AMD_NO_AUTO_MATERIALIZE", true, 0, 1},
@@ -181,7 +184,7 @@ struct rp_ctx {
     int64_t last_best_index = -1;
     // Which of the two ways to answer the collision query is the faster one depends on the scene (how deep into the cost order
     // the first free candidate lies) and on the batch (what a collision round costs against the eager kernel's extra work): the
-    // context times its own plans -- whole calls, rp_plan / rp_plan_packed / rp_plan_coeffs -- per path and uses the faster one,
+    // context times its own plans -- whole calls, rp_plan / rp_plan_coeffs -- per path and uses the faster one,
     // measuring the other again every 64th plan.  Results are the same either way (rp_amd.h: rp_last_path).
     double path_us[2] = {0.0, 0.0};        // running mean of the call time, [0] eager [1] cost-ordered (where the stage found the winner)
     int path_n[2] = {0, 0};
@@ -191,7 +194,7 @@ struct rp_ctx {
     std::chrono::steady_clock::time_point plan_t0;
     bool epilogue_dirty = false;           // a plan's chain was cut short (an error between its launches and its result): the scratch words
                                            // its epilogues keep at zero between launches (arrival tickets, totals, histogram) are cleared first
-    // a plan whose kernels are on the stream and whose result has not been collected (rp_plan_begin .. rp_plan_wait)
+    // a plan whose kernels are on the stream and whose result has not been collected (rp_plan with RP_PLAN_BEGIN .. rp_plan_wait)
     struct Pending {
         bool active = false, cin = false, skip_eval = false, ticket = false, done = false, time_valid = false, mat = false, coeffs = false;
         unsigned long long seq = 0;
@@ -199,7 +202,7 @@ struct rp_ctx {
         KArgs ka{};
         std::chrono::steady_clock::time_point tp0, tp1;
     } pending;
-    // a chain of sampling levels in flight (rp_plan_levels_begin .. rp_plan_wait): what every level's launch left behind -- the
+    // a chain of sampling levels in flight (rp_plan_levels with RP_PLAN_BEGIN .. rp_plan_wait): what every level's launch left behind -- the
     // result names the level it belongs to, whose state then becomes the context's "last plan"
     struct LevelState {
         Pending pending;
@@ -212,6 +215,7 @@ struct rp_ctx {
     std::vector<LevelState> chain;          // levels of the chain in flight (empty: a plan on its own)
     int chain_total = 0;                    // levels the caller handed over (levels behind the chain run one by one in rp_plan_wait)
     unsigned long long *d_gate = nullptr;   // device word of the chain (KArgs::gate)
+    unsigned long long *d_sweep = nullptr;  // bounded sweep: cost key of the cheapest free candidate found so far (KArgs::sweep_bound)
     struct ChainInputs {                    // the caller's arguments, kept for the levels behind the chain
         rp_params p; rp_cost cost; std::vector<rp_grids> grids; std::vector<std::vector<double>> T, L, D; std::vector<std::vector<int32_t>> tl;
         int want = 0;
@@ -224,11 +228,12 @@ struct rp_ctx {
     unsigned long long seq = 0;              // completion tickets handed to the kernels
     bool spin_wait = true;                   // the kernels hand a completion ticket over in the pinned result block (off: RP_WAIT_EVENT)
     hipEvent_t ev_done = nullptr;            // RP_WAIT_EVENT: recorded behind a plan's last launch; the host thread sleeps on it
+    long long wait_fallbacks = 0;            // waits for a ticket that ended in the 200-ms fall-back (a kernel chain that did not hand it over)
 
     // last plan
     bool have_last = false, last_mat = false, last_coeffs = false;
     std::unordered_map<const void *, hipFunction_t> functions;   // kernel symbol -> function handle (launch_kargs)
-    std::vector<double> fast_buf;   // rp_fast_buffer: grids of rp_plan_packed, written by the caller ([T | L | D | traj_len int32])
+    std::vector<double> fast_buf;   // rp_fast_buffer: grids of RP_PLAN_PACKED calls, written by the caller ([T | L | D | traj_len int32])
     // option "timing": host-side phase times of rp_plan (sums over calls, printed by rp_destroy)
     bool timing = false;
     double t_sum[6] = {0, 0, 0, 0, 0, 0};   // entry -> first launch | launches | wait for the ticket | unpack | evaluation launch | epilogue launch
@@ -247,7 +252,7 @@ struct rp_ctx {
     char *h_arena = nullptr, *h_arena_dev = nullptr;   // rp_coeffs_arena: pinned [lon 6 cap | lat 6 cap | traj_len cap] and its device address
     int64_t arena_cap = 0;
     const double *cin_lon = nullptr, *cin_lat = nullptr;   // host arrays the last rp_plan_coeffs read (pinned stage or arena)
-    int64_t cin_groups = 0;                 // rp_plan_coeffs_grouped: groups of the last such plan (0: one pair per candidate)
+    int64_t cin_groups = 0;                 // rp_plan_coeffs with groups: groups of the last such plan (0: one pair per candidate)
     const int32_t *cin_group_of = nullptr;  //   and the host view of its candidate -> group table (arena)
     int64_t cin_count = -1;   // rp_plan_coeffs: the explicit polynomials of the last such plan are the first 12 * cin_count doubles of h_stage (lon | lat)
 };
@@ -638,9 +643,15 @@ void table_window(const rp_ctx *c, const rp_params *p, const rp_grids *g, KArgs 
     ka.win_b0 = b0; ka.win_nb = b1 - b0 + 1;
 }
 
+// the kernels' 28 words -> the caller's rp_result (its struct_size header stays the caller's)
+inline void result_from_core(rp_result *dst, const ResultCore &src) { std::memcpy(&dst->best_index, &src, sizeof(ResultCore)); }
+
 int validate(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_result *res) {
     if (!c) return RP_EINVAL;
     if (!p || !cost || !res) return fail(c, RP_EINVAL, "null params / cost / result");
+    if (p->struct_size != sizeof(rp_params) || cost->struct_size != sizeof(rp_cost) || res->struct_size != sizeof(rp_result))
+        return fail(c, RP_EABI, "struct_size of rp_params / rp_cost / rp_result is not this library's (RP_ABI_VERSION " + std::to_string(RP_ABI_VERSION) +
+                                ": set it with RP_*_INIT; built against another rp_amd.h?)");
     if (!c->d_tables) return fail(c, RP_ESTATE, "rp_set_reference has not been called");
     if (p->N < 1 || p->N > 4094) return fail(c, RP_EINVAL, "N out of range [1, 4094]");
     if (!(p->dt > 0.0)) return fail(c, RP_EINVAL, "dt must be positive");
@@ -720,6 +731,7 @@ bool poll_ticket(const rp_ctx *c, unsigned long long seq) {
 }
 int wait_ticket(rp_ctx *c, unsigned long long seq, hipStream_t stream = nullptr) {
     if (poll_ticket(c, seq)) return RP_OK;
+    ++c->wait_fallbacks;   // (200 ms without the ticket: read-only option "wait_fallbacks")
     HIP_TRY(c, hipStreamSynchronize(stream ? stream : c->stream));
     return RP_OK;
 }
@@ -756,6 +768,7 @@ int run_lazy(rp_ctx *c, const KArgs &ka, bool cin, int G, const int &grid /* wor
     KArgs k1 = ka;
     k1.flags |= RP_FLAG_SKIP_COLLISION;
     k1.lazy_ctl = c->d_lazy_ctl;
+    k1.sweep_init = c->d_sweep;   // (should the lists run dry, a bounded sweep takes over: pipeline_begin)
     k1.states = nullptr;
     if ((rc = launch_main_eval(k1, false)) != RP_OK) return rc;
     int n_partials = grid, p_first = 0;
@@ -862,7 +875,9 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     int block = c->last_block ? c->last_block : RP_BLOCK;   // (rp_select: nothing of the batch is launched again)
     if (!skip_eval) { block = fused_lds ? RP_BLOCK : eval_block(c, ka, count, G, mat); c->last_block = block; }
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G, block);
-    const int part_grid = grid;   // (rp_cost_kernel / rp_chunk_kernel: one partial per 64 candidates, fewer than the 16-lane kernel's)
+    // (rp_cost_kernel / rp_chunk_kernel: one partial per 64 candidates, fewer than the 16-lane kernel's; a bounded sweep keeps its pass 1's
+    //  partials behind its own: room for two sets)
+    const int part_grid = 2 * grid + 2;
     if (std::max(part_grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
@@ -892,6 +907,9 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     bool time_valid = false;
     const auto tp0 = c->timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     bool lazy_done = false;   // the cost-ordered collision stage delivered the result (its last round handed the ticket over)
+    bool swept = false;       // ... ran as a bounded sweep: the common epilogue picks the winner from the sweep's partials
+    int pass1_grid = 0;       //     and takes the batch's counters from its pass 1's (pass1_grid of them, behind the sweep's)
+    bool swept_totals = false;   //  ... or from the control block of the list stage the sweep took over from
     if (c->epilogue_dirty && (!ka.gate || ka.gate_level == 1)) {   // (the last chain of kernels on this context did not reach its result: see rp_ctx::epilogue_dirty)
         HIP_TRY(c, hipMemsetAsync(c->d_sel_scratch, 0, RP_SEL_SCRATCH * sizeof(unsigned long long), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t), c->stream));
@@ -1027,6 +1045,46 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             }
         }
         c->last_lazy = 0;
+        // The cost-ordered stage as ONE bounded sweep (no histogram, no lists, no decision of the host between the launches): pass 1 --
+        // costs of every candidate, no query -- and then the eager 16-lane kernel over the whole batch, in which a lane group evaluates
+        // its candidate only while no cheaper FREE candidate is known (KArgs::sweep_bound: atomic minimum of the cost keys of the
+        // candidates found free).  Every candidate cheaper than the winner is looked at -- its cost is below every value the bound
+        // ever has -- so the winner, the candidates labelled in front of it and infeasible_count_collision are those of the eager
+        // query; how many candidates BEHIND the winner were looked at before the bound closed depends on the order the wavefronts
+        // ran in (rp_result.n_collision reports the count in front of the winner).
+        // WHEN: as the fallback of the list rounds on large batches.  A winner near the top of the cost order is found by the first list
+        // round for less (cfg3f 91 vs 188 us, cfg4 330 vs 492: the sweep launches every workgroup of the batch, if only to find nothing to
+        // do); a winner deep in the cost order -- the three lists, 21 504 candidates, all collide -- leaves the eager kernel over the whole
+        // batch or the sweep: cfg4 + road boundary 880 -> 602 us, cfg3 (62 496 candidates, 97 % collide) 145 -> 159 us: from 131 072
+        // candidates on (profiles/probe_chunk_kernel.py).  Option "sweep" = 1: the sweep instead of the lists, whatever the size (tests).
+        const bool sweep_first = lazy_try && c->opt.sweep == 1 && !fused_lds;
+        const bool sweep_fallback = lazy_possible && c->opt.sweep != 0 && !fused_lds && !small && count >= (int64_t)c->num_cus * kSweepMinPerCU &&
+                                    !c->path_adaptive;
+        auto launch_sweep = [&](bool pass1) -> int {
+            if (pass1) {
+                KArgs k1 = ka;
+                k1.flags |= RP_FLAG_SKIP_COLLISION;
+                k1.states = nullptr;
+                k1.sweep_init = c->d_sweep;
+                k1.partials_first = grid;        // (behind the sweep's own partials)
+                const int r1 = launch_main_eval(k1, false);
+                if (r1 != RP_OK) return r1;
+                pass1_grid = main_grid;
+            }
+            KArgs kb = ka;
+            kb.states = nullptr;
+            kb.sweep_bound = c->d_sweep;
+            launch_eval(c, kb, grid, false, cin, G, block);
+            main_grid = grid;
+            swept = true;
+            swept_totals = !pass1;   // (behind exhausted lists: the batch's counters are in the stage's control block, summed from pass 1)
+            c->last_lazy = RP_PATH_SWEEP;
+            return RP_OK;
+        };
+        if (sweep_first) {
+            if ((rc = launch_sweep(true)) != RP_OK) return rc;
+            c->lazy_penalty = c->lazy_skip = 0;
+        } else
         if (lazy_try) {
             int lazy_rounds = 0;
             if ((rc = run_lazy(c, ka, cin, G, main_grid, best_states != nullptr, launch_main_eval, &lazy_done, &lazy_rounds)) != RP_OK) return rc;
@@ -1043,16 +1101,20 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
                     c->lazy_penalty = 0;
                 }
             }
-            else {   // the eager kernel decides (profiles are in place); the next plans do not try again for a while
+            else {   // the eager kernel (large batches: the bounded sweep) decides (profiles are in place); the next plans do not try again for a while
                 c->lazy_penalty = std::min(64, std::max(1, c->lazy_penalty * 2));
                 c->lazy_skip = c->lazy_penalty;
                 c->last_lazy = 2;
                 seq = ++c->seq;
                 if (ticket) hrb_host->seq = 0;
                 fin_seq = (ticket && !winner_pass) ? seq : 0ull;
+                if (sweep_fallback && (rc = launch_sweep(false)) != RP_OK) return rc;
             }
+        } else if (sweep_fallback && !always) {
+            // (the back-off after an exhausted stage: the plans it keeps away from the lists)
+            if ((rc = launch_sweep(true)) != RP_OK) return rc;
         }
-        if (count > 0 && !lazy_done && (rc = launch_main_eval(ka, mat)) != RP_OK) return rc;
+        if (count > 0 && !lazy_done && !swept && (rc = launch_main_eval(ka, mat)) != RP_OK) return rc;
         n_partials = count == 0 ? 0 : main_grid;
     } else {
         n_partials = (int)std::max<int64_t>(1, std::min<int64_t>((count + RP_BLOCK - 1) / RP_BLOCK, c->cap_partials));
@@ -1083,7 +1145,9 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         fa.row_stride = ka.row_stride; fa.tail_split = ka.tail_split; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
         fa.scratch = c->d_sel_scratch;
         fa.gate = const_cast<unsigned long long *>(ka.gate); fa.gate_seq = ka.gate_seq; fa.gate_level = ka.gate_level; fa.gate_last = chain_last ? 1 : 0;
-        if (small) {   // one workgroup does it all (count of the colliding candidates before the winner included)
+        fa.cnt_first = (swept && !swept_totals) ? grid : 0; fa.n_cnt_partials = (swept && !swept_totals) ? pass1_grid : 0;
+        fa.lazy = (swept && swept_totals) ? c->d_lazy_ctl : nullptr;
+        if (small && !swept) {   // one workgroup does it all (count of the colliding candidates before the winner included)
             fa.count_inline = 1;
             launch_block(c, (const void *)rp_finalize_kernel, 1, RP_FIN_THREADS, 0, &fa, sizeof(fa));
         } else {       // many workgroups, the last one to arrive writes the result and the ticket (rp_kernels.h: rp_select_kernel)
@@ -1144,7 +1208,7 @@ int pipeline_wait(rp_ctx *c, rp_result *result, double *best_states) {
 
     c->epilogue_dirty = false;   // the chain ran through: its epilogues have left their scratch words at zero
     const ResultBlock *hrb = reinterpret_cast<const ResultBlock *>(c->h_result);
-    *result = hrb->r;
+    result_from_core(result, hrb->r);
     result->n_collision_before_best = (int64_t)hrb->n_before;
     host_winner_coeffs(c, ka, cin, result);
     c->last_best_cost = result->best_cost; c->last_best_index = result->best_index;
@@ -1234,7 +1298,7 @@ void note_path_time(rp_ctx *c) {
     if (!c->path_adaptive) return;
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c->plan_t0).count();
     if (c->last_lazy == 2) return;   // (an exhausted stage is the back-off's business -- lazy_skip --, not a sample of what the stage costs when it works)
-    const int k = c->last_lazy;
+    const int k = c->last_lazy == RP_PATH_EAGER ? 0 : 1;
     c->path_us[k] = c->path_n[k] == 0 ? us : c->path_us[k] + 0.25 * (us - c->path_us[k]);
     if (c->path_n[k] < (1 << 30)) ++c->path_n[k];
 }
@@ -1285,6 +1349,7 @@ int rp_create(rp_ctx **out, int device) {
     HIP_TRY(c, hipMalloc((void **)&c->d_lazy_ctl, sizeof(LazyCtl)));
     HIP_TRY(c, hipMemset(c->d_lazy_ctl, 0, sizeof(LazyCtl)));
     HIP_TRY(c, hipMalloc((void **)&c->d_lazy_lists, kLazyListWords * sizeof(int32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_sweep, sizeof(unsigned long long)));
     HIP_TRY(c, hipMalloc((void **)&c->d_lazy_hist, (RP_LAZY_BINS + 1) * sizeof(uint32_t)));
     HIP_TRY(c, hipMemset(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t)));
 #if defined(RP_STAMPS) || defined(RP_TIMELINE)
@@ -1308,7 +1373,7 @@ void rp_destroy(rp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void *dev[] = {c->d_tables, c->d_sobb, c->d_tri, c->d_circ, c->d_dyn, c->d_clus, c->d_slot, c->d_grid, c->d_clus_info, c->d_stage, c->d_status, c->d_cost, c->d_user,
                    c->d_states, c->d_compact, c->d_partials, c->d_result, c->d_single, c->d_profile, c->d_profile_one,
-                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_sel_scratch, c->d_lazy_ctl, c->d_lazy_lists, c->d_lazy_hist, c->d_lazy_states, c->d_gate};
+                   c->d_pair_hdr, c->d_pair_hdr_one, c->d_sel_scratch, c->d_lazy_ctl, c->d_lazy_lists, c->d_lazy_hist, c->d_lazy_states, c->d_gate, c->d_sweep};
     for (void *p : dev)
         if (p) (void)hipFree(p);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1357,6 +1422,7 @@ int rp_set_option(rp_ctx *c, const char *key, int64_t value) {
 
 int rp_get_option(const rp_ctx *c, const char *key, int64_t *value) {
     if (!c || !value) return RP_EINVAL;
+    if (key && std::strcmp(key, "wait_fallbacks") == 0) { *value = c->wait_fallbacks; return RP_OK; }   // (read-only counter)
     const OptionDesc *d = find_option(key);
     if (!d) return RP_EINVAL;
     *value = c->opt.*(d->field);
@@ -1660,23 +1726,44 @@ struct LevelGate {   // a level of a chain (rp_plan_levels): see KArgs::gate
 };
 int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
                     int32_t want_best_states, const LevelGate *lg);
+int plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end, int32_t want_best_states);
+int plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, int32_t want_best_states);
+// grids of a RP_PLAN_PACKED call: the sizes in `dims`, the arrays in the context's buffer (rp_fast_buffer), level behind level
+int packed_grids(rp_ctx *c, int32_t n_levels, const rp_grids *dims, rp_grids *out);
 }  // namespace
 
 extern "C" {
 
-int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
-            rp_result *result, double *best_states) {
-    if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
-    if (c) c->time_whole = true;
-    int rc = rp_plan_begin(c, p, cost, g, cand_begin, cand_end, best_states != nullptr ? 1 : 0);
-    if (rc == RP_OK) rc = rp_plan_wait(c, result, best_states);
-    if (c) { if (rc == RP_OK) note_path_time(c); c->time_whole = false; }
-    return rc;
+int rp_plan(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end, uint32_t flags,
+            rp_result *result, double *out) {
+    if (!c) return RP_EINVAL;
+    if (flags & ~(RP_PLAN_BEGIN | RP_PLAN_ROWS | RP_PLAN_PACKED)) return fail(c, RP_EINVAL, "rp_plan: unknown flag");
+    rp_grids pg;
+    if (flags & RP_PLAN_PACKED) {
+        if (!p || !cost || !g) return fail(c, RP_EINVAL, "rp_plan: null argument");
+        if (cand_begin != 0 || cand_end >= 0) return fail(c, RP_EINVAL, "rp_plan: RP_PLAN_PACKED plans whole grids (cand_begin 0, cand_end -1)");
+        if (!(flags & RP_PLAN_BEGIN) && !out) return fail(c, RP_EINVAL, "rp_plan: RP_PLAN_PACKED needs the output block");
+        const int grc = packed_grids(c, 1, g, &pg);
+        if (grc != RP_OK) return grc;
+        g = &pg;
+    }
+    if (flags & RP_PLAN_BEGIN) return plan_begin(c, p, cost, g, cand_begin, cand_end, ((flags & RP_PLAN_ROWS) || out) ? 1 : 0);
+    if (!result) return fail(c, RP_EINVAL, "null params / cost / result");
+    if (result->struct_size != sizeof(rp_result)) return fail(c, RP_EABI, "rp_plan: rp_result.struct_size is not this library's");
+    c->time_whole = true;
+    int rc = plan_begin(c, p, cost, g, cand_begin, cand_end, out != nullptr ? 1 : 0);
+    if (rc == RP_OK) rc = rp_plan_wait(c, result, out);
+    if (rc == RP_OK) note_path_time(c);
+    c->time_whole = false;
+    if (rc != RP_OK || !(flags & RP_PLAN_PACKED) || result->best_index < 0) return rc;
+    const int n = p->N + 1;
+    return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
 }
 
 int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
     if (!c) return RP_EINVAL;
     if (!result) return fail(c, RP_EINVAL, "rp_plan_wait: null result");
+    if (result->struct_size != sizeof(rp_result)) return fail(c, RP_EABI, "rp_plan_wait: rp_result.struct_size is not this library's");
     if (!c->pending.active) return fail(c, RP_ESTATE, "rp_plan_wait: no plan in flight on this context");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->chain.size() > 1) {
@@ -1721,29 +1808,61 @@ int rp_plan_wait(rp_ctx *c, rp_result *result, double *best_states) {
             ++next;
         }
     }
+    // The loop of plan() visits an empty level like any other (reactive_planner.py:616-636: an empty bundle has no winner and leaves
+    // its counters at zero): when no level delivered and the LAST one is empty, the result is that level's -- nothing evaluated.
+    if (c->chain_total > 0 && result->best_index < 0) {
+        const int last = c->chain_total - 1;
+        const rp_grids &gl = c->chain_in.grids[(size_t)last];
+        if ((int64_t)gl.nT * gl.nL * gl.nD == 0 && c->last_level < last) {
+            result->n_candidates = result->n_feasible = result->n_collision = result->n_collision_before_best = 0;
+            for (int64_t &r : result->reason_counts) r = 0;
+            c->last_level = last;
+            c->have_last = false;   // (there is no "last plan" to fetch labels of)
+        }
+    }
+    c->chain_total = 0;
     return RP_OK;
-}
-
-int rp_plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
-                  int32_t want_best_states) {
-    if (c) { c->chain.clear(); c->chain_total = 0; c->last_level = 0; }
-    return plan_begin_impl(c, p, cost, g, cand_begin, cand_end, want_best_states, nullptr);
 }
 
 }  // extern "C"
 
 namespace {
+int plan_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end, int32_t want_best_states) {
+    if (c) { c->chain.clear(); c->chain_total = 0; c->last_level = 0; }
+    return plan_begin_impl(c, p, cost, g, cand_begin, cand_end, want_best_states, nullptr);
+}
+
+int packed_grids(rp_ctx *c, int32_t n_levels, const rp_grids *dims, rp_grids *out) {
+    if (c->fast_buf.empty()) return fail(c, RP_EINVAL, "RP_PLAN_PACKED: rp_fast_buffer was never asked for");
+    const double *b = c->fast_buf.data();
+    size_t at = 0;   // doubles
+    for (int k = 0; k < n_levels; ++k) {
+        if (dims[k].struct_size != sizeof(rp_grids)) return fail(c, RP_EABI, "RP_PLAN_PACKED: rp_grids.struct_size is not this library's");
+        const int nT = dims[k].nT, nL = dims[k].nL, nD = dims[k].nD;
+        if (nT < 0 || nL < 0 || nD < 0) return fail(c, RP_EINVAL, "RP_PLAN_PACKED: negative grid size");
+        const size_t words = (size_t)nT + nL + nD + ((size_t)nT + 1) / 2;
+        if (at + words > c->fast_buf.size()) return fail(c, RP_EINVAL, "RP_PLAN_PACKED: grids do not fit the buffer of rp_fast_buffer");
+        out[k].struct_size = (uint32_t)sizeof(rp_grids);
+        out[k].nT = nT; out[k].nL = nL; out[k].nD = nD;
+        out[k].T = b + at; out[k].L = b + at + nT; out[k].D = b + at + nT + nL;
+        out[k].traj_len = reinterpret_cast<const int32_t *>(b + at + nT + nL + nD);
+        at += words;
+    }
+    return RP_OK;
+}
+
 int plan_begin_impl(rp_ctx *c, const rp_params *p, const rp_cost *cost, const rp_grids *g, int64_t cand_begin, int64_t cand_end,
                     int32_t want_best_states, const LevelGate *lg) {
-    rp_result dummy_result;
-    rp_result *const result = &dummy_result;   // (validate only checks it for null)
+    rp_result dummy_result = RP_RESULT_INIT;
+    rp_result *const result = &dummy_result;   // (validate checks the caller's in the entry point; here only params and cost)
     double *const best_states = want_best_states ? reinterpret_cast<double *>(c) : nullptr;   // (only its being non-null matters below)
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
-    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_begin: a plan is already in flight on this context (rp_plan_wait first)");
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan: a plan is already in flight on this context (rp_plan_wait first)");
     c->have_last = false;   // (before anything of the last plan -- inline grids, staging area -- is overwritten: an early return leaves no half-valid plan behind)
     if (c->timing) c->t_entry = std::chrono::steady_clock::now();
     if (!g || g->nT < 0 || g->nL < 0 || g->nD < 0) return fail(c, RP_EINVAL, "rp_plan: bad grids");
+    if (g->struct_size != sizeof(rp_grids)) return fail(c, RP_EABI, "rp_plan: rp_grids.struct_size is not this library's");
     const int64_t total = (int64_t)g->nT * g->nL * g->nD;
     if (total > 0x7fffffffLL) return fail(c, RP_EINVAL, "rp_plan: more than 2^31 - 1 candidates in one grid");
     if (total > 0 && (!g->T || !g->traj_len || !g->L || !g->D)) return fail(c, RP_EINVAL, "rp_plan: null grid array");
@@ -1829,16 +1948,11 @@ bool level_chainable(const rp_ctx *c, const rp_params *p, const rp_grids *g) {
     // (plans of this size that want the winner's rows write every candidate's: no winner re-evaluation, no cost-ordered stage)
     return c->opt.auto_materialize && (size_t)total * RP_N_ARRAYS * (size_t)(p->N + 1) * sizeof(double) <= kAutoMaterializeBytes;
 }
-}  // namespace
 
-extern "C" {
-
-int rp_last_level(const rp_ctx *c) { return c ? c->last_level : 0; }
-
-int rp_plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, int32_t want_best_states) {
+int plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, int32_t want_best_states) {
     if (!c) return RP_EINVAL;
     if (n_levels < 1 || n_levels > 64 || !grids) return fail(c, RP_EINVAL, "rp_plan_levels: need 1 .. 64 levels");
-    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_levels_begin: a plan is already in flight on this context (rp_plan_wait first)");
+    if (c->pending.active) return fail(c, RP_ESTATE, "rp_plan_levels: a plan is already in flight on this context (rp_plan_wait first)");
     c->chain.clear(); c->chain_total = n_levels; c->last_level = 0;
     // the caller's inputs are kept: levels behind the chain (too large for it) run one by one inside rp_plan_wait
     rp_ctx::ChainInputs &in = c->chain_in;
@@ -1848,6 +1962,7 @@ int rp_plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int
     in.T.resize(n_levels); in.L.resize(n_levels); in.D.resize(n_levels); in.tl.resize(n_levels);
     for (int k = 0; k < n_levels; ++k) {
         const rp_grids &g = grids[k];
+        if (g.struct_size != sizeof(rp_grids)) return fail(c, RP_EABI, "rp_plan_levels: rp_grids.struct_size is not this library's");
         if (g.nT < 0 || g.nL < 0 || g.nD < 0 || ((int64_t)g.nT * g.nL * g.nD > 0 && (!g.T || !g.traj_len || !g.L || !g.D)))
             return fail(c, RP_EINVAL, "rp_plan_levels: bad grids");
         in.T[k].assign(g.T, g.T + (g.T ? g.nT : 0)); in.L[k].assign(g.L, g.L + (g.L ? g.nL : 0)); in.D[k].assign(g.D, g.D + (g.D ? g.nD : 0));
@@ -1911,35 +2026,32 @@ int rp_plan_levels_begin(rp_ctx *c, const rp_params *p, const rp_cost *cost, int
     return RP_OK;
 }
 
-int rp_plan_levels(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, rp_result *result,
-                   double *best_states, int32_t *level) {
-    if (c && !result) return fail(c, RP_EINVAL, "null params / cost / result");
-    int rc = rp_plan_levels_begin(c, p, cost, n_levels, grids, best_states != nullptr ? 1 : 0);
-    if (rc == RP_OK) rc = rp_plan_wait(c, result, best_states);
-    if (rc == RP_OK && level) *level = c->last_level;
-    return rc;
-}
+}  // namespace
 
-int rp_plan_levels_packed(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const int32_t *dims, rp_result *result, double *out,
-                          int32_t *level) {
+extern "C" {
+
+int rp_last_level(const rp_ctx *c) { return c ? c->last_level : 0; }
+
+int rp_plan_levels(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, uint32_t flags, rp_result *result,
+                   double *out, int32_t *level) {
     if (!c) return RP_EINVAL;
-    if (!p || !cost || !result || !out || !dims || n_levels < 1 || n_levels > 64) return fail(c, RP_EINVAL, "rp_plan_levels_packed: null argument / level count");
-    if (c->fast_buf.empty()) return fail(c, RP_EINVAL, "rp_plan_levels_packed: rp_fast_buffer was never asked for");
-    rp_grids g[64];
-    const double *b = c->fast_buf.data();
-    size_t at = 0;   // doubles
-    for (int k = 0; k < n_levels; ++k) {
-        const int nT = dims[3 * k], nL = dims[3 * k + 1], nD = dims[3 * k + 2];
-        if (nT < 0 || nL < 0 || nD < 0) return fail(c, RP_EINVAL, "rp_plan_levels_packed: negative grid size");
-        const size_t words = (size_t)nT + nL + nD + ((size_t)nT + 1) / 2;
-        if (at + words > c->fast_buf.size()) return fail(c, RP_EINVAL, "rp_plan_levels_packed: grids do not fit the buffer of rp_fast_buffer");
-        g[k].nT = nT; g[k].nL = nL; g[k].nD = nD; g[k].reserved_ = 0;
-        g[k].T = b + at; g[k].L = b + at + nT; g[k].D = b + at + nT + nL;
-        g[k].traj_len = reinterpret_cast<const int32_t *>(b + at + nT + nL + nD);
-        at += words;
+    if (flags & ~(RP_PLAN_BEGIN | RP_PLAN_ROWS | RP_PLAN_PACKED)) return fail(c, RP_EINVAL, "rp_plan_levels: unknown flag");
+    if (n_levels < 1 || n_levels > 64 || !grids) return fail(c, RP_EINVAL, "rp_plan_levels: need 1 .. 64 levels");
+    rp_grids pg[64];
+    if (flags & RP_PLAN_PACKED) {
+        if (!p || !cost) return fail(c, RP_EINVAL, "rp_plan_levels: null argument");
+        if (!(flags & RP_PLAN_BEGIN) && !out) return fail(c, RP_EINVAL, "rp_plan_levels: RP_PLAN_PACKED needs the output block");
+        const int grc = packed_grids(c, n_levels, grids, pg);
+        if (grc != RP_OK) return grc;
+        grids = pg;
     }
-    const int rc = rp_plan_levels(c, p, cost, n_levels, g, result, out, level);
-    if (rc != RP_OK || result->best_index < 0) return rc;
+    if (flags & RP_PLAN_BEGIN) return plan_levels_begin(c, p, cost, n_levels, grids, ((flags & RP_PLAN_ROWS) || out) ? 1 : 0);
+    if (!result) return fail(c, RP_EINVAL, "null params / cost / result");
+    if (result->struct_size != sizeof(rp_result)) return fail(c, RP_EABI, "rp_plan_levels: rp_result.struct_size is not this library's");
+    int rc = plan_levels_begin(c, p, cost, n_levels, grids, out != nullptr ? 1 : 0);
+    if (rc == RP_OK) rc = rp_plan_wait(c, result, out);
+    if (rc == RP_OK && level) *level = c->last_level;
+    if (rc != RP_OK || !(flags & RP_PLAN_PACKED) || result->best_index < 0) return rc;
     const int n = p->N + 1;
     return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
 }
@@ -1966,12 +2078,6 @@ int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_co
     return RP_OK;
 }
 
-int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
-                   const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, rp_result *result,
-                   double *best_states) {
-    return rp_plan_coeffs_grouped(c, p, cost, C, lon_coeffs, lat_coeffs, lon_T, traj_len, 0, nullptr, nullptr, result, best_states);
-}
-
 int rp_coeffs_arena_groups(rp_ctx *c, int32_t **group, int32_t **group_first) {
     if (!c) return RP_EINVAL;
     if (!c->h_arena || !group || !group_first) return fail(c, RP_ESTATE, "rp_coeffs_arena_groups: no arena (rp_coeffs_arena first) / null output");
@@ -1981,9 +2087,9 @@ int rp_coeffs_arena_groups(rp_ctx *c, int32_t **group, int32_t **group_first) {
     return RP_OK;
 }
 
-int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
-                           const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups, const int32_t *group,
-                           const int32_t *group_first, rp_result *result, double *best_states) {
+int rp_plan_coeffs(rp_ctx *c, const rp_params *p, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                   const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups, const int32_t *group,
+                   const int32_t *group_first, rp_result *result, double *best_states) {
     int rc = validate(c, p, cost, result);
     if (rc != RP_OK) return rc;
     if (c->timing) c->t_entry = std::chrono::steady_clock::now();
@@ -2049,7 +2155,7 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
     if (n_groups > 0 && group && group_first && !no_zero_copy) {   // (RP_AMD_NO_ZERO_COPY: the A/B path copies the rows, the group tables stay behind)
         int32_t *tl_h = reinterpret_cast<int32_t *>(reinterpret_cast<double *>(c->h_arena) + 12 * c->arena_cap);
         if (!in_arena || group != tl_h + c->arena_cap || group_first != tl_h + 2 * c->arena_cap || n_groups > C)
-            return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: groups come with candidates out of the context's arena (rp_coeffs_arena, rp_coeffs_arena_groups)");
+            return fail(c, RP_EINVAL, "rp_plan_coeffs: groups come with candidates out of the context's arena (rp_coeffs_arena, rp_coeffs_arena_groups)");
         // (the kernels index profiles and polynomials through these tables: every entry is looked at -- ~10 us at 25 000 candidates)
         bool tables_ok = C > 0 && group[0] == 0 && group_first[0] == 0 && group[C - 1] == (int32_t)(n_groups - 1);
         for (int64_t i = 1; tables_ok && i < C; ++i) {
@@ -2057,7 +2163,7 @@ int rp_plan_coeffs_grouped(rp_ctx *c, const rp_params *p, const rp_cost *cost, i
             tables_ok = step == 0 || (step == 1 && group_first[group[i]] == (int32_t)i);
         }
         if (!tables_ok)
-            return fail(c, RP_EINVAL, "rp_plan_coeffs_grouped: groups must be adjacent and numbered 0 .. n_groups - 1 in order, group_first their first candidates");
+            return fail(c, RP_EINVAL, "rp_plan_coeffs: groups must be adjacent and numbered 0 .. n_groups - 1 in order, group_first their first candidates");
         if (!no_groups && !single_launch) {   // (tables checked either way: what a call accepts does not depend on the batch size)
             const int32_t *tl_d = reinterpret_cast<const int32_t *>(reinterpret_cast<const double *>(c->h_arena_dev) + 12 * c->arena_cap);
             ka.pair_of = tl_d + c->arena_cap;
@@ -2174,7 +2280,7 @@ int rp_count_collisions_before(rp_ctx *c, double cost, int64_t index, int64_t *c
     if (!c->have_last || !count) return fail(c, RP_ESTATE, "rp_count_collisions_before: no plan / null output");
     // after a cost-ordered plan the labels are complete up to the plan's own winner (all of them without one): a key behind it
     // would count candidates nobody looked at
-    if (c->last_lazy == 1 && c->last_best_index >= 0 && !(cost < c->last_best_cost || (cost == c->last_best_cost && index <= c->last_best_index)))
+    if ((c->last_lazy == RP_PATH_LAZY || c->last_lazy == RP_PATH_SWEEP) && c->last_best_index >= 0 && !(cost < c->last_best_cost || (cost == c->last_best_cost && index <= c->last_best_index)))
         return fail(c, RP_ESTATE, "rp_count_collisions_before: (cost, index) sorts behind the winner of a plan that answered the collision "
                                   "query in cost order (rp_last_path() == RP_PATH_LAZY)");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2199,9 +2305,10 @@ int rp_select(rp_ctx *c, const double *costs, int64_t count, rp_result *result, 
     if (c->pending.active) return fail(c, RP_ESTATE, "rp_select: a plan is in flight on this context (rp_plan_wait first)");
     if (!c->have_last) return fail(c, RP_ESTATE, "rp_select: no plan on this context");
     if (!result || count != c->last.count || (count && !costs)) return fail(c, RP_EINVAL, "rp_select: count mismatch");
+    if (result->struct_size != sizeof(rp_result)) return fail(c, RP_EABI, "rp_select: rp_result.struct_size is not this library's");
     // a cost-ordered plan (rp_last_path() == RP_PATH_LAZY) answered the collision query for the candidates it had to look at only:
     // the others keep RP_LABEL_FEASIBLE, and a selection with other costs could crown a colliding one
-    if (c->last_lazy == 1)
+    if (c->last_lazy == RP_PATH_LAZY || c->last_lazy == RP_PATH_SWEEP)
         return fail(c, RP_ESTATE, "rp_select: the last plan answered the collision query in cost order (rp_last_path() == RP_PATH_LAZY); "
                                   "plan with RP_FLAG_MATERIALIZE_ALL / RP_COST_EXTERNAL, which take the eager query");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -2253,7 +2360,8 @@ int rp_combine_results(rp_ctx *c, const void *d_msgs, int32_t world, void *strea
         HIP_TRY(c, hipStreamSynchronize(st));
         if (__atomic_load_n(&hrb_host->seq, __ATOMIC_ACQUIRE) != seq) return fail(c, RP_EHIP, "rp_combine_results: no completion ticket");
     }
-    *global = hrb_host->r;
+    if (global->struct_size != sizeof(rp_result)) return fail(c, RP_EABI, "rp_combine_results: rp_result.struct_size");
+    result_from_core(global, hrb_host->r);
     global->n_collision_before_best = 0;
     global->kernel_ms = 0.0;
     KArgs ka = c->last;
@@ -2344,23 +2452,6 @@ int rp_fast_buffer(rp_ctx *c, void **ptr, size_t *bytes) {
     *ptr = c->fast_buf.data();
     *bytes = c->fast_buf.size() * sizeof(double);
     return RP_OK;
-}
-
-int rp_plan_packed(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t nT, int32_t nL, int32_t nD, rp_result *result, double *out) {
-    if (!c) return RP_EINVAL;
-    if (!p || !cost || !result || !out) return fail(c, RP_EINVAL, "rp_plan_packed: null argument");
-    if (nT < 0 || nL < 0 || nD < 0 || c->fast_buf.empty() ||
-        ((size_t)nT + nL + nD) * sizeof(double) + (size_t)nT * sizeof(int32_t) > c->fast_buf.size() * sizeof(double))
-        return fail(c, RP_EINVAL, "rp_plan_packed: grids do not fit the buffer of rp_fast_buffer (or it was never asked for)");
-    const double *b = c->fast_buf.data();
-    rp_grids g;
-    g.nT = nT; g.nL = nL; g.nD = nD; g.reserved_ = 0;
-    g.T = b; g.L = b + nT; g.D = b + nT + nL;
-    g.traj_len = reinterpret_cast<const int32_t *>(b + nT + nL + nD);
-    const int rc = rp_plan(c, p, cost, &g, 0, -1, result, out);
-    if (rc != RP_OK || result->best_index < 0) return rc;
-    const int n = p->N + 1;
-    return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
 }
 
 int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out) {
@@ -2580,8 +2671,10 @@ int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq,
     if (local->best_index >= 0 && local_best_states) std::memcpy(mine + l.states_off, local_best_states, sbytes);
     __atomic_store_n(reinterpret_cast<uint64_t *>(mine), seq, __ATOMIC_RELEASE);
     if (!mailbox_wait(region, l, world, seq, 0)) return RP_ESTATE;
+    if (local->struct_size != sizeof(rp_result) || global->struct_size != sizeof(rp_result)) return RP_EABI;
     rp_result g;
     std::memset(&g, 0, sizeof(g));
+    g.struct_size = (uint32_t)sizeof(rp_result);
     g.best_index = -1;
     g.best_cost = std::nan("");
     g.best_lat_T = std::nan("");

@@ -8,7 +8,7 @@
 #include <stddef.h>
 #include "rp_amd.h"
 
-typedef int (*rp_plan_fn)(rp_ctx *, const rp_params *, const rp_cost *, const rp_grids *, int64_t, int64_t, rp_result *, double *);
+typedef int (*rp_plan_fn)(rp_ctx *, const rp_params *, const rp_cost *, const rp_grids *, int64_t, int64_t, uint32_t, rp_result *, double *);
 typedef int (*rp_last_path_fn)(const rp_ctx *);
 
 typedef struct rp_hostloop_stats {
@@ -26,7 +26,7 @@ int rp_hostloop_run(rp_plan_fn plan, rp_last_path_fn last_path, rp_ctx *ctx, int
                     int64_t k0, int64_t steps, rp_result *result, double *best_states, rp_hostloop_stats *st) {
     for (int64_t k = k0; k < k0 + steps; ++k) {
         const int32_t i = (int32_t)(k % n_inputs);
-        const int rc = plan(ctx, params[i], cost[i], grids[i], cand_begin ? cand_begin[i] : 0, cand_end ? cand_end[i] : -1, result,
+        const int rc = plan(ctx, params[i], cost[i], grids[i], cand_begin ? cand_begin[i] : 0, cand_end ? cand_end[i] : -1, 0u, result,
                             best_states);
         if (rc != 0) return rc;
         if (st) {
@@ -68,7 +68,7 @@ int rp_hostloop_run_sharded(rp_plan_fn plan, rp_last_path_fn last_path, rp_excha
     double t_ex = 0.0;
     for (int64_t k = k0; k < k0 + steps; ++k) {
         const int32_t i = (int32_t)(k % n_inputs);
-        int rc = plan(ctx, params[i], cost[i], grids[i], cand_begin[i], cand_end[i], local, local_states);
+        int rc = plan(ctx, params[i], cost[i], grids[i], cand_begin[i], cand_end[i], 0u, local, local_states);
         if (rc != 0) return rc;
         if (st) {
             st->feasible_sum += local->n_feasible;

@@ -79,6 +79,12 @@ struct KArgs {
                                   // per candidate): rows hold the first M steps (row_stride == M), the last N + 1 - M steps of rows 2q and
                                   // 2q + 1 share 128-byte line q behind the rows -- see state_offset
     struct LazyCtl *lazy_ctl;     // first pass of the cost-ordered collision stage: workgroup 0 clears the stage's control block
+    // Bounded collision sweep (rp_host.hip: run_sweep): pass 1 -- costs without the query -- opens the bound (workgroup 0 stores ~0 to
+    // *sweep_init); the sweep -- the eager 16-lane kernel over the whole batch -- evaluates only candidates that are FEASIBLE by pass 1 and
+    // whose cost key is <= *sweep_bound, and every candidate it finds free lowers the bound (atomic min of its cost key)
+    unsigned long long *sweep_init;
+    unsigned long long *sweep_bound;
+    int32_t partials_first, pad_sweep_;   // first slot of this launch's block partials (the sweep's and its pass 1's share one allocation)
     // tables
     const double *tables;  // [TB_ROWS][n_ref]
     int32_t n_ref, search_iters, n_buckets, table_words;
@@ -251,10 +257,18 @@ struct GatherArgs {
     uint32_t target[RP_LAZY_LEVELS], pad2_;   // cumulative number of candidates each level is meant to reach
 };
 
-struct DevResult {
-    rp_result r;
-    // followed in the same allocation by best_states[14][N+1]
+// The 28 eight-byte words of rp_result behind its struct_size header (include/rp_amd.h): what the kernels write.  The result blocks
+// in device and pinned host memory hold these; the host copies them into the caller's rp_result (rp_host.hip: result_from_core).
+struct ResultCore {
+    int64_t best_index;
+    double best_cost;
+    int64_t n_candidates, n_feasible, n_collision_before_best, n_collision;
+    int64_t reason_counts[8];
+    double best_lon_coeffs[6], best_lat_coeffs[6];
+    double best_lat_T, kernel_ms;
 };
+static_assert(sizeof(ResultCore) == 28 * 8 && sizeof(rp_result) == 8 + sizeof(ResultCore) && offsetof(rp_result, best_index) == 8 &&
+              offsetof(rp_result, kernel_ms) == 8 + offsetof(ResultCore, kernel_ms), "rp_result = struct_size header + ResultCore");
 
 // In-kernel stamps (diagnostic build only; see cdna_hip_programming.md section 7).  Values go to a
 // buffer nothing else reads.
@@ -385,7 +399,7 @@ __device__ __forceinline__ bool better(double c, int64_t i, double bc, int64_t b
 #define RP_WSTATUS_ROWS_ON_HOST 0x100u   // FinalizeOut.w_status: the winner's state rows are NOT behind this header in device memory
                                          // (non-materialising plans re-evaluate the winner straight into the host mirror)
 struct FinalizeOut {          // layout shared with the host (rp_host.hip: ResultBlock)
-    rp_result r;
+    ResultCore r;
     unsigned long long n_before;
     uint32_t w_status, pad_;
     double w_cost;
@@ -449,6 +463,9 @@ struct FinArgs {
     unsigned long long *gate;
     unsigned long long gate_seq;
     int32_t gate_level, gate_last;
+    // epilogue of a bounded sweep (rp_select_kernel): the winner comes from the sweep's partials (`partials`), the counters of the batch
+    // from its pass 1's -- slots cnt_first .. cnt_first + n_cnt_partials - 1 of the same allocation (n_cnt_partials == 0: one set of partials)
+    int32_t cnt_first, n_cnt_partials;
 };
 #ifdef RP_STAMPS
 #define RP_FSTAMP(k)                                                                             \
@@ -482,7 +499,7 @@ __device__ __forceinline__ void store_result_header(FinalizeOut *dev_out, Finali
                                                     const unsigned long long *extra = nullptr /* [4]: words 31 .. 34 (w_coeffs[0..3]) */,
                                                     int level_tag = 0) {
     constexpr int words = (int)(offsetof(FinalizeOut, seq) / 8);
-    static_assert(words == 44 && sizeof(rp_result) == 28 * 8, "FinalizeOut layout");
+    static_assert(words == 44 && sizeof(ResultCore) == 28 * 8, "FinalizeOut layout");
     if (tid < words) {
         const int k = tid;
         const bool have = widx >= 0;
@@ -761,11 +778,16 @@ __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs
     double bc = 0.0;
     long long bi = -1;
     partials_min(pp, n_partials, tid, RP_SEL_THREADS, bc, bi);
-    // counters of this workgroup's slice of the partials
+    // counters of this workgroup's slice of the partials (after a bounded sweep: of its pass 1's partials -- the sweep's own count only
+    // the candidates it looked at)
     unsigned int cnt[RP_PARTIAL_CNT] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int per_p = (n_partials + nwg - 1) / nwg, k0 = w * per_p, k1 = k0 + per_p < n_partials ? k0 + per_p : n_partials;
+    const bool swept_totals = a.lazy != nullptr;   // (the sweep took over from exhausted list rounds: the counters are in their control block)
+    const bool swept = a.n_cnt_partials > 0 || swept_totals;
+    const int n_cp = swept_totals ? 0 : (swept ? a.n_cnt_partials : n_partials);
+    const Partials pcn = swept ? partials_at(a.partials, a.partials_cap, a.cnt_first) : pp;
+    const int per_p = (n_cp + nwg - 1) / nwg, k0 = w * per_p, k1 = k0 + per_p < n_cp ? k0 + per_p : n_cp;
     for (int k = k0 + tid; k < k1; k += RP_SEL_THREADS) {
-        const uint2 *pq = reinterpret_cast<const uint2 *>(pp.cnt + (size_t)k * RP_PARTIAL_CNT);
+        const uint2 *pq = reinterpret_cast<const uint2 *>(pcn.cnt + (size_t)k * RP_PARTIAL_CNT);
         const uint2 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4];
         cnt[0] += q0.x; cnt[1] += q0.y; cnt[2] += q1.x; cnt[3] += q1.y; cnt[4] += q2.x;
         cnt[5] += q2.y; cnt[6] += q3.x; cnt[7] += q3.y; cnt[8] += q4.x; cnt[9] += q4.y;
@@ -841,6 +863,12 @@ __global__ __launch_bounds__(RP_SEL_THREADS) void rp_select_kernel(const FinArgs
     // -- the last workgroup: totals -> result header -> completion ticket; scratch cleared for the next launch
     if (tid < RP_PARTIAL_CNT) sh_c32[tid] = (unsigned int)__hip_atomic_load(&a.scratch[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid == RP_PARTIAL_CNT) sh_before = __hip_atomic_load(&a.scratch[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // (after a bounded sweep "colliding candidates found" is the number in front of the winner: which candidates BEHIND it the sweep
+    //  looked at before the bound closed depends on the order its wavefronts ran in -- not a property of the plan)
+    if (swept_totals && tid < RP_PARTIAL_CNT) sh_c32[tid] = (unsigned int)a.lazy->totals[tid];
+    __syncthreads();
+    if (swept && tid == 0) sh_c32[1] = (unsigned int)sh_before;
     __syncthreads();
     if (tid < 12) __hip_atomic_store(&a.scratch[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     store_result_header(dev_out, host_out, tid, widx, wcost, a.count, sh_c32, sh_before, want_rows, nullptr, a.gate_level);
@@ -1703,7 +1731,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
         count_ = (int64_t)(lc < (uint32_t)a.list_cap ? lc : (uint32_t)a.list_cap);
         if ((int64_t)blockIdx.x * GPB >= count_) {
             if (a.partials) {
-                const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+                const Partials bp = partials_at(a.partials, a.partials_cap, a.partials_first + (int)blockIdx.x);
                 if (tid == 0) { bp.cost[0] = 0.0; bp.idx[0] = -1; }
                 if (tid >= 8 && tid < 8 + RP_PARTIAL_CNT) bp.cnt[tid - 8] = 0u;
             }
@@ -1713,6 +1741,34 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
     const int64_t count = count_;
     if (!LON_FUSED && a.lazy_ctl && blockIdx.x == 0 && tid < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
         reinterpret_cast<unsigned long long *>(a.lazy_ctl)[tid] = 0ull;
+    if (!LON_FUSED && a.sweep_init && blockIdx.x == 0 && tid == 0)   // (pass 1 of the bounded sweep: no free candidate known yet)
+        __hip_atomic_store(a.sweep_init, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The sweep itself: a lane group evaluates its candidate only if pass 1 left it FEASIBLE and no cheaper free candidate is known; a
+    // workgroup none of whose candidates needs that leaves an empty partial and is gone after one round trip.
+    const bool sweep = !LON_FUSED && !MAT && COLL != 0 && a.sweep_bound != nullptr && !a.index_list && !a.single_index;
+    bool sweep_need = true;
+    if (sweep) {
+        const int64_t sl = wave_first + group_in_wave;
+        const bool v0 = sl < count;
+        const int64_t slc = v0 ? sl : 0;
+        const uint32_t st0 = a.status[slc];
+        const double cs0 = a.cost[slc];
+        const unsigned long long bound = __hip_atomic_load(a.sweep_bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sweep_need = v0 && RP_STATUS_LABEL(st0) == RP_LABEL_FEASIBLE && cs0 == cs0 && cost_key(cs0) <= bound;
+        __shared__ int sh_sweep_any;
+        if (tid == 0) sh_sweep_any = 0;
+        __syncthreads();
+        if (__ballot(sweep_need) != 0 && lane == 0) sh_sweep_any = 1;
+        __syncthreads();
+        if (!sh_sweep_any) {   // (workgroup-uniform)
+            if (a.partials) {
+                const Partials bp = partials_at(a.partials, a.partials_cap, a.partials_first + (int)blockIdx.x);
+                if (tid == 0) { bp.cost[0] = 0.0; bp.idx[0] = -1; }
+                if (tid >= 8 && tid < 8 + RP_PARTIAL_CNT) bp.cnt[tid - 8] = 0u;
+            }
+            return;
+        }
+    }
 
     __shared__ GroupScratch sh_grp[GPB];
     __shared__ double sh_best_cost[GPB];
@@ -2038,7 +2094,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
     if (wave_first < count) {   // wave-uniform
         const int64_t w0 = wave_first;
         const int64_t slot = w0 + group_in_wave;                      // local candidate slot of this group
-        const bool valid = slot < count;
+        const bool valid = slot < count && sweep_need;
         // (lanes without a candidate shadow the first candidate of their wavefront, whose profile rows exist)
         const int64_t gidx = al.single_index ? *al.single_index
                              : ((!LON_FUSED && al.index_list) ? (int64_t)al.index_list[valid ? slot : w0] : al.cand_begin + (valid ? slot : w0));
@@ -2483,6 +2539,11 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                 const int64_t fs = gidx - al.cand_begin;
                 al.status[fs] = status;
                 cost = decided_bad ? cost : al.cost[fs];
+            } else if (sweep) {   // the candidate's label; its cost stays pass 1's; a free candidate lowers the bound for everyone behind it
+                al.status[slot] = status;
+                cost = decided_bad ? cost : al.cost[slot];
+                if (status == RP_LABEL_FEASIBLE && cost == cost)
+                    __hip_atomic_fetch_min(al.sweep_bound, cost_key(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 al.status[slot] = status;
                 al.cost[slot] = cost;
@@ -2514,7 +2575,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                 for (int k = 0; k < GPB; ++k)
                     if (sh_best_idx[k] >= 0 && better(sh_best_cost[k], (int64_t)sh_best_idx[k], bc, (int64_t)bi)) { bc = sh_best_cost[k]; bi = sh_best_idx[k]; }
             }
-            const Partials bp = partials_at(al.partials, al.partials_cap, (int)blockIdx.x);
+            const Partials bp = partials_at(al.partials, al.partials_cap, al.partials_first + (int)blockIdx.x);
             if (tid == 0) { bp.cost[0] = bi >= 0 ? bc : 0.0; bp.idx[0] = bi; }
             if (tid >= 8 && tid < 8 + RP_PARTIAL_CNT) bp.cnt[tid - 8] = (uint32_t)sh_cnt[tid - 8];
         }
@@ -2564,6 +2625,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_W
     const int64_t w0 = (int64_t)blockIdx.x * RP_COST_BLOCK;
     if (a.lazy_ctl && blockIdx.x == 0 && lane < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
         reinterpret_cast<unsigned long long *>(a.lazy_ctl)[lane] = 0ull;
+    if (a.sweep_init && blockIdx.x == 0 && lane == 0) __hip_atomic_store(a.sweep_init, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (pass 1 of the bounded sweep)
     const int64_t slot = w0 + lane;
     const bool valid = slot < count;
     const int64_t gidx = a.cand_begin + (valid ? slot : w0);   // (lanes behind the batch shadow the wavefront's first candidate)
@@ -2793,7 +2855,7 @@ __global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_W
         double bc = (valid && lab == RP_LABEL_FEASIBLE && cost == cost) ? cost : 0.0;
         long long bi = (valid && lab == RP_LABEL_FEASIBLE && cost == cost) ? (long long)gidx : -1;
         wave_min_pair(bc, bi);
-        const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+        const Partials bp = partials_at(a.partials, a.partials_cap, a.partials_first + (int)blockIdx.x);
         const unsigned int n_feas = (unsigned int)__popcll(__ballot(valid && (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION)));
         unsigned int mine = 0;
 #pragma unroll
@@ -2861,6 +2923,7 @@ __global__ __launch_bounds__(RP_CHUNK_BLOCK * RP_CHUNK_MAX_BLOCKS, COLL ? RP_WAV
     const int64_t w0 = (int64_t)blockIdx.x * RP_CHUNK_BLOCK;
     if (a.lazy_ctl && blockIdx.x == 0 && tid < (int)(sizeof(LazyCtl) / 8))   // (first pass of the lazy stage)
         reinterpret_cast<unsigned long long *>(a.lazy_ctl)[tid] = 0ull;
+    if (a.sweep_init && blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.sweep_init, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (pass 1 of the bounded sweep)
     const int64_t slot = w0 + lane;
     const bool valid = slot < count;
     const int64_t gidx = a.cand_begin + (valid ? slot : w0);   // (lanes behind the batch shadow the wavefront's first candidate)
@@ -3153,7 +3216,7 @@ __global__ __launch_bounds__(RP_CHUNK_BLOCK * RP_CHUNK_MAX_BLOCKS, COLL ? RP_WAV
         double bc = (mine && lab == RP_LABEL_FEASIBLE && cost == cost) ? cost : 0.0;
         long long bi = (mine && lab == RP_LABEL_FEASIBLE && cost == cost) ? (long long)gidx : -1;
         wave_min_pair(bc, bi);
-        const Partials bp = partials_at(a.partials, a.partials_cap, (int)blockIdx.x);
+        const Partials bp = partials_at(a.partials, a.partials_cap, a.partials_first + (int)blockIdx.x);
         const unsigned int n_feas = (unsigned int)__popcll(__ballot(mine && (lab == RP_LABEL_FEASIBLE || lab == RP_LABEL_INFEASIBLE_COLLISION)));
         unsigned int cnt_mine = 0;
 #pragma unroll
@@ -3402,7 +3465,7 @@ __global__ __launch_bounds__(RP_BLOCK) void rp_partials_kernel(const uint32_t *s
 // infeasible_count_collision: colliding feasible samples that precede the winner in cost order
 // (the lazy loop of reactive_planner.py:1031-1046 touches exactly those).  out += count.
 __global__ __launch_bounds__(RP_BLOCK) void rp_count_before_kernel(const uint32_t *status, const double *cost, int64_t count,
-                                                                   int64_t cand_begin, const rp_result *res,
+                                                                   int64_t cand_begin, const ResultCore *res,
                                                                    double wcost_in, int64_t widx_in, int use_args,
                                                                    unsigned long long *out) {
     if (!use_args && res->n_collision == 0) return;

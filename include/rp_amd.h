@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 1
+#define RP_ABI_VERSION 2   /* 2 (round 5): struct_size fields + RP_EABI; the plan entries folded into rp_plan / rp_plan_levels / rp_plan_coeffs
+                              with a flags word; the collision path defaults to RP_COLLISION_AUTO (since round 4) */
 
 /* error codes */
 #define RP_OK 0
@@ -50,6 +51,8 @@ extern "C" {
 #define RP_ENOMEM (-4)
 #define RP_EDOMAIN (-5)    /* point outside the projection domain of the reference path */
 #define RP_EDIRECTION (-6) /* the vehicle does not drive along the reference path (negative longitudinal velocity) */
+#define RP_EABI (-7)       /* a struct's struct_size is not sizeof() of this library's struct: the caller was built against another
+                              version of this header (every struct below starts with its size; RP_*_INIT set it) */
 
 /* per-candidate status word:  label | reason << 4 | first_bad_step << 8 */
 #define RP_LABEL_NONE 0u                 /* reference label None: pre-filtered or left the projection domain */
@@ -103,7 +106,7 @@ enum rp_array {
 #define RP_FLAG_SKIP_COLLISION (1u << 2)  /* do not test against the obstacle tables */
 
 typedef struct rp_params {
-    double dt;              /* planning.dt */
+    uint32_t struct_size;   /* sizeof(rp_params), set by the caller (RP_PARAMS_INIT): checked by every entry, RP_EABI on mismatch */
     int32_t N;              /* planning.time_steps_computation; arrays have N + 1 entries */
     int32_t factor;         /* planning.factor (collision time index = time_step0 + i * factor) */
     int32_t time_step0;     /* x_0.time_step */
@@ -111,7 +114,7 @@ typedef struct rp_params {
     int32_t lon_mode;       /* RP_LON_* */
     uint32_t constraint_mask; /* RP_CHECK_* */
     uint32_t flags;         /* RP_FLAG_* */
-    int32_t reserved_;
+    double dt;              /* planning.dt */
     double x0_lon[3];       /* s, s_dot, s_ddot */
     double x0_lat[3];       /* d, d_dot, d_ddot (derivatives w.r.t. s in low-velocity mode) */
     double x0_orientation;  /* x_0.orientation (standstill branch, reactive_planner.py:866) */
@@ -120,8 +123,8 @@ typedef struct rp_params {
 } rp_params;
 
 typedef struct rp_cost {
+    uint32_t struct_size; /* sizeof(rp_cost) */
     int32_t kind;         /* RP_COST_* */
-    int32_t reserved_;
     double w_a;           /* DefaultCostFunction.w_a (5, or 1 in stopping mode) */
     double desired_speed; /* NaN = None */
     double desired_d;
@@ -129,7 +132,8 @@ typedef struct rp_cost {
 } rp_cost;
 
 typedef struct rp_grids {
-    int32_t nT, nL, nD, reserved_;
+    uint32_t struct_size;    /* sizeof(rp_grids) */
+    int32_t nT, nL, nD;
     const double *T;         /* [nT] durations, reference iteration order */
     const int32_t *traj_len; /* [nT] len(np.arange(0, round(T + dt, 5), dt)) (reactive_planner.py:733,748) */
     const double *L;         /* [nL] longitudinal samples (stopping mode: already filtered by
@@ -138,6 +142,8 @@ typedef struct rp_grids {
 } rp_grids;
 
 typedef struct rp_result {
+    uint32_t struct_size;     /* sizeof(rp_result), set by the CALLER before the call (RP_RESULT_INIT): the library writes no more than that */
+    uint32_t reserved_;
     int64_t best_index;       /* winner = lexicographic min over (cost, index) among feasible,
                                  collision-free candidates of this call's range; -1 if none */
     double best_cost;         /* NaN if none */
@@ -154,6 +160,11 @@ typedef struct rp_result {
     double kernel_ms;         /* device time of this call's kernels (HIP events on the ctx stream);
                                  0 unless profiling is enabled */
 } rp_result;
+
+#define RP_PARAMS_INIT {(uint32_t)sizeof(rp_params)}
+#define RP_COST_INIT {(uint32_t)sizeof(rp_cost)}
+#define RP_GRIDS_INIT {(uint32_t)sizeof(rp_grids)}
+#define RP_RESULT_INIT {(uint32_t)sizeof(rp_result)}
 
 typedef struct rp_ctx rp_ctx;
 
@@ -189,6 +200,7 @@ int rp_get_wait_mode(const rp_ctx *ctx);
  *   "cost_kernel"       RP_AMD_COST_KERNEL          -1 by batch | 0 never | 1 whenever rp_cost_kernel applies
  *   "chunk_kernel"      RP_AMD_CHUNK_KERNEL         -1 by batch | 0 never | 1 whenever rp_chunk_kernel applies
  *   "lazy"              RP_AMD_LAZY                 -1 by rp_set_collision_path | 0 never | 1 cost-ordered stage whenever the launch path allows
+ *   "sweep"             RP_AMD_SWEEP                -1 by batch | 0 | 1: the cost-ordered stage as a bounded sweep (RP_PATH_SWEEP) instead of list rounds
  *   "fused_lon"         RP_AMD_NO_FUSED_LON         1 | 0: single-launch variant of small batches
  *   "fused_lon_blocks"  RP_AMD_FUSED_LON_BLOCKS     -1 (4 workgroups per CU) | largest grid that takes it
  *   "auto_materialize"  RP_AMD_NO_AUTO_MATERIALIZE  1 | 0: small batches whose winner rows are wanted write every candidate's rows
@@ -197,6 +209,8 @@ int rp_get_wait_mode(const rp_ctx *ctx);
  *   "fold_threshold"    RP_AMD_FOLD_THRESHOLD       block partials beyond which they are folded before the epilogue
  *   "event_bracket", "winner_lanes_as_batch", "lazy_trace", "print_stamps", "timing"   RP_AMD_<NAME>: 0 | 1 (measurement variants, diagnostics on stderr)
  *   "wait_mode"         RP_AMD_WAIT_MODE            RP_WAIT_* (as rp_set_wait_mode)
+ *   "wait_fallbacks"    (read-only, rp_get_option) waits for a completion ticket that ended in the 200-ms fall-back: 0 unless a kernel
+ *                       chain failed to hand its ticket over
  * RP_EINVAL: unknown key or value out of range; RP_ESTATE: a plan is in flight. */
 int rp_set_option(rp_ctx *ctx, const char *key, int64_t value);
 int rp_get_option(const rp_ctx *ctx, const char *key, int64_t *value);
@@ -214,21 +228,32 @@ int rp_set_obstacles(rp_ctx *ctx, int32_t n_sobb, const double *sobb, int32_t n_
                      const double *dyn);
 
 /* ---- the hot path ------------------------------------------------------------------------------ */
-/* Evaluate candidates [cand_begin, cand_end) of the nT*nL*nD grid (cand_end < 0: all).
- * best_states: NULL or [RP_N_ARRAYS][N + 1] receiving the winner's state block. */
+/* Three entries (round 5; rounds 1-4 had nine -- their names remain as inline wrappers at the end of this header):
+ *   rp_plan         one sampling level: candidates [cand_begin, cand_end) of the nT*nL*nD grid (cand_end < 0: all)
+ *   rp_plan_levels  the LEVEL LOOP of plan() in one call
+ *   rp_plan_coeffs  explicit polynomials of a foreign sampling space
+ * and rp_plan_wait, the second half of a call made with RP_PLAN_BEGIN.  `flags`:
+ *   RP_PLAN_BEGIN   validate, stage, put the kernels of the plan on the context's stream and return (result and out may be NULL);
+ *                   rp_plan_wait waits for the completion ticket the last kernel writes into pinned host memory and unpacks the result.
+ *                   Between the two the host is free -- the replanning loop packs the previous cycle's output and does its
+ *                   bookkeeping.  One plan in flight per context; the calls that read "the last plan" refer to the last COLLECTED
+ *                   one.  Plans whose chain needs decisions of the host in between (the list rounds of the cost-ordered collision
+ *                   stage of large batches) run them inside the call.
+ *   RP_PLAN_ROWS    with RP_PLAN_BEGIN: the winner's state block will be asked for by rp_plan_wait (without RP_PLAN_BEGIN a non-NULL
+ *                   `out` says so)
+ *   RP_PLAN_PACKED  for a binding whose per-argument cost matters (ctypes: ~0.5 us per array argument): the grids come from a buffer
+ *                   of the context the caller has filled -- rp_fast_buffer hands it out once, 32 KB, valid for the life of the
+ *                   context: per level [T (nT doubles) | L (nL) | D (nD) | traj_len (nT int32, padded to 8 bytes)], the levels
+ *                   one behind the other -- grids[k] holds the sizes only (T, traj_len, L, D NULL); and `out`
+ *                   ([RP_N_ARRAYS + 13][N + 1] doubles) receives, behind the winner's state block [RP_N_ARRAYS][N + 1], the packed
+ *                   output of rp_pack_trajectory [N + 1][13].  Whole grids only (cand_begin 0, cand_end -1).
+ * out: NULL or [RP_N_ARRAYS][N + 1] receiving the winner's state block (RP_PLAN_PACKED: see there). */
+#define RP_PLAN_BEGIN (1u << 0)
+#define RP_PLAN_ROWS (1u << 1)
+#define RP_PLAN_PACKED (1u << 2)
 int rp_plan(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids,
-            int64_t cand_begin, int64_t cand_end, rp_result *result, double *best_states);
-
-/* The same call in two halves.  rp_plan_begin validates, stages and puts the kernels of the plan on the context's stream and
- * returns; rp_plan_wait waits for the completion ticket the last kernel writes into pinned host memory and unpacks the result
- * (rp_plan = begin + wait).  Between the two the host is free -- the replanning loop packs the previous cycle's output and does
- * its bookkeeping.  (The levels of one cycle, which plan() visits one after the other -- reactive_planner.py:616-636 -- go onto the
- * stream together through rp_plan_levels below.)
- * One plan in flight per context; the calls that read "the last plan" refer to the last COLLECTED one.  Plans whose chain needs
- * decisions of the host in between (the cost-ordered collision stage of large batches) run them inside rp_plan_begin. */
-int rp_plan_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids, int64_t cand_begin,
-                  int64_t cand_end, int32_t want_best_states);
-int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *best_states);
+            int64_t cand_begin, int64_t cand_end, uint32_t flags, rp_result *result, double *out);
+int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *out);
 
 /* The LEVEL LOOP of plan() (commonroad_rp/reactive_planner.py:616-636: `while optimal_trajectory is None and i < sampling_level`,
  * one _create_trajectory_bundle + _get_optimal_trajectory per sampling level) in one call and ONE device round trip: grids[k] are the
@@ -239,23 +264,22 @@ int rp_plan_wait(rp_ctx *ctx, rp_result *result, double *best_states);
  * read "the last plan" (rp_fetch_status, rp_cost_range, rp_eval_one, ...) refer to that level.
  * Levels of up to 16 384 candidates whose grids fit the launch block (96 doubles: the reference's sampling levels hold at most
  * 29 + 17 + 18 samples) ride in the chain; a level that does not, and the levels behind it, are planned one by one inside the call.
- * rp_plan_levels = rp_plan_levels_begin + rp_plan_wait; rp_plan_levels_packed: the grids from the context's buffer
- * (rp_fast_buffer), level after level [T | L | D | traj_len (int32, padded to 8 bytes)], dims[k] = nT, nL, nD; output as
- * rp_plan_packed. */
-int rp_plan_levels(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids,
-                   rp_result *result, double *best_states, int32_t *level);
-int rp_plan_levels_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids,
-                         int32_t want_best_states);
-int rp_plan_levels_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const int32_t *dims /* [n_levels][3] */,
-                          rp_result *result, double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */, int32_t *level);
+ * flags as rp_plan (RP_PLAN_BEGIN: *level through rp_last_level after rp_plan_wait). */
+int rp_plan_levels(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids, uint32_t flags,
+                   rp_result *result, double *out, int32_t *level);
 int rp_last_level(const rp_ctx *ctx);
 
 /* Generic entry for foreign SamplingSpace plug-ins (sampling.py:165-175): the polynomials come
- * from the plug-in's TrajectorySample objects.  lon_coeffs/lat_coeffs: [C][6]; lon_T/lat_T: [C]
- * delta_tau of each polynomial; traj_len: [C].  Candidate index = list index. */
-int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C,
-                   const double *lon_coeffs, const double *lat_coeffs, const double *lon_T,
-                   const int32_t *traj_len, rp_result *result, double *best_states);
+ * from the plug-in's TrajectorySample objects.  lon_coeffs/lat_coeffs: [C][6]; lon_T: [C]
+ * delta_tau of each polynomial; traj_len: [C].  Candidate index = list index.
+ * Candidates that come in groups with a common longitudinal polynomial (and traj_len) -- all lateral samples of one (time, velocity)
+ * sample of a corridor level -- may say so: n_groups > 0, group[C] ascending without gaps from 0, the candidates of a group adjacent,
+ * group_first[n_groups]; the rows of a group's first candidate stand for the group (one longitudinal profile per group on the device
+ * instead of one per candidate).  Groups only with arrays out of the context's arena (rp_coeffs_arena, rp_coeffs_arena_groups);
+ * n_groups == 0 or group == NULL: one profile per candidate.  Results are the same either way. */
+int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                   const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups,
+                   const int32_t *group, const int32_t *group_first, rp_result *result, double *best_states);
 /* Pinned host arrays for the explicit polynomials of up to `cap` candidates, owned by the context: lon_coeffs [cap][6],
  * lat_coeffs [cap][6], traj_len [cap].  A sampling space that writes its candidates straight into them (rp_corridor_coeffs
  * with these as its outputs; CorridorSampling.generate_trajectories_at_level, sampling.py:340-397, builds one object per
@@ -268,15 +292,8 @@ int rp_plan_coeffs(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, in
  * have been collected -- writing the next level's candidates is what ends a level anyway. */
 int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len);
 /* Two more arrays of the arena handed out last, int32 [cap] each: room for the group of every candidate and the first candidate of
-   every group (rp_corridor_coeffs_grouped writes them, rp_plan_coeffs_grouped reads them). */
+   every group (rp_corridor_coeffs_grouped writes them, rp_plan_coeffs reads them). */
 int rp_coeffs_arena_groups(rp_ctx *ctx, int32_t **group, int32_t **group_first);
-/* rp_plan_coeffs for candidates that come in groups with a common longitudinal polynomial (and traj_len): group[C] ascending without
-   gaps from 0, the candidates of a group adjacent; group_first[n_groups].  The rows of a group's first candidate stand for the
-   group.  Arrays out of the context's arena only (rp_coeffs_arena, rp_coeffs_arena_groups); n_groups == 0 or group == NULL: as
-   rp_plan_coeffs.  Results are those of rp_plan_coeffs on the same candidates. */
-int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C, const double *lon_coeffs,
-                           const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups,
-                           const int32_t *group, const int32_t *group_first, rp_result *result, double *best_states);
 
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
 /* How the last plan answered the collision query (reactive_planner.py:1019-1063):
@@ -302,6 +319,9 @@ int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *
 #define RP_PATH_EAGER 0
 #define RP_PATH_LAZY 1
 #define RP_PATH_LAZY_FALLBACK 2
+#define RP_PATH_SWEEP 3   /* cost-ordered, as one bounded sweep: costs of every candidate first, then the eager query over the batch for the
+                             candidates no cheaper free one rules out -- same guarantees as RP_PATH_LAZY (every candidate in front of the
+                             winner is labelled); rp_result.n_collision == n_collision_before_best */
 int rp_last_path(const rp_ctx *ctx);
 /* Which kernel evaluated the batch of the last plan (diagnostic: what a measurement prices the plan against).
  *   RP_KERNEL_EVAL  rp_eval_kernel: 16 / 32 / 64 lanes per candidate, a lane per time step (every plan that keeps state rows)
@@ -360,13 +380,8 @@ int rp_check_swept(rp_ctx *ctx, const rp_params *params, int32_t n_poses, const 
    (shift_orientation, utility/general.py:49-55) | steering angle atan2(wheelbase * kappa, 1) (:539) | yaw rate
    (theta[i] - theta[i-1]) / dt (:535; entry 0 is 0: state 0 carries x_0.yaw_rate). */
 int rp_pack_trajectory(int32_t n, const double *states, double dt, double wheelbase, double x0_orientation, double *out);
-/* One replanning level in one call, for a binding whose per-argument cost matters (ctypes: ~0.5 us per array argument): the grids
-   come from a buffer of the context the caller has filled -- rp_fast_buffer hands it out once, 32 KB, valid for the life of the
-   context: [T (nT doubles) | L (nL) | D (nD) | traj_len (nT int32)] -- and the result leaves as rp_plan's plus, behind the winner's
-   state block in `out` ([RP_N_ARRAYS][N + 1], then [N + 1][13]), the packed output of rp_pack_trajectory. */
+/* The grid buffer of RP_PLAN_PACKED calls (rp_plan above): handed out once, 32 KB, valid for the life of the context. */
 int rp_fast_buffer(rp_ctx *ctx, void **ptr, size_t *bytes);
-int rp_plan_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t nT, int32_t nL, int32_t nD, rp_result *result,
-                   double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */);
 
 /* ---- adaptive sampling space (host only; no GPU involved) -----------------------------------------
    rp_corridor_coeffs: the candidates CorridorSampling.generate_trajectories_at_level returns (commonroad_rp/sampling.py:
@@ -456,6 +471,42 @@ int rp_mailbox_exchange(void *region, int32_t world, int32_t rank, uint64_t seq,
 int rp_mailbox_sum(void *region, int32_t world, int32_t rank, uint64_t seq, int32_t n_steps, int64_t value, int64_t *total);
 int rp_mailbox_set_timeout(double seconds);   /* wait budget per peer, process-wide; seconds > 0 */
 int rp_mailbox_stalled_rank(void);            /* peer the calling thread's last failed wait was spinning on; -1: none */
+
+/* ---- the plan entries of ABI version 1 (rounds 1-4), as wrappers over the three above: source compatibility only, nothing exported */
+static inline int rp_plan_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, const rp_grids *grids, int64_t cand_begin,
+                                int64_t cand_end, int32_t want_best_states) {
+    return rp_plan(ctx, params, cost, grids, cand_begin, cand_end, RP_PLAN_BEGIN | (want_best_states ? RP_PLAN_ROWS : 0u), (rp_result *)0, (double *)0);
+}
+static inline int rp_plan_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t nT, int32_t nL, int32_t nD,
+                                 rp_result *result, double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */) {
+    rp_grids g;
+    g.struct_size = (uint32_t)sizeof(rp_grids);
+    g.nT = nT; g.nL = nL; g.nD = nD;
+    g.T = g.L = g.D = (const double *)0; g.traj_len = (const int32_t *)0;
+    return rp_plan(ctx, params, cost, &g, 0, -1, RP_PLAN_PACKED, result, out);
+}
+static inline int rp_plan_levels_begin(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels, const rp_grids *grids,
+                                       int32_t want_best_states) {
+    return rp_plan_levels(ctx, params, cost, n_levels, grids, RP_PLAN_BEGIN | (want_best_states ? RP_PLAN_ROWS : 0u), (rp_result *)0, (double *)0,
+                          (int32_t *)0);
+}
+static inline int rp_plan_levels_packed(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int32_t n_levels,
+                                        const int32_t *dims /* [n_levels][3] */, rp_result *result, double *out, int32_t *level) {
+    rp_grids g[64];
+    int32_t k;
+    if (n_levels < 1 || n_levels > 64 || !dims) return RP_EINVAL;
+    for (k = 0; k < n_levels; ++k) {
+        g[k].struct_size = (uint32_t)sizeof(rp_grids);
+        g[k].nT = dims[3 * k]; g[k].nL = dims[3 * k + 1]; g[k].nD = dims[3 * k + 2];
+        g[k].T = g[k].L = g[k].D = (const double *)0; g[k].traj_len = (const int32_t *)0;
+    }
+    return rp_plan_levels(ctx, params, cost, n_levels, g, RP_PLAN_PACKED, result, out, level);
+}
+static inline int rp_plan_coeffs_grouped(rp_ctx *ctx, const rp_params *params, const rp_cost *cost, int64_t C, const double *lon_coeffs,
+                                         const double *lat_coeffs, const double *lon_T, const int32_t *traj_len, int64_t n_groups,
+                                         const int32_t *group, const int32_t *group_first, rp_result *result, double *best_states) {
+    return rp_plan_coeffs(ctx, params, cost, C, lon_coeffs, lat_coeffs, lon_T, traj_len, n_groups, group, group_first, result, best_states);
+}
 
 #ifdef __cplusplus
 }

@@ -175,6 +175,17 @@ def check_swept(params, tables: OracleTables, x, y, theta, want_boxes: bool = Fa
     return int(first), boxes
 
 
+def check_poses(params, tables: OracleTables, x, y, theta):
+    """Per-pose collision verdicts of one trajectory (``cc.collide`` of the ego rectangle at scenario time index
+    ``time_step0 + i * factor``, reactive_planner.py:1033-1046): (hit [n] bool, any)."""
+    x, y, theta = f64(x), f64(y), f64(theta)
+    n = len(x)
+    hit = np.zeros(n, dtype=np.int32)
+    tb = tables.c_struct()
+    lib().rp_oracle_check_poses(C.byref(params), C.byref(tb), n, dptr(x), dptr(y), dptr(theta), hit.ctypes.data_as(C.POINTER(C.c_int32)))
+    return hit.astype(bool), bool(hit.any())
+
+
 def obb_sum_rows(dyn_obb) -> np.ndarray:
     """trajectory_preprocess_obb_sum of every dynamic obstacle of a (n_dyn, n_steps, 5) table
     (commonroad_rp/reactive_planner.py:238-245)."""

@@ -644,6 +644,17 @@ int rp_oracle_check_swept(const rp_params *p, const rpo_tables *tb, int n, const
     return first;
 }
 
+/* cc.collide(ego rectangle of pose i at scenario time index time_step0 + i * factor), pose by pose (reactive_planner.py:1033-1046):
+ * hit[n] = 0 / 1.  What tests/test_thirdparty_pins.py compares with the verdicts of the real pycrcc. */
+void rp_oracle_check_poses(const rp_params *p, const rpo_tables *tb, int n, const double *x, const double *y, const double *theta, int32_t *hit) {
+    const double hl = 0.5 * p->length, hw = 0.5 * p->width;
+    for (int i = 0; i < n; ++i) {
+        const double c0 = cos(theta[i]), s0 = sin(theta[i]);
+        obb_t ego = {x[i] + p->wb_rear_axle * c0, y[i] + p->wb_rear_axle * s0, c0, s0, hl, hw};
+        hit[i] = pose_collides(tb, &ego, p->time_step0 + i * p->factor);
+    }
+}
+
 /* ------------------------------------------------------------------------------------------- */
 /* sampling: FixedIntervalSampling.generate_trajectories_at_level, commonroad_rp/sampling.py:202-242 */
 /* ------------------------------------------------------------------------------------------- */

@@ -30,6 +30,8 @@ int64_t rp_oracle_count_collisions_before(int64_t C, int64_t base, const uint32_
                                           double wcost, int64_t windex);
 int rp_oracle_check_swept(const rp_params *p, const rpo_tables *tb, int n, const double *x, const double *y,
                           const double *theta, double *boxes);
+void rp_oracle_check_poses(const rp_params *p, const rpo_tables *tb, int n, const double *x, const double *y, const double *theta,
+                           int32_t *hit);
 void rp_oracle_obb_sum_rows(int n_steps, const double *rows, double *out);
 void rp_oracle_sample(const rp_params *p, const rp_grids *g, int64_t idx, double lon[6], double lat[6],
                       double *lat_T, int *traj_len);

@@ -7,7 +7,7 @@ def lazy_relaxed(status, cost, orun, ctx, out, lo=0):
     reactive_planner.py:1031-1062) label the colliding candidates they had to look at: at least every one that sorts before the
     winner.  Returns the device labels with the others marked as the eager query would, and their number -- after checking
     that each of them really sorts behind the winner (and that there is a winner: without one every candidate was looked at)."""
-    if ctx is None or out is None or ctx.last_path() != 1:
+    if ctx is None or out is None or ctx.last_path() not in (1, 3):
         return status, 0
     unl = ((orun.status & 3) == 3) & ((status & 3) == 1)
     if unl.any():

@@ -10,7 +10,9 @@
   wave_wg        two-kernel path, 16 lanes per candidate, ONE wavefront per workgroup of the evaluation kernel (what costs-only plans
                  of batches beyond 131 072 candidates take: rp_host.hip eval_block)
   lane_chunk     two-kernel path; costs-only launches through rp_chunk_kernel: one lane per candidate and step block of 16 steps
-                 (what such plans take between 4 096 and 262 144 candidates at horizons of 17 .. 128 steps)"""
+                 (what such plans take from ~30 000 to ~200 000 candidates at horizons of 17 .. 64 steps)
+  sweep          two-kernel path with the cost-ordered stage forced AND run as a bounded sweep: costs of every candidate, then the eager
+                 kernel over the batch for the candidates no cheaper free one rules out (rp_last_path() == 3)"""
 import contextlib
 
 from commonroad_rp_amd import _capi
@@ -25,6 +27,7 @@ LAUNCH_PATHS = {
     "wave_wg": {"fused_lon": 0, "lanes": 16, "eval_block": 64, "chunk_kernel": 0},
     "lane_cand": {"fused_lon": 0, "cost_kernel": 1, "chunk_kernel": 0, "auto_materialize": 0},
     "lane_chunk": {"fused_lon": 0, "chunk_kernel": 1, "auto_materialize": 0},
+    "sweep": {"fused_lon": 0, "lazy": 1, "sweep": 1, "auto_materialize": 0},
 }
 
 

@@ -43,13 +43,13 @@ def test_collision_path_is_a_setting_of_the_context():
                 np.testing.assert_array_equal(lab, o.status & 3)          # every colliding candidate carries the label
                 assert out.n_collision == o.out.n_collision
             else:
-                assert ctx.last_path() == 1
+                assert ctx.last_path() in (1, 3)
                 diff = lab != (o.status & 3)                                # the ones the stage never looked at keep FEASIBLE
                 assert np.all(((o.status & 3)[diff] == 3) & (lab[diff] == 1))
                 assert o.out.n_collision_before_best <= out.n_collision <= o.out.n_collision
             seen[mode] = lab.copy()
-            # the stage's costs-only first pass over a batch of this size: one lane per candidate; with the query at this size: lanes over steps
-            assert ctx.last_kernel() == ("rp_eval_kernel" if mode == _capi.COLLISION_EAGER else "rp_cost_kernel")
+            # the stage's costs-only first pass over a batch of this size: one lane per candidate and step block; with the query at this size: lanes over steps
+            assert ctx.last_kernel() == ("rp_eval_kernel" if mode == _capi.COLLISION_EAGER else "rp_chunk_kernel")
         # a plan that keeps state rows answers the query for every pose whatever the setting, with the lanes-over-steps kernel
         ctx.set_collision_path(_capi.COLLISION_COST_ORDERED)
         out = ctx.plan(_draw(w.inputs))

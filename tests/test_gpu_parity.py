@@ -54,9 +54,11 @@ def _compare_collision_counts(out, oout, ctx=None, unlabelled=None):
     """infeasible_count_collision is the same on every path; the number of colliding candidates FOUND is all of them after an
     eager plan and at least the ones before the winner after a cost-ordered one."""
     assert out.n_collision_before_best == oout.n_collision_before_best
-    if ctx is not None and ctx.last_path() == 1:
+    if ctx is not None and ctx.last_path() in (1, 3):
         assert oout.n_collision_before_best <= out.n_collision <= oout.n_collision
-        if unlabelled is not None:
+        if ctx.last_path() == 3:   # bounded sweep: the count in front of the winner (what it looked at behind it is not a property of the plan)
+            assert out.n_collision == oout.n_collision_before_best
+        elif unlabelled is not None:
             assert out.n_collision == oout.n_collision - unlabelled
     else:
         assert out.n_collision == oout.n_collision
@@ -146,7 +148,7 @@ def test_sharded_ranges_compose(ctx, name):
     best = min(((p.best_cost, p.best_index) for p in parts if p.best_index >= 0), default=(np.nan, -1))
     assert best[1] == full.best_index
     assert sum(p.n_feasible for p in parts) == full.n_feasible
-    if ctx.last_path() != 1:   # (the cost-ordered stage reports the colliding candidates it looked at, which depends on the range)
+    if ctx.last_path() not in (1, 3):   # (the cost-ordered stage reports the colliding candidates it looked at, which depends on the range)
         assert sum(p.n_collision for p in parts) == full.n_collision
     np.testing.assert_array_equal(sum(p.reason_counts for p in parts), full.reason_counts)
     # second pass: colliding samples that precede the global winner, per shard
@@ -217,7 +219,7 @@ def test_select_after_plan_without_states(ctx, name):
     user = np.where((lab == 1) | (lab == 3), 10.0 + np.arange(len(lab)) * 1e-3, np.nan)
     pick = int(feas[len(feas) // 2])
     user[pick] = 1.0
-    if ctx.last_path() == 1:
+    if ctx.last_path() in (1, 3):
         # the plan answered the collision query in cost order: candidates behind its winner were never looked at, a selection with
         # other costs could crown a colliding one -- refused; plans for plug-in costs materialise and run eager
         with pytest.raises(_capi.RpError, match="cost order"):
@@ -270,13 +272,13 @@ def test_edge_cases(ctx):
     g2 = Golden("arc_all_collide")
     g2.setup_context(ctx)
     assert ctx.plan(g2.inputs).best_index == -1
-    # ... and "no winner" must come back as promptly as a winner does (the completion ticket is written on
-    # that path too; a missing ticket shows up as the 200 ms fall-back of the host's spin wait)
-    import time
-    t0 = time.perf_counter()
-    for _ in range(5):
+    # ... and "no winner" hands the completion ticket over like a winner does: the result block in pinned memory carries the ticket of
+    # THIS plan when the call returns (a missing ticket would leave the host in its 200-ms fall-back -- a stream synchronisation --
+    # and the block without it)
+    fallbacks = ctx.get_option("wait_fallbacks")
+    for _ in range(3):
         assert ctx.plan(g2.inputs).best_index == -1
-    assert (time.perf_counter() - t0) / 5 < 0.05
+    assert ctx.get_option("wait_fallbacks") == fallbacks
     out = ctx.plan(_with_flags(g2.inputs, FLAG_SKIP_COLLISION))
     assert out.best_index >= 0 and out.n_collision == 0
     # error paths: bad range, plan before reference

@@ -51,6 +51,19 @@ def test_sampling_grids_follow_reference_set_order():
         np.testing.assert_array_equal(tl, g["traj_len"])
         np.testing.assert_array_equal(L, g["L"])
         np.testing.assert_array_equal(D, g["D"])
+        # a replacement of a 1-D sample set goes through samples_at_level(), as generate_trajectories_at_level does
+
+        class Halved(VelocitySampling):
+            def samples_at_level(self, sampling_level=0):
+                return set(sorted(super().samples_at_level(sampling_level))[::2])
+        sp.samples_v = Halved(min_v, max(min_v + 5.0, v0 + 2), 4)
+        T2, tl2, L2, D2 = sp.grids_at_level(level, g["x0_lon"], g["x0_lat"], "velocity_keeping")
+        np.testing.assert_array_equal(T2, T)
+        np.testing.assert_array_equal(tl2, tl)
+        np.testing.assert_array_equal(D2, D)
+        assert list(L2) == list(sp.samples_v.samples_at_level(level)) and len(L2) == (len(L) + 1) // 2
+        ref = sp.generate_trajectories_at_level(level, g["x0_lon"], g["x0_lat"], "velocity_keeping", False)
+        assert len(ref) == len(T2) * len(L2) * len(D2)
 
 
 def test_output_packing_paths_agree():
