@@ -675,6 +675,8 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
     bar = Barrier(torch, dist, xdev)
     sync = torch.cuda.synchronize
     ctx = RpContext(local_rank)
+    from commonroad_rp_amd.distributed import wait_mode_for_group, local_world_size, cpu_quota
+    ctx.set_wait_mode(wait_mode_for_group(local_world_size(dist)))   # (yield between polls of the completion ticket when ranks outnumber CPUs / 2)
 
     def bcast(obj):
         box = [obj]
@@ -777,7 +779,7 @@ def run_multi(args, torch, dist, rank, local_rank, world, rehearse):
         ones = torch.ones(1, dtype=torch.int32, device=device)
         dist.all_reduce(ones)
         rccl_ranks = int(ones.item())
-    ctx_wait_mode = ctx.wait_mode_name() if hasattr(ctx, "wait_mode_name") else "spin"
+    ctx_wait_mode = ctx.wait_mode_name() + " (cpu quota %s, affinity %d)" % cpu_quota()
     ctx.close()
     # ---- ReactivePlanner.plan() with the planner's process group set: the sharding decision, the shard's rp_plan and the winner
     #      exchange all happen inside plan() (every rank drives the same closed loop on the strong-scaling workload)
@@ -848,18 +850,9 @@ def sharded_plan_latency(w, dist, xdev, local_rank, transport, n_replans=60, war
 
 
 def cpu_quota():
-    """CPUs the control group of this process may use at a time (cgroup v2 cpu.max / v1 cfs quota), or None without a limit."""
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else max(1, int(round(int(q) / int(per))))
-    except Exception:
-        pass
-    try:
-        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return None if q <= 0 else max(1, int(round(q / per)))
-    except Exception:
-        return None
+    """CPUs the control group of this process may use at a time (cgroup cpu.max / cfs quota), or None without a limit."""
+    from commonroad_rp_amd.distributed import cpu_quota as q
+    return q()[0]
 
 
 # --------------------------------------------------------------------------------------------------------------------

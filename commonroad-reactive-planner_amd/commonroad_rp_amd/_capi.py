@@ -84,6 +84,14 @@ class RpResult(_Sized):
 
 
 assert C.sizeof(RpResult) == 29 * 8 and RpResult.best_index.offset == 8
+
+
+class RpCycle(_Sized):
+    """``rp_cycle``: the inputs and by-products of one replanning cycle (``rp_plan_cycle``)"""
+    _fields_ = [("struct_size", C.c_uint32), ("have_curvilinear", C.c_int32), ("prev_low_vel_mode", C.c_int32), ("low_vel_mode", C.c_int32),
+                ("level", C.c_int32), ("reserved_", C.c_int32),
+                ("x", C.c_double), ("y", C.c_double), ("orientation", C.c_double), ("velocity", C.c_double), ("acceleration", C.c_double),
+                ("steering_angle", C.c_double), ("low_vel_mode_threshold", C.c_double), ("x0_lon", C.c_double * 3), ("x0_lat", C.c_double * 3)]
 _DP = C.POINTER(C.c_double)
 
 
@@ -244,6 +252,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "rp_plan_levels": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.c_uint32, C.POINTER(RpResult),
                                      C.c_void_p, ip]),
         "rp_last_level": (C.c_int, [ctx]),
+        "rp_plan_cycle": (C.c_int, [ctx, C.POINTER(RpCycle), C.POINTER(RpParams), C.POINTER(RpCost), C.c_int32, C.POINTER(RpGrids), C.POINTER(RpResult),
+                                    C.c_void_p]),
         "rp_pack_trajectory": (C.c_int, [C.c_int32, dp, C.c_double, C.c_double, C.c_double, dp]),
         "rp_fast_buffer": (C.c_int, [ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
         "rp_plan_coeffs": (C.c_int, [ctx, C.POINTER(RpParams), C.POINTER(RpCost), C.c_int64, dp, dp, dp, ip, C.c_int64, ip, ip,
@@ -290,11 +300,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     return lib
 
 
-_OPTIONAL_IN_AB_BUILDS = ("rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_kernel", "rp_plan_levels", "rp_last_level", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
+_OPTIONAL_IN_AB_BUILDS = ("rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_kernel", "rp_plan_levels", "rp_last_level", "rp_plan_cycle", "rp_set_collision_path", "rp_last_path", "rp_source_hash", "rp_plan_wait", "rp_pack_trajectory", "rp_pyset_order",
                           "rp_corridor_coeffs", "rp_fast_buffer", "rp_coeffs_arena", "rp_coeffs_arena_groups",
                           "rp_corridor_coeffs_grouped")
 EXPORTED_SYMBOLS = ("rp_abi_version", "rp_source_hash", "rp_create", "rp_destroy", "rp_last_error", "rp_set_profiling", "rp_set_wait_mode", "rp_get_wait_mode", "rp_set_option", "rp_get_option", "rp_last_path", "rp_last_kernel", "rp_set_collision_path",
-                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_wait", "rp_plan_levels", "rp_last_level", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_fetch_status",
+                    "rp_set_reference", "rp_set_obstacles", "rp_plan", "rp_plan_wait", "rp_plan_levels", "rp_last_level", "rp_plan_cycle", "rp_pack_trajectory", "rp_fast_buffer", "rp_plan_coeffs", "rp_coeffs_arena", "rp_coeffs_arena_groups", "rp_fetch_status",
                     "rp_fetch_states", "rp_eval_one", "rp_count_collisions_before", "rp_select",
                     "rp_cost_range", "rp_check_swept", "rp_pyset_order", "rp_corridor_coeffs", "rp_corridor_coeffs_grouped", "rp_build_reference", "rp_project", "rp_initial_state", "rp_result_device", "rp_combine_results", "rp_mailbox_bytes", "rp_mailbox_exchange", "rp_mailbox_sum",
                     "rp_mailbox_set_timeout", "rp_mailbox_stalled_rank")
@@ -624,6 +634,7 @@ class RpContext:
         if not (same and last[3] is D and not D.flags.writeable):
             f64v[nT + nL:nd] = D
         self._fast_last = ((nT, nL, nD), T, L, D, traj_len)
+        self._cycle_last = None
         n = params.N + 1
         raw, out = self._packed_out(n)
         res = self._res
@@ -675,6 +686,7 @@ class RpContext:
             gk.nT, gk.nL, gk.nD = nT, nL, nD
             at += words
         self._fast_last = None   # (the buffer no longer holds what plan_packed left there)
+        self._cycle_last = None
         n = params.N + 1
         raw, out = self._packed_out(n)
         res, lvl = self._res, self._lvl_out
@@ -688,6 +700,71 @@ class RpContext:
         if res.best_index < 0:
             return res, lvl.value, None, None
         return res, lvl.value, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
+
+    def plan_cycle(self, cycle: RpCycle, params: RpParams, cost: RpCost, levels):
+        """``rp_plan_cycle``: one foreign call per replanning cycle.  ``levels``: [(T, traj_len, L, Dlin), ...] -- per level the
+        time samples, the longitudinal samples (set order, unfiltered) and the INSERTION sequence of the lateral sample set
+        (``np.linspace(d_min, d_max, n)``); the call appends the current lateral offset the way ``set.union`` does, filters goals
+        behind the vehicle in stopping mode, works the initial state out if ``cycle.have_curvilinear`` is 0, runs the level loop and
+        packs the output -> (result struct, state block [14, N + 1], packed output [N + 1, 13]) (``None``, ``None`` without a
+        winner); ``cycle.level`` / ``.low_vel_mode`` / ``.x0_lon`` / ``.x0_lat`` are filled in.  Arrays that are the same read-only
+        objects at the same place as in the previous call are not staged again."""
+        fb = getattr(self, "_fast", None)
+        if fb is None:
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
+            raw = (C.c_char * nbytes.value).from_address(ptr.value)
+            fb = self._fast = (np.frombuffer(raw, dtype=np.float64), np.frombuffer(raw, dtype=np.int32), self._lib.rp_plan)
+            self._fast_dims = RpGrids()
+        f64v, i32v = fb[0], fb[1]
+        nlev = len(levels)
+        dims = getattr(self, "_lvl_dims", None)
+        if dims is None or len(dims) < nlev:
+            dims = self._lvl_dims = (RpGrids * max(nlev, 8))()
+            for g_ in dims:
+                g_.struct_size = C.sizeof(RpGrids)
+            self._lvl_out = C.c_int32(0)
+        last = self.__dict__.get("_cycle_last")
+        same_shape = last is not None and len(last) == nlev
+        at = 0
+        held = []
+        for k, (T, traj_len, L, D) in enumerate(levels):
+            nT, nL, nD = len(T), len(L), len(D)
+            nd = nT + nL + nD
+            words = nd + (nT + 1) // 2
+            if (at + words) * 8 > f64v.nbytes:
+                raise RpError("plan_cycle: grids larger than the context's buffer")
+            lk = last[k] if same_shape else None
+            keep = lk is not None and lk[0] == (at, nT, nL, nD)
+            if not (keep and lk[1] is T and lk[4] is traj_len and not T.flags.writeable and not traj_len.flags.writeable):
+                f64v[at:at + nT] = T
+                i32v[2 * (at + nd):2 * (at + nd) + nT] = traj_len
+            if not (keep and lk[2] is L and not L.flags.writeable):
+                f64v[at + nT:at + nT + nL] = L
+            if not (keep and lk[3] is D and not D.flags.writeable):
+                f64v[at + nT + nL:at + nd] = D
+            if not keep:
+                gk = dims[k]
+                gk.nT, gk.nL, gk.nD = nT, nL, nD
+            held.append(((at, nT, nL, nD), T, L, D, traj_len))
+            at += words
+        self._cycle_last = held
+        self._fast_last = None   # (the buffer no longer holds what plan_packed left there)
+        n = params.N + 1
+        raw, out = self._packed_out(n)
+        res = self._res
+        rc = self._lib.rp_plan_cycle(self._h, cycle, params, cost, nlev, dims, res, raw)
+        if rc != 0:
+            if rc in (E_DOMAIN, E_DIRECTION):
+                return rc, None, None
+            self._check(rc, "rp_plan_cycle")
+        self._N = n - 1
+        self._last_count = res.n_candidates
+        self._serial += 1
+        self._last_best = None
+        if res.best_index < 0:
+            return res, None, None
+        return res, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
 
     def plan_levels_begin(self, params: RpParams, cost: RpCost, levels, want_best_states: bool = True):
         """First half of ``rp_plan_levels`` (collected by ``plan_wait``, which then also reports ``last_level()``)."""

@@ -223,6 +223,15 @@ def same_host(dist) -> bool:
     return all(nm == names[0] for nm in names)
 
 
+def local_world_size(dist) -> int:
+    """ranks of the default group that run on THIS host (they share its CPUs)"""
+    import socket
+    names = [None] * dist.get_world_size()
+    me = socket.gethostname()
+    dist.all_gather_object(names, me)
+    return sum(1 for nm in names if nm == me)
+
+
 class _DeviceBlock:
     """A device address range as an object ``torch.as_tensor`` can alias (``__cuda_array_interface__``, float64 words)."""
 
@@ -321,6 +330,42 @@ def exchange_winner(ctx, out: PlanOutput, dist, device, transport: str = "auto")
     The choice is collective on first use (all ranks must pass the same value)."""
     n = (out.best_states.shape[1] if out.best_states is not None else ctx._N + 1)
     return make_exchange(dist, device, n, transport)(ctx, out)
+
+
+def cpu_quota():
+    """CPUs the control group of this process may use at a time (cgroup v2 cpu.max / v1 cfs quota) -- ``None`` without a limit --
+    and the size of its affinity mask."""
+    import os
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else max(1, int(round(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else max(1, int(round(q / per)))
+        except Exception:
+            quota = None
+    try:
+        affinity = max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        affinity = max(1, os.cpu_count() or 1)
+    return quota, affinity
+
+
+def wait_mode_for_group(local_world: int) -> int:
+    """How the ranks of one node should wait for their plans (``rp_set_wait_mode``): every rank's host thread polls the completion
+    ticket of its plan -- a busy core per rank -- which is fine while there are two CPUs per rank (one for the poll, one for the
+    binding and the exchange); with fewer (eight ranks under a 16-CPU quota is the edge) the polls give their core away between
+    looks (``WAIT_YIELD``).  ``RP_AMD_WAIT_MODE`` in the environment overrides (read by rp_create)."""
+    import os
+    from . import _capi
+    if os.environ.get("RP_AMD_WAIT_MODE"):
+        return int(os.environ["RP_AMD_WAIT_MODE"])
+    quota, affinity = cpu_quota()
+    cpus = min(quota, affinity) if quota else affinity
+    return _capi.WAIT_YIELD if cpus < 2 * max(1, int(local_world)) else _capi.WAIT_SPIN
 
 
 def make_exchange(dist, device, n: int, transport: str = "auto"):

@@ -45,6 +45,7 @@ from .trajectories import (CartesianSample, CurviLinearSample, FeasibilityStatus
                            label_from_status)
 
 logger = logging.getLogger("RP_LOGGER")
+_ZERO3 = (0.0, 0.0, 0.0)
 
 
 class _CostView:
@@ -236,6 +237,12 @@ class GpuBackendMixin:
         self.shard_transport = transport
         if min_candidates is not None:
             self.shard_min_candidates = int(min_candidates)
+        if dist is not None and dist.get_world_size() > 1:
+            # (ranks of one node share its CPUs: distributed.wait_mode_for_group -- yield between polls when there are fewer than two per rank)
+            from .distributed import wait_mode_for_group, local_world_size
+            ctx = self._gpu_ctx() if self._co is not None else None
+            if ctx is not None and hasattr(ctx, "set_wait_mode"):
+                ctx.set_wait_mode(wait_mode_for_group(local_world_size(dist)))
 
     def _shard_world(self, n_candidates: int, grid_plan: bool, external: bool) -> int:
         """Ranks this level is sharded over (1: not sharded).  The same decision on every rank: it depends on the inputs only."""
@@ -760,20 +767,25 @@ class ReactivePlanner(GpuBackendMixin):
         start = time.time()
         assert self.x_0 is not None, "<ReactivePlanner.plan(): Planner Cartesian initial state is empty!>"
         assert self._co is not None, "<ReactivePlanner.plan(): No coordinate system given. Call set_reference_path()>"
-        if not self.x_0_cl:
-            self.x_0_cl = self._compute_initial_states(self.x_0)
-        assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
-        x_0_lon, x_0_lat = self.x_0_cl
-        self._low_vel_mode = bool(self.x_0.velocity < self.config.planning.low_vel_mode_threshold)
         optimal, bundle = None, None
         i = 1 if current_sampling_level is None else current_sampling_level
+        prev_low = self._low_vel_mode
         if self._fast_path_ok():
-            result = self._plan_fast(x_0_lon, x_0_lat, i, current_sampling_level is not None)
+            # (one foreign call per cycle -- rp_plan_cycle -- where the context has it: a missing curvilinear state is then worked
+            #  out inside that call, with the low-velocity flag of the previous cycle, as below)
+            x_0_lon, x_0_lat = self.x_0_cl if self.x_0_cl else (None, None)
+            result = self._plan_fast(x_0_lon, x_0_lat, i, current_sampling_level is not None, prev_low)
             if result is not NotImplemented:
                 self._planning_times_list.append(time.time() - start)
                 if result is None:
                     logger.warning("Planner failed to find an optimal trajectory with given sampling configuration!")
                 return result
+            self._low_vel_mode = prev_low
+        if not self.x_0_cl:
+            self.x_0_cl = self._compute_initial_states(self.x_0)
+        assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
+        x_0_lon, x_0_lat = self.x_0_cl
+        self._low_vel_mode = bool(self.x_0.velocity < self.config.planning.low_vel_mode_threshold)
         while optimal is None and i < self.sampling_level:
             bundle = self._create_trajectory_bundle(x_0_lon, x_0_lat, samp_level=i)
             optimal = self._get_optimal_trajectory(bundle)
@@ -821,8 +833,10 @@ class ReactivePlanner(GpuBackendMixin):
     #:   "sequential" one call per level.
     level_policy = "adaptive"
     LEVEL_CHAIN_CYCLES = 16
+    #: ``rp_plan_cycle`` for every cycle of the fast path, not only for those that start from a Cartesian state (tests, measurements)
+    always_plan_cycle = False
 
-    def _plan_fast(self, x_0_lon, x_0_lat, level: int, single_level: bool):
+    def _plan_fast(self, x_0_lon, x_0_lat, level: int, single_level: bool, prev_low_vel_mode: bool = False):
         """The level loop of ``plan()`` (reactive_planner.py:616-636) on the arrays themselves: grids -> ``rp_plan_levels`` (or
         ``rp_plan_packed`` for one level) -> counters, the output packing of :514-568 done in the same call.  Which levels travel
         together: ``level_policy``.  Same results, same counters as the general loop (tests/test_planner_mirror.py runs both)."""
@@ -831,8 +845,37 @@ class ReactivePlanner(GpuBackendMixin):
             return NotImplemented
         ctx = self._gpu_ctx()
         sp, mode = self.sampling_space, self.config.sampling.longitudinal_mode
-        params = self._gpu_params(x_0_lon, x_0_lat, 0)
         hook = self.on_device_launched
+        x0 = self.x_0
+        # rp_plan_cycle: initial state (if missing), low-velocity flag, the lateral samples' union with the current offset, the level
+        # loop and the output packing in ONE foreign call
+        # -- for the cycles that START FROM A CARTESIAN STATE: there the separate path pays a second foreign call with five table
+        # arguments (rp_initial_state).  With the curvilinear state at hand (every cycle of a closed loop but the first: reset() gets
+        # it from the last trajectory) the separate calls below are the faster Python (profiles/r05_plan_latency.txt: cfg2 p50 43.2
+        # vs 47.3 us -- filling the cycle struct through ctypes costs more than the set union it saves).
+        cyc = None
+        plan_cycle = getattr(ctx, "plan_cycle", None) if (hook is None and (x_0_lon is None or self.always_plan_cycle)) else None
+        if plan_cycle is not None and getattr(sp, "cycle_ok", None) is not None and sp.cycle_ok():
+            cyc = self.__dict__.get("_rp_cycle")
+            if cyc is None:
+                cyc = self._rp_cycle = _capi.RpCycle()
+            cyc.prev_low_vel_mode = 1 if prev_low_vel_mode else 0
+            cyc.x, cyc.y = x0.position[0], x0.position[1]
+            cyc.orientation, cyc.velocity = x0.orientation, x0.velocity
+            cyc.acceleration, cyc.steering_angle = x0.acceleration or 0.0, x0.steering_angle or 0.0
+            cyc.low_vel_mode_threshold = self.config.planning.low_vel_mode_threshold
+            if x_0_lon is None:
+                cyc.have_curvilinear = 0
+            else:
+                cyc.have_curvilinear = 1
+                cyc.x0_lon[0], cyc.x0_lon[1], cyc.x0_lon[2] = x_0_lon
+                cyc.x0_lat[0], cyc.x0_lat[1], cyc.x0_lat[2] = x_0_lat
+        elif x_0_lon is None:
+            self.x_0_cl = self._compute_initial_states(x0)
+            assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
+            x_0_lon, x_0_lat = self.x_0_cl
+        self._low_vel_mode = bool(x0.velocity < self.config.planning.low_vel_mode_threshold)
+        params = self._gpu_params(x_0_lon if x_0_lon is not None else _ZERO3, x_0_lat if x_0_lat is not None else _ZERO3, 0)
         stop = min(level + 1, self.sampling_level) if single_level else self.sampling_level
         self._reset_statistics()
         if level >= stop:
@@ -846,6 +889,32 @@ class ReactivePlanner(GpuBackendMixin):
             # the levels of this call: all that are left, or the next one alone
             upto = stop if (whole or (policy == "adaptive" and level > first)) else level + 1
             many = upto - level > 1
+            if cyc is not None:
+                levels = [sp.cycle_level(k, mode) for k in range(level, upto)]
+                if any(lv is None for lv in levels):
+                    cyc = None   # (a lateral sample set that is not the level's linspace: the general path from here on)
+                    if x_0_lon is None:
+                        self.x_0_cl = self._compute_initial_states(x0)
+                        x_0_lon, x_0_lat = self.x_0_cl
+                        params = self._gpu_params(x_0_lon, x_0_lat, 0)
+                else:
+                    res, blk, buf = plan_cycle(cyc, params, cost, levels)
+                    if type(res) is int:   # the initial state could not be worked out: as _compute_initial_states raises
+                        if res == _capi.E_DOMAIN:
+                            logger.critical("Initial state could not be transformed.")
+                            raise ValueError("Initial state could not be transformed.")
+                        raise Exception("Initial state or reference incorrect! The longitudinal velocity along the reference path is negative: "
+                                        "the ego vehicle does not drive in the direction of the reference path")
+                    if cyc.have_curvilinear == 0:
+                        x_0_lon, x_0_lat = list(cyc.x0_lon), list(cyc.x0_lat)
+                        self.x_0_cl = (x_0_lon, x_0_lat)
+                        cyc.have_curvilinear = 1
+                        if not self.always_plan_cycle:   # (levels still to come go through the separate calls: the state is at hand now)
+                            cyc = None
+                            params = self._gpu_params(x_0_lon, x_0_lat, 0)
+                    decided = level + self._rp_cycle.level
+                    level = upto
+                    continue
             levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)] if many else \
                 (sp.grids_at_level(level, x_0_lon, x_0_lat, mode),)
             packed = getattr(ctx, "plan_levels_packed" if many else "plan_packed", None) if hook is None else None

@@ -152,6 +152,42 @@ class FixedIntervalSampling(SamplingSpace):
             D = np.fromiter(u, np.float64, len(u))
         return T, traj_len, L, D
 
+    # ---- the same for ``rp_plan_cycle``: what does NOT depend on the vehicle's state ------------------------------------------
+    def cycle_ok(self) -> bool:
+        """the 1-D sample sets are this package's own (their sets are what ``_sample`` made of low / up / level)"""
+        return (type(self.samples_t) is TimeSampling and type(self.samples_v) is VelocitySampling and type(self.samples_d) is PositionSampling
+                and type(self.samples_s) is PositionSampling)
+
+    def cycle_level(self, level_sampling: int, longitudinal_mode: str):
+        """(T, traj_len, L, Dlin) of a level for ``rp_plan_cycle``: time samples and longitudinal samples in set order (unfiltered:
+        the call drops goals behind the vehicle itself), and the INSERTION sequence of the lateral sample set --
+        ``np.linspace(low, up, n)``, sampling.py:95-99 -- from which the call forms ``set(..).union({d0})``; ``None`` when the
+        level's lateral set is not that (someone replaced it): the caller takes the general path."""
+        t_set = self.samples_t._dict_level_to_sample_set[level_sampling]
+        hit = self.__dict__.get("_t_cache", _EMPTY).get(id(t_set))
+        if hit is not None and hit[0] is t_set and len(hit[1]) == len(t_set):
+            T, traj_len = hit[1], hit[2]
+        else:
+            T, traj_len = self._cached_T(t_set)
+        src = self.samples_v if longitudinal_mode == "velocity_keeping" else self.samples_s
+        L = self._cached_array(src._dict_level_to_sample_set[level_sampling])
+        d_set = self.samples_d._dict_level_to_sample_set[level_sampling]
+        cache = self.__dict__.setdefault("_dlin_cache", {})
+        hd = cache.get(id(d_set))
+        if hd is None or hd[0] is not d_set:
+            if len(cache) > 64:
+                cache.clear()
+            n = 3
+            for _ in range(level_sampling):
+                n = (n * 2) - 1
+            lin = np.linspace(self.samples_d.low, self.samples_d.up, n)
+            ok = set(lin) == d_set and list(set(lin)) == list(d_set)
+            lin.flags.writeable = False
+            hd = cache[id(d_set)] = (d_set, lin if ok else None)
+        if hd[1] is None:
+            return None
+        return T, traj_len, L, hd[1]
+
     def _grids_via_interface(self, level_sampling: int, x_0_lon, x_0_lat, longitudinal_mode: str):
         """``grids_at_level`` through ``samples_at_level()`` of whatever objects hold the 1-D sample sets (no caches, no private fields)."""
         t_set = self.samples_t.samples_at_level(level_sampling)

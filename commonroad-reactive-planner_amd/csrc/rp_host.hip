@@ -139,6 +139,8 @@ struct rp_ctx {
     double bucket_inv_h = 0.0;
     double proj_d_limit = 20.0;
     std::vector<double> h_pos;    // host copy of ref_pos (table window of the single-launch variant)
+    rpfe::Tables h_front;         // host copy of the reference path and its tables (rp_plan_cycle: initial state of a Cartesian state)
+    std::vector<double> cycle_buf;   // rp_plan_cycle: the grids of the cycle's levels as handed to the level loop
     // obstacles
     double *d_sobb = nullptr, *d_tri = nullptr, *d_circ = nullptr, *d_dyn = nullptr, *d_clus = nullptr, *d_slot = nullptr;
     // uniform grid over the static shapes, built for the ego radius of the plans (ensure_static_grid)
@@ -1490,6 +1492,10 @@ int rp_set_reference(rp_ctx *c, int32_t n, const double *ref_pos, const double *
     c->n_buckets = nb;
     c->bucket_inv_h = 1.0 / hmin;
     c->h_pos.assign(ref_pos, ref_pos + n);
+    c->h_front.ref.resize((size_t)n);
+    for (int i = 0; i < n; ++i) c->h_front.ref[(size_t)i] = {ref_x[i], ref_y[i]};
+    c->h_front.pos.assign(ref_pos, ref_pos + n); c->h_front.theta.assign(ref_theta, ref_theta + n);
+    c->h_front.curv.assign(ref_curv, ref_curv + n); c->h_front.curv_d.assign(ref_curv_d, ref_curv_d + n);
     c->table_words = (int)t.size();
     c->n_ref = n;
     c->proj_d_limit = proj_domain_d_limit;
@@ -2054,6 +2060,65 @@ int rp_plan_levels(rp_ctx *c, const rp_params *p, const rp_cost *cost, int32_t n
     if (rc != RP_OK || !(flags & RP_PLAN_PACKED) || result->best_index < 0) return rc;
     const int n = p->N + 1;
     return rp_pack_trajectory(n, out, p->dt, p->wheelbase, p->x0_orientation, out + (size_t)RP_N_ARRAYS * n);
+}
+
+int rp_plan_cycle(rp_ctx *c, rp_cycle *cy, const rp_params *tmpl, const rp_cost *cost, int32_t n_levels, const rp_grids *dims, rp_result *result,
+                  double *out) {
+    if (!c) return RP_EINVAL;
+    if (!cy || !tmpl || !cost || !dims || !result || !out) return fail(c, RP_EINVAL, "rp_plan_cycle: null argument");
+    if (cy->struct_size != sizeof(rp_cycle)) return fail(c, RP_EABI, "rp_plan_cycle: rp_cycle.struct_size is not this library's");
+    if (n_levels < 1 || n_levels > 64) return fail(c, RP_EINVAL, "rp_plan_cycle: need 1 .. 64 levels");
+    int rc = validate(c, tmpl, cost, result);
+    if (rc != RP_OK) return rc;
+    rp_params p = *tmpl;
+    // 1. curvilinear initial state
+    if (!cy->have_curvilinear) {
+        const rpfe::Tables &tb = c->h_front;
+        double s = 0.0, d = 0.0;
+        if (!rpfe::project(tb.ref, tb.pos, c->proj_d_limit, cy->x, cy->y, s, d)) return fail(c, RP_EDOMAIN, "rp_plan_cycle: initial state outside the projection domain");
+        if (rpfe::initial_state(tb, s, d, cy->orientation, cy->velocity, cy->acceleration, cy->steering_angle, p.wheelbase, cy->prev_low_vel_mode != 0,
+                                cy->x0_lon, cy->x0_lat) != 0)
+            return fail(c, RP_EDIRECTION, "rp_plan_cycle: negative longitudinal velocity along the reference path");
+    }
+    // 2. low-velocity mode of this cycle
+    cy->low_vel_mode = cy->velocity < cy->low_vel_mode_threshold ? 1 : 0;
+    p.low_vel_mode = cy->low_vel_mode;
+    for (int k = 0; k < 3; ++k) { p.x0_lon[k] = cy->x0_lon[k]; p.x0_lat[k] = cy->x0_lat[k]; }
+    p.x0_orientation = cy->orientation;
+    // 3. the grids of the levels
+    rp_grids staged[64], g[64];
+    if ((rc = packed_grids(c, n_levels, dims, staged)) != RP_OK) return rc;
+    size_t words = 0;
+    for (int k = 0; k < n_levels; ++k) words += (size_t)staged[k].nT * 2 + (size_t)staged[k].nL + (size_t)staged[k].nD + 2;
+    if (c->cycle_buf.size() < words) c->cycle_buf.assign(words + 64, 0.0);
+    double *w = c->cycle_buf.data();
+    std::vector<double> dvals;
+    for (int k = 0; k < n_levels; ++k) {
+        const rp_grids &sg = staged[k];
+        g[k].struct_size = (uint32_t)sizeof(rp_grids);
+        g[k].nT = sg.nT;
+        g[k].T = w;
+        std::memcpy(w, sg.T, sizeof(double) * (size_t)sg.nT); w += sg.nT;
+        g[k].traj_len = reinterpret_cast<const int32_t *>(w);
+        std::memcpy(w, sg.traj_len, sizeof(int32_t) * (size_t)sg.nT); w += ((size_t)sg.nT + 1) / 2;
+        g[k].L = w;
+        int nL = 0;
+        for (int i = 0; i < sg.nL; ++i)   // stopping mode: goals behind the vehicle are no candidates (trajectories.py:545-550)
+            if (p.lon_mode != RP_LON_STOPPING || sg.L[i] > cy->x0_lon[0]) w[nL++] = sg.L[i];
+        g[k].nL = nL; w += nL;
+        dvals.clear();
+        rpco::PySetF64::from_values(sg.D, sg.nD).union_with(&cy->x0_lat[0], 1).values(dvals);   // sampling.py:226
+        g[k].D = w; g[k].nD = (int32_t)dvals.size();
+        std::memcpy(w, dvals.data(), sizeof(double) * dvals.size()); w += dvals.size();
+    }
+    // 4. the level loop, the output packing (one level: a plan on its own -- no copy of the inputs for levels behind a chain)
+    rc = n_levels == 1 ? plan_begin(c, &p, cost, &g[0], 0, -1, 1) : plan_levels_begin(c, &p, cost, n_levels, g, 1);
+    if (rc == RP_OK) rc = rp_plan_wait(c, result, out);
+    if (rc != RP_OK) return rc;
+    cy->level = c->last_level;
+    if (result->best_index < 0) return RP_OK;
+    const int n = p.N + 1;
+    return rp_pack_trajectory(n, out, p.dt, p.wheelbase, p.x0_orientation, out + (size_t)RP_N_ARRAYS * n);
 }
 
 int rp_coeffs_arena(rp_ctx *c, int64_t cap, double **lon_coeffs, double **lat_coeffs, int32_t **traj_len) {

@@ -295,6 +295,36 @@ int rp_coeffs_arena(rp_ctx *ctx, int64_t cap, double **lon_coeffs, double **lat_
    every group (rp_corridor_coeffs_grouped writes them, rp_plan_coeffs reads them). */
 int rp_coeffs_arena_groups(rp_ctx *ctx, int32_t **group, int32_t **group_first);
 
+/* ONE call per replanning cycle (round 5): what ReactivePlanner.plan() does between its entry and the optimal trajectory
+ * (commonroad_rp/reactive_planner.py:570-665) for the standard sampling space, so that a binding makes one foreign call per cycle:
+ *   1. the curvilinear initial state: taken from `cycle` (reset() was handed it, :586-588 skipped) or worked out from the Cartesian
+ *      state (_compute_initial_states, :446-512 -- rp_initial_state on the tables of rp_set_reference) with the low-velocity flag of
+ *      the PREVIOUS cycle (`prev_low_vel_mode`: the reference sets the flag of this cycle only afterwards, :594);
+ *   2. low_vel_mode = velocity < low_vel_mode_threshold (:594);
+ *   3. the grids of the levels: T, longitudinal samples and traj_len as staged by the caller in the context's buffer (rp_fast_buffer,
+ *      layout of RP_PLAN_PACKED: per level [T | L | D | traj_len]); the lateral samples D there are the INSERTION sequence of the
+ *      level's set -- np.linspace(d_min, d_max, n), sampling.py:95-99 -- and the call appends the current offset x0_lat[0] the way
+ *      `samples_d.union({x_0_lat[0]})` does (sampling.py:226: iteration order of a CPython set, csrc/rp_corridor.h); in stopping
+ *      mode longitudinal samples that are not ahead of the vehicle are dropped (filter_goals_behind, trajectories.py:545-550);
+ *   4. the level loop (rp_plan_levels) and the output packing (rp_pack_trajectory) -- `out` as for RP_PLAN_PACKED.
+ * `params` is the template of the cycle: everything but x0_lon, x0_lat, x0_orientation and low_vel_mode, which the call fills in.
+ * Errors of step 1: RP_EDOMAIN / RP_EDIRECTION (as rp_initial_state). */
+typedef struct rp_cycle {
+    uint32_t struct_size;        /* sizeof(rp_cycle) */
+    int32_t have_curvilinear;    /* in: 1 = x0_lon / x0_lat below are the state; 0 = from the Cartesian state */
+    int32_t prev_low_vel_mode;   /* in: the planner's low-velocity flag before this cycle (step 1) */
+    int32_t low_vel_mode;        /* out */
+    int32_t level;               /* out: index (into dims) of the level the result belongs to */
+    int32_t reserved_;
+    double x, y, orientation, velocity, acceleration, steering_angle;   /* in: x_0 (rear axle) */
+    double low_vel_mode_threshold;                                     /* in: planning.low_vel_mode_threshold */
+    double x0_lon[3], x0_lat[3];                                        /* in (have_curvilinear) / out */
+} rp_cycle;
+#define RP_CYCLE_INIT {(uint32_t)sizeof(rp_cycle)}
+int rp_plan_cycle(rp_ctx *ctx, rp_cycle *cycle, const rp_params *params, const rp_cost *cost, int32_t n_levels,
+                  const rp_grids *dims /* [n_levels]: sizes of the staged arrays */, rp_result *result,
+                  double *out /* [(RP_N_ARRAYS + 13) * (N + 1)] */);
+
 /* ---- results of the last rp_plan / rp_plan_coeffs on this ctx ---------------------------------- */
 /* How the last plan answered the collision query (reactive_planner.py:1019-1063):
  *   RP_PATH_EAGER          every pose of every candidate inside the evaluation kernel (draw / materialising plans, small

@@ -136,3 +136,53 @@ def test_sweep_takes_over_from_exhausted_lists():
         assert ctx.last_path() == 2 and out2.best_index == out.best_index and out2.n_collision == o.out.n_collision
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["plan_arc_hv_obs", "plan_scurve_lv", "plan_standstill", "plan_all_collide", "plan_arc_stop"])
+def test_plan_cycle_is_the_cycle_of_plan(name):
+    """rp_plan_cycle (one foreign call per replanning cycle: initial state, low-velocity flag, lateral samples + current offset, level
+    loop, output packing) against the same cycle through the separate calls -- with the curvilinear state handed over, and worked
+    out from the Cartesian one inside the call."""
+    from _golden import build_planner_from_plan_golden, compare_plan_result, plan_case_names
+    if name not in plan_case_names():
+        pytest.skip("fixture absent")
+    _capi.set_default_options(None)
+    calls = {"cycle": 0, "packed": 0}
+
+    class Counting(RpContext):
+        def plan_cycle(self, *a, **k):
+            calls["cycle"] += 1
+            return super().plan_cycle(*a, **k)
+
+        def plan_packed(self, *a, **k):
+            calls["packed"] += 1
+            return super().plan_packed(*a, **k)
+
+    class NoCycle(RpContext):
+        plan_cycle = None   # the path of rounds 1-4: separate calls
+
+    rp_a, z = build_planner_from_plan_golden(name, Counting)
+    rp_b, _ = build_planner_from_plan_golden(name, NoCycle)
+    rp_a.always_plan_cycle = True   # (by default only cycles that start from a Cartesian state take it)
+    try:
+        res_a, res_b = rp_a.plan(), rp_b.plan()
+        compare_plan_result(res_a, rp_a, z, 1e-6)
+        compare_plan_result(res_b, rp_b, z, 1e-6)
+        fast = rp_a._fast_path_ok()
+        assert (calls["cycle"] >= 1 and calls["packed"] == 0) or not fast
+        assert rp_a.infeasible_count_kinematics == rp_b.infeasible_count_kinematics and rp_a.infeasible_count_collision == rp_b.infeasible_count_collision
+        # the same cycle from the Cartesian state alone: the curvilinear state comes out of the call, as _compute_initial_states has it
+        x0 = rp_a.x_0
+        want = rp_b._compute_initial_states(x0)
+        for rp in (rp_a, rp_b):
+            rp.reset(initial_state_cart=x0, initial_state_curv=None, collision_checker=rp.collision_checker, coordinate_system=rp.coordinate_system)
+        r2a, r2b = rp_a.plan(), rp_b.plan()
+        np.testing.assert_allclose(np.concatenate(rp_a.x_0_cl), np.concatenate(want), rtol=0, atol=1e-12)
+        assert (r2a is None) == (r2b is None)
+        if r2a is not None:
+            for sa, sb in zip(r2a[0].state_list, r2b[0].state_list):
+                np.testing.assert_allclose(sa.position, sb.position, rtol=0, atol=1e-9)
+                assert sa.time_step == sb.time_step
+            assert r2a[2][1] == r2b[2][1] and r2a[3][1] == r2b[3][1]
+    finally:
+        rp_a.close(); rp_b.close()
