@@ -55,8 +55,8 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0
 FP64_VALU_PEAK_TFLOPS = 78.6  # half the FP32 vector peak of the same table (157.3 TFLOPS): 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2.4 GHz
 # counter files written by profiles/collect_pmc.sh / collect_fp64.sh; every entry names the hash of the sources of the library it
 # was measured on (rp_source_hash): an entry is reported only when that is the library this run has loaded
-PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
-FLOP_FILE = os.path.join(REPO, "profiles", "r04_fp64_flops.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
+FLOP_FILE = os.path.join(REPO, "profiles", "r05_fp64_flops.json")
 
 
 def parse_args():

@@ -6,9 +6,9 @@ import glob
 import os
 import sys
 
-ROUND = "r04"
+ROUND = "r05"
 # the kernels that evaluate a batch (one of them per plan: rp_last_kernel) and the ones around it
-MAIN_KERNELS = ("rp_eval_kernel", "rp_cost_kernel")
+MAIN_KERNELS = ("rp_eval_kernel", "rp_cost_kernel", "rp_chunk_kernel")
 SIDE_KERNELS = ("rp_lon_kernel", "rp_select_kernel", "rp_finalize_kernel")
 
 

@@ -8,7 +8,7 @@ ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 # counters first: the bench line below then carries `traffic` and the FP64 fraction of this very code (bench.py reports the
-# numbers of profiles/r04_*.json only when their source hash is the library's)
+# numbers of profiles/r05_*.json only when their source hash is the library's)
 if [ -z "$QUICK" ]; then
 for wl in cfg1 cfg2 cfg2rb cfg3 cfg3rb cfg3f cfg3frb cfg4 cfg4rb cfg5; do
   steps=20; [ $wl = cfg5 ] && steps=6; [ $wl = cfg4 ] && steps=8; [ $wl = cfg4rb ] && steps=8
@@ -17,11 +17,13 @@ for wl in cfg1 cfg2 cfg2rb cfg3 cfg3rb cfg3f cfg3frb cfg4 cfg4rb cfg5; do
   rm -rf $ROOT/gpurun_out/pmc_${wl}_draw $ROOT/gpurun_out/fp64_${wl}_fused
   echo "$wl counters done"
 done
-cp profiles/r04_pmc_traffic.json profiles/r04_fp64_flops.json $OUT/
+cp profiles/r05_pmc_traffic.json profiles/r05_fp64_flops.json $OUT/
 fi
 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+cp gpurun_out/bench_detail_n1.json $OUT/${TAG}_bench_detail.json
 # cfg2 as the headline workload (the headline of rounds 1-2; carries plan() latency on cfg2)
 python3 bench.py --workload cfg2 --no-configs --no-cpu-baseline > $OUT/${TAG}_bench_cfg2.json 2>> $OUT/bench.err
+cp gpurun_out/bench_detail_n1.json $OUT/${TAG}_bench_cfg2_detail.json
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof.err

@@ -1,8 +1,9 @@
 #!/bin/bash
 # The last act of a round, on the library that is committed: counters + bench + kernel trace (collect_round.sh), then the parity
 # sweeps outside pytest (tests/sweeps/) on the default launch paths and with the cost-ordered stage / rp_cost_kernel forced -- every
-# output names the source hash of the library it ran on.   usage (GPU box): bash profiles/final_pass.sh r04 [quick]
-TAG=${1:-r04}; QUICK=${2:-}
+# output names the source hash of the library it ran on.  (The RP_AMD_* variables are the DEFAULTS rp_create gives a context's options:
+# set for the whole process here.)   usage (GPU box): bash profiles/final_pass.sh r05 [quick]
+TAG=${1:-r05}; QUICK=${2:-}
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
@@ -18,10 +19,14 @@ cd $ROOT
   python3 tests/sweeps/fuzz_parity.py 100000 30000 2>&1 | grep -v amdgpu.ids | tail -1
   echo "cost-ordered stage forced (RP_AMD_NO_FUSED_LON=1 RP_AMD_LAZY=1 RP_AMD_NO_AUTO_MATERIALIZE=1), seeds 130000 .. 139999:"
   RP_AMD_NO_FUSED_LON=1 RP_AMD_LAZY=1 RP_AMD_NO_AUTO_MATERIALIZE=1 python3 tests/sweeps/fuzz_parity.py 130000 10000 2>&1 | grep -v amdgpu.ids | tail -1
-  echo "rp_cost_kernel forced (RP_AMD_NO_FUSED_LON=1 RP_AMD_COST_KERNEL=1 RP_AMD_NO_AUTO_MATERIALIZE=1), seeds 140000 .. 149999:"
-  RP_AMD_NO_FUSED_LON=1 RP_AMD_COST_KERNEL=1 RP_AMD_NO_AUTO_MATERIALIZE=1 python3 tests/sweeps/fuzz_parity.py 140000 10000 2>&1 | grep -v amdgpu.ids | tail -1
-  echo "two-kernel path, 16 lanes, one wavefront per workgroup (RP_AMD_NO_FUSED_LON=1 RP_AMD_G=16 RP_AMD_EVAL_BLOCK=64), seeds 150000 .. 154999:"
-  RP_AMD_NO_FUSED_LON=1 RP_AMD_G=16 RP_AMD_EVAL_BLOCK=64 python3 tests/sweeps/fuzz_parity.py 150000 5000 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "rp_cost_kernel forced (RP_AMD_NO_FUSED_LON=1 RP_AMD_COST_KERNEL=1 RP_AMD_CHUNK_KERNEL=0 RP_AMD_NO_AUTO_MATERIALIZE=1), seeds 140000 .. 144999:"
+  RP_AMD_NO_FUSED_LON=1 RP_AMD_COST_KERNEL=1 RP_AMD_CHUNK_KERNEL=0 RP_AMD_NO_AUTO_MATERIALIZE=1 python3 tests/sweeps/fuzz_parity.py 140000 5000 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "rp_chunk_kernel forced (RP_AMD_NO_FUSED_LON=1 RP_AMD_CHUNK_KERNEL=1 RP_AMD_NO_AUTO_MATERIALIZE=1), seeds 145000 .. 154999:"
+  RP_AMD_NO_FUSED_LON=1 RP_AMD_CHUNK_KERNEL=1 RP_AMD_NO_AUTO_MATERIALIZE=1 python3 tests/sweeps/fuzz_parity.py 145000 10000 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "bounded sweep forced (RP_AMD_NO_FUSED_LON=1 RP_AMD_LAZY=1 RP_AMD_SWEEP=1 RP_AMD_NO_AUTO_MATERIALIZE=1), seeds 155000 .. 159999:"
+  RP_AMD_NO_FUSED_LON=1 RP_AMD_LAZY=1 RP_AMD_SWEEP=1 RP_AMD_NO_AUTO_MATERIALIZE=1 python3 tests/sweeps/fuzz_parity.py 155000 5000 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "two-kernel path, 16 lanes, one wavefront per workgroup (RP_AMD_NO_FUSED_LON=1 RP_AMD_G=16 RP_AMD_EVAL_BLOCK=64 RP_AMD_CHUNK_KERNEL=0), seeds 160000 .. 162999:"
+  RP_AMD_NO_FUSED_LON=1 RP_AMD_G=16 RP_AMD_EVAL_BLOCK=64 RP_AMD_CHUNK_KERNEL=0 python3 tests/sweeps/fuzz_parity.py 160000 3000 2>&1 | grep -v amdgpu.ids | tail -1
 } > $OUT/${TAG}_fuzz_parity.txt 2>&1
 echo "fuzz done"
 {

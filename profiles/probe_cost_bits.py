@@ -9,11 +9,18 @@ ctx = RpContext(0); w.setup(ctx)
 p = copy_params(w.inputs.params); p.flags |= FLAG_SKIP_COLLISION
 inp = PlanInputs(p, w.inputs.cost, w.inputs.T, w.inputs.traj_len, w.inputs.L, w.inputs.D)
 res = {}
-for ck in ("0", "1"):
-    os.environ["RP_AMD_COST_KERNEL"] = ck
+ctx.set_option("fused_lon", 0); ctx.set_option("auto_materialize", 0)
+for ck, opts in (("eval16", {"cost_kernel": 0, "chunk_kernel": 0}), ("lane", {"cost_kernel": 1, "chunk_kernel": 0}), ("chunk", {"cost_kernel": 0, "chunk_kernel": 1})):
+    for k, v in opts.items():
+        ctx.set_option(k, v)
     ctx.plan(inp, want_best_states=False)
-    res[ck] = ctx.fetch_status()
-a, b = res["0"][1], res["1"][1]
+    res[ck] = ctx.fetch_status() + (ctx.last_kernel(),)
+for other in ("lane", "chunk"):
+    a0, b0 = res["eval16"], res[other]
+    okc = ~np.isnan(a0[1])
+    print(f"{sys.argv[1] if len(sys.argv) > 1 else 'cfg4'}: {a0[2]} vs {b0[2]}: candidates with a cost {int(okc.sum())}, cost bits differing "
+          f"{int(np.sum(okc & (a0[1].view(np.uint64) != b0[1].view(np.uint64))))}, status words differing {int(np.sum(a0[0] != b0[0]))}")
+a, b = res["eval16"][1], res["lane"][1]
 ok = ~np.isnan(a)
 diff = np.flatnonzero(ok & (a.view(np.uint64) != b.view(np.uint64)))
 print("candidates with a cost:", ok.sum(), "differing:", len(diff), "max rel", np.max(np.abs(a[diff] - b[diff]) / np.abs(a[diff])) if len(diff) else 0)

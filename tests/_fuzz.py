@@ -135,7 +135,8 @@ def compare(ctx, seed):
         # collision is found at is not part of the reference's result)
         key = lambda w: np.where((w & 3) == 2, w, w & 0xff)
         # (plans that ran the cost-ordered collision stage label the colliding candidates they looked at: _lazy.lazy_relaxed)
-        lazy_run = getattr(ctx, "last_path", lambda: 0)() == 1
+        path = getattr(ctx, "last_path", lambda: 0)()
+        lazy_run = path in (1, 3)   # (list rounds | bounded sweep)
         unlabelled = 0
         if lazy_run:
             try:
@@ -152,7 +153,9 @@ def compare(ctx, seed):
             problems.append(f"{variant}: cost deviation {np.max(np.abs(cs[both] - rc[both]) / np.maximum(1.0, np.abs(rc[both]))):.3g}")
         if out.best_index != ro.best_index:
             problems.append(f"{variant}: winner {out.best_index} want {ro.best_index}")
-        if (out.n_feasible, out.n_collision + unlabelled, out.n_collision_before_best) != (ro.n_feasible, ro.n_collision, ro.n_collision_before_best):
+        # (after a bounded sweep "collisions found" is the count in front of the winner: include/rp_amd.h, RP_PATH_SWEEP)
+        found = ro.n_collision if (path == 3 and out.n_collision == out.n_collision_before_best) else out.n_collision + unlabelled
+        if (out.n_feasible, found, out.n_collision_before_best) != (ro.n_feasible, ro.n_collision, ro.n_collision_before_best):
             problems.append(f"{variant}: counters {(out.n_feasible, out.n_collision, out.n_collision_before_best)} want "
                             f"{(ro.n_feasible, ro.n_collision, ro.n_collision_before_best)}")
         if not np.array_equal(out.reason_counts[:7], ro.reason_counts[:7]):

@@ -3,7 +3,7 @@ import numpy as np
 
 
 def lazy_relaxed(status, cost, orun, ctx, out, lo=0):
-    """Plans that ran the cost-ordered collision stage (rp_last_path() == 1; the reference's own order of work,
+    """Plans that ran the cost-ordered collision stage (rp_last_path() == 1, list rounds, or 3, bounded sweep; the reference's own order of work,
     reactive_planner.py:1031-1062) label the colliding candidates they had to look at: at least every one that sorts before the
     winner.  Returns the device labels with the others marked as the eager query would, and their number -- after checking
     that each of them really sorts behind the winner (and that there is a winner: without one every candidate was looked at)."""

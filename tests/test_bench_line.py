@@ -1,6 +1,6 @@
 """The line ``bench.py`` prints is the record the driver parses out of a 16-KB tail of stdout: it must stay ONE compact JSON object
 (< 4 KB) carrying the contract's keys, ``roofline`` and ``cpu_baseline`` -- round 4's 24-KB line left the driver's record unparsed.
-Input here: the full records of earlier runs (``profiles/r04_bench.json``: the 24-KB N = 1 record itself) pushed through
+Input here: the full records of earlier runs (``profiles/archive/r04_bench.json``: the 24-KB N = 1 record itself) pushed through
 ``bench.compact_line`` / ``bench.emit``; no GPU, no timing."""
 import json
 import os
@@ -18,7 +18,7 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 
 def _full_n1():
-    return json.load(open(os.path.join(REPO, "profiles", "r04_bench.json")))
+    return json.load(open(os.path.join(REPO, "profiles", "archive", "r04_bench.json")))
 
 
 def test_compact_line_of_the_round4_record(tmp_path, monkeypatch):
