@@ -365,6 +365,16 @@ int collision_level(const KArgs &ka) {
     return (ka.obs.n_sobb + ka.obs.n_tri + ka.obs.n_circ) > 0 ? 2 : 1;
 }
 
+// the bounded sweep's variant of rp_eval_kernel by run-time (explicit polynomials, collision level, one step block)
+const void *sweep_kernel_fn(bool cin, int coll, bool one_chunk) {
+    if (cin) {
+        if (coll == 2) return one_chunk ? (const void *)rp_eval_kernel<16, false, true, 2, true, false, false, RP_BLOCK, true> : (const void *)rp_eval_kernel<16, false, true, 2, false, false, false, RP_BLOCK, true>;
+        return one_chunk ? (const void *)rp_eval_kernel<16, false, true, 1, true, false, false, RP_BLOCK, true> : (const void *)rp_eval_kernel<16, false, true, 1, false, false, false, RP_BLOCK, true>;
+    }
+    if (coll == 2) return one_chunk ? (const void *)rp_eval_kernel<16, false, false, 2, true, false, false, RP_BLOCK, true> : (const void *)rp_eval_kernel<16, false, false, 2, false, false, false, RP_BLOCK, true>;
+    return one_chunk ? (const void *)rp_eval_kernel<16, false, false, 1, true, false, false, RP_BLOCK, true> : (const void *)rp_eval_kernel<16, false, false, 1, false, false, false, RP_BLOCK, true>;
+}
+
 // rp_chunk_kernel<LOW, COLL> by run-time (low-velocity mode, collision level)
 const void *chunk_kernel_fn(bool low, int coll) {
     if (low) return coll == 2 ? (const void *)rp_chunk_kernel<true, 2> : (coll == 1 ? (const void *)rp_chunk_kernel<true, 1> : (const void *)rp_chunk_kernel<true, 0>);
@@ -879,7 +889,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     const int grid = fused_lds ? (int)((count + RP_BLOCK / G - 1) / (RP_BLOCK / G)) : eval_grid(c, count, G, block);
     // (rp_cost_kernel / rp_chunk_kernel: one partial per 64 candidates, fewer than the 16-lane kernel's; a bounded sweep keeps its pass 1's
     //  partials behind its own: room for two sets)
-    const int part_grid = 2 * grid + 2;
+    const int part_grid = 2 * std::max(grid, (int)((count + 15) / 16)) + 2;
     if (std::max(part_grid, kLazyCap[RP_LAZY_LEVELS - 1] / (RP_BLOCK / 64)) > c->cap_partials) {
         if (c->d_partials) HIP_TRY(c, hipFree(c->d_partials));
         c->d_partials = nullptr;
@@ -912,6 +922,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
     bool swept = false;       // ... ran as a bounded sweep: the common epilogue picks the winner from the sweep's partials
     int pass1_grid = 0;       //     and takes the batch's counters from its pass 1's (pass1_grid of them, behind the sweep's)
     bool swept_totals = false;   //  ... or from the control block of the list stage the sweep took over from
+    int swept_grid = 0;          //  workgroups (= block partials) of the sweep's launch
     if (c->epilogue_dirty && (!ka.gate || ka.gate_level == 1)) {   // (the last chain of kernels on this context did not reach its result: see rp_ctx::epilogue_dirty)
         HIP_TRY(c, hipMemsetAsync(c->d_sel_scratch, 0, RP_SEL_SCRATCH * sizeof(unsigned long long), c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_lazy_hist, 0, (RP_LAZY_BINS + 1) * sizeof(uint32_t), c->stream));
@@ -968,11 +979,15 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         const int chunk_G = (chunk_nb >= 2 && chunk_nb <= RP_CHUNK_MAX_BLOCKS) ? chunk_nb : 0;
         const bool lane_kernel_ok = count > 0 && !fused_lds && !cin && !(ka.flags & RP_FLAG_DRAW_ALL) && !ka.single_index && !ka.index_list &&
                                     ka.cost_kind != RP_COST_EXTERNAL;
+        // (rp_cost_kernel addresses the profile rows by a 32-bit byte offset from the launch's first pair: below 4 GiB of rows only --
+        //  332 000 pairs at N = 100; beyond, the 16-lane kernel, whose offsets are relative to each wavefront's first pair)
+        const bool cost_rows_ok = (unsigned long long)ka.pair_count * PF_FIELDS * (unsigned long long)(ka.N + 1) * 8ull < (1ull << 32);
         const bool cost_big = count >= (int64_t)c->num_cus * 1024;
         // 0: rp_eval_kernel, 1: rp_cost_kernel, 2: rp_chunk_kernel -- for a launch with collision level `coll`
         auto lane_kernel_for = [&](int coll) -> int {
             if (!lane_kernel_ok) return 0;
             if (c->opt.chunk_kernel == 1 && chunk_G) return 2;
+            if (!cost_rows_ok) return (chunk_G && c->opt.chunk_kernel != 0 && coll == 0) ? 2 : 0;
             if (c->opt.cost_kernel == 1) return 1;
             // WITH the eager query inside the kernel the step blocks of a candidate want to run one after the other -- a candidate that has
             // collided is not asked again, and in traffic most collide early: the 16-lane kernel (cfg3 95 us, chunk 126 us, lane 152 us;
@@ -1062,13 +1077,14 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         const bool sweep_first = lazy_try && c->opt.sweep == 1 && !fused_lds;
         const bool sweep_fallback = lazy_possible && c->opt.sweep != 0 && !fused_lds && !small && count >= (int64_t)c->num_cus * kSweepMinPerCU &&
                                     !c->path_adaptive;
+        const int sweep_grid = eval_grid(c, count, 16, RP_BLOCK);   // the sweep's own variant: 16 lanes per candidate, 256-thread workgroups
         auto launch_sweep = [&](bool pass1) -> int {
             if (pass1) {
                 KArgs k1 = ka;
                 k1.flags |= RP_FLAG_SKIP_COLLISION;
                 k1.states = nullptr;
                 k1.sweep_init = c->d_sweep;
-                k1.partials_first = grid;        // (behind the sweep's own partials)
+                k1.partials_first = sweep_grid;  // (behind the sweep's own partials)
                 const int r1 = launch_main_eval(k1, false);
                 if (r1 != RP_OK) return r1;
                 pass1_grid = main_grid;
@@ -1076,9 +1092,10 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
             KArgs kb = ka;
             kb.states = nullptr;
             kb.sweep_bound = c->d_sweep;
-            launch_eval(c, kb, grid, false, cin, G, block);
-            main_grid = grid;
+            launch_kargs(c, sweep_kernel_fn(cin, collision_level(kb), kb.N + 1 <= 16), sweep_grid, RP_BLOCK, 0, kb);
+            main_grid = sweep_grid;
             swept = true;
+            swept_grid = sweep_grid;
             swept_totals = !pass1;   // (behind exhausted lists: the batch's counters are in the stage's control block, summed from pass 1)
             c->last_lazy = RP_PATH_SWEEP;
             return RP_OK;
@@ -1147,7 +1164,7 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         fa.row_stride = ka.row_stride; fa.tail_split = ka.tail_split; fa.inv_n = (uint32_t)(0x100000000ull / (unsigned long long)n) + 1u;
         fa.scratch = c->d_sel_scratch;
         fa.gate = const_cast<unsigned long long *>(ka.gate); fa.gate_seq = ka.gate_seq; fa.gate_level = ka.gate_level; fa.gate_last = chain_last ? 1 : 0;
-        fa.cnt_first = (swept && !swept_totals) ? grid : 0; fa.n_cnt_partials = (swept && !swept_totals) ? pass1_grid : 0;
+        fa.cnt_first = (swept && !swept_totals) ? swept_grid : 0; fa.n_cnt_partials = (swept && !swept_totals) ? pass1_grid : 0;
         fa.lazy = (swept && swept_totals) ? c->d_lazy_ctl : nullptr;
         if (small && !swept) {   // one workgroup does it all (count of the colliding candidates before the winner included)
             fa.count_inline = 1;

@@ -1694,8 +1694,11 @@ __device__ __forceinline__ CandIn fetch_candidate(const KArgs &a, int64_t gidx, 
 // tables and profile rows, the LDS tile of the staged copy-out; the plain two-kernel variants of LARGE batches run one wavefront
 // per workgroup (BLOCK = 64): a workgroup is placed, and its slot freed, as a whole, and the four wavefronts of a 256-thread
 // workgroup finish far apart (in-kernel stamps on cfg3: the first at 30 k cycles, the workgroup at 42 k).
-template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED, int BLOCK = RP_BLOCK>
+// SWEEP: the bounded collision sweep (KArgs::sweep_bound) -- a variant of its own (16 lanes per candidate, no state rows, two-kernel path):
+// as a run-time switch of the plain variants it cost them two more spilled registers and 3.5 % (cfg3 eager 93.6 -> 97.0 us).
+template <int G, bool MAT, bool COEFFS_IN, int COLL, bool ONE_CHUNK, bool STAGE_OUT, bool LON_FUSED, int BLOCK = RP_BLOCK, bool SWEEP = false>
 __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const KArgsG ag) {
+    static_assert(!SWEEP || (G == 16 && !MAT && COLL != 0 && !STAGE_OUT && !LON_FUSED && BLOCK == RP_BLOCK), "the sweep's variant");
     const KArgs &a = ag.k;
     extern __shared__ double lds_out[];   // STAGE_OUT: [groups per block][14][N+1];  LON_FUSED: tables, profiles, headers, votes
     static_assert(!(LON_FUSED && STAGE_OUT), "the single-launch variant stores state rows directly");
@@ -1745,7 +1748,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
         __hip_atomic_store(a.sweep_init, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // The sweep itself: a lane group evaluates its candidate only if pass 1 left it FEASIBLE and no cheaper free candidate is known; a
     // workgroup none of whose candidates needs that leaves an empty partial and is gone after one round trip.
-    const bool sweep = !LON_FUSED && !MAT && COLL != 0 && a.sweep_bound != nullptr && !a.index_list && !a.single_index;
+    constexpr bool sweep = SWEEP;
     bool sweep_need = true;
     if (sweep) {
         const int64_t sl = wave_first + group_in_wave;
@@ -2686,13 +2689,12 @@ __global__ __launch_bounds__(RP_COST_BLOCK, COLL ? RP_WAVES_PER_SIMD : RP_COST_W
         // last valid state (step L - 1) for the horizon extension (trajectories.py:168-197, 302-332)
         double l_v = 0.0, l_acc = 0.0, l_s = 0.0, l_d = 0.0, l_thcl = 0.0, l_sd = 0.0, l_dd = 0.0;
         double l_x = 0.0, l_y = 0.0, l_cos = 1.0, l_sin = 0.0, cumx = 0.0, cumy = 0.0;   // (COLL: poses of the extended steps)
-        // profile rows: wave-uniform row bases (scalar registers; the block of the wavefront's FIRST pair) + one 32-bit byte offset per
-        // lane (its pair's block behind that one: a wavefront spans at most 64 pairs -- an offset from the batch's first pair would wrap
-        // at 4 GiB of profile rows, 8 192 pairs at N = 4 094)
+        // profile rows: wave-uniform row bases (scalar registers) + one 32-bit byte offset per lane (its pair's block).  (The offset is from
+        // the batch's first pair: the host takes this kernel only while the profile rows of a launch stay below 4 GiB -- cost_rows_ok.
+        // Relative to the wavefront's first pair, as rp_chunk_kernel has it, measured 5 % slower here: cfg5 368 -> 389 us.)
+        const uint32_t voff = (uint32_t)pair_slot * (uint32_t)PF_FIELDS * (uint32_t)n * 8u;
+        const char *const pb = reinterpret_cast<const char *>(a.profile);
         const size_t n8 = (size_t)n * 8;
-        const int32_t pair_w = __builtin_amdgcn_readfirstlane((int32_t)pair_slot);
-        const uint32_t voff = (uint32_t)((int32_t)pair_slot - pair_w) * (uint32_t)PF_FIELDS * (uint32_t)n8;
-        const char *const pb = reinterpret_cast<const char *>(a.profile) + (size_t)pair_w * PF_FIELDS * n8;
 #pragma nounroll
         for (int i = 0; i <= N; ++i) {   // wave-uniform
             const bool act = i < L;
