@@ -85,6 +85,15 @@ class RpResult(_Sized):
 
 assert C.sizeof(RpResult) == 29 * 8 and RpResult.best_index.offset == 8
 
+# The cycle's one foreign call without ctypes (csrc/rp_pyfast.c -> _rpfast.so beside this file; RpContext.plan_packed_fast).  A binding
+# accelerator only: it calls the same rp_plan of the same library; an extension built against another header is not used.
+try:
+    from . import _rpfast
+    if (_rpfast.ABI_VERSION, _rpfast.SIZEOF_PARAMS, _rpfast.SIZEOF_RESULT) != (ABI_VERSION, C.sizeof(RpParams), C.sizeof(RpResult)):
+        _rpfast = None
+except ImportError:
+    _rpfast = None
+
 
 class RpCycle(_Sized):
     """``rp_cycle``: the inputs and by-products of one replanning cycle (``rp_plan_cycle``)"""
@@ -487,12 +496,14 @@ class RpContext:
         self._res = RpResult()    # C result of the last plan / plan_coeffs / select on this context ...
         self._last_best = None    # ... and its winner state block (what the intra-node exchange posts as they are)
         self._serial = 0          # ... and the number of that call (PlanOutput.serial)
+        if _rpfast is None:       # (the extension has not been built: callers ask with getattr(ctx, "plan_packed_fast", None))
+            self.plan_packed_fast = None
 
     def close(self):
         if getattr(self, "_h", None):
             self._lib.rp_destroy(self._h)
             self._h = None
-        self._arena = self._fast = self._fast_last = None   # (views of memory the context owned)
+        self._arena = self._fast = self._fast_last = self._pk = None   # (views of memory the context owned)
 
     def __del__(self):
         try:
@@ -644,6 +655,33 @@ class RpContext:
         rc = call(self._h, params, cost, gd, 0, -1, PLAN_PACKED, res, raw)
         if rc != 0:
             self._check(rc, "rp_plan (packed)")
+        self._N = n - 1
+        self._last_count = res.n_candidates
+        self._serial += 1
+        self._last_best = None
+        if res.best_index < 0:
+            return res, None, None
+        return res, out[:N_ARRAYS], out[N_ARRAYS:].reshape(n, 13)
+
+    def plan_packed_fast(self, params: RpParams, cost: RpCost, T, traj_len, L, D, time_step0, low_vel_mode, flags, x0_lon, x0_lat, orientation):
+        """``plan_packed`` with the cycle's fields of ``params`` (time step, low-velocity flag, flags, curvilinear state, orientation)
+        written, the grids copied and ``rp_plan`` called by the ``_rpfast`` extension (csrc/rp_pyfast.c) instead of through ctypes
+        descriptors, slice assignments and argument marshalling: same call, same results, ~5 us less of Python per replanning cycle
+        (profiles/r05_plan_latency.txt).  ``None`` (the attribute, see ``__init__``) when the extension has not been built."""
+        pk = self.__dict__.get("_pk")
+        if pk is None:
+            if not self._h:
+                raise RpError("plan_packed_fast: the context is closed")
+            ptr, nbytes = C.c_void_p(), C.c_size_t()
+            self._check(self._lib.rp_fast_buffer(self._h, C.byref(ptr), C.byref(nbytes)), "rp_fast_buffer")
+            pk = self._pk = _rpfast.Packed(C.cast(self._lib.rp_plan, C.c_void_p).value, self._h.value, ptr.value, nbytes.value, C.addressof(self._res))
+        n = params.N + 1
+        out = np.empty((N_ARRAYS + 13, n), np.float64)   # (fresh per call: the last cycle's winner may still be referred to)
+        self._fast_last = self._cycle_last = None        # (the buffer no longer holds what the ctypes paths remember of it)
+        rc = pk.plan(params, cost, T, traj_len, L, D, out, time_step0, low_vel_mode, flags, x0_lon, x0_lat, orientation)
+        if rc != 0:
+            self._check(rc, "rp_plan (packed)")
+        res = self._res
         self._N = n - 1
         self._last_count = res.n_candidates
         self._serial += 1

@@ -334,9 +334,10 @@ class GpuBackendMixin:
                 sp.__dict__.pop(key, None)
 
     # ---- per-call inputs ---------------------------------------------------------------------------
-    def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
-        """The ``rp_params`` of this call.  The struct is kept between calls and only what changes from one replanning cycle to
-        the next is written again (filling all 25 fields through ctypes costs more than the rest of the call's set-up)."""
+    def _gpu_params_struct(self):
+        """The ``rp_params`` struct of this call with everything that does NOT change from one replanning cycle to the next filled
+        in.  The struct is kept between calls (filling all 25 fields through ctypes costs more than the rest of the call's set-up);
+        the cycle's own fields are written by ``_gpu_params`` -- or by the call itself (``RpContext.plan_packed_fast``)."""
         cfg, vp = self.config, self.vehicle_params
         key = (id(cfg), id(vp), self.dt, self.N, cfg.planning.factor, cfg.sampling.longitudinal_mode,
                tuple(cfg.planning.constraints_to_check), vp.wheelbase, vp.wb_rear_axle, vp.length, vp.width, vp.a_max,
@@ -355,7 +356,11 @@ class GpuBackendMixin:
         # two structs used in turn (a copy per call costs ~1.5 us): the inputs of the previous plan stay intact while this one
         # runs; whoever keeps inputs longer copies them (workloads.replan_sequence does)
         cached[3][0] ^= 1
-        p = cached[2][cached[3][0]]
+        return cached[2][cached[3][0]]
+
+    def _gpu_params(self, x_0_lon, x_0_lat, flags: int):
+        """The ``rp_params`` of this call: ``_gpu_params_struct`` with the cycle's fields written (reactive_planner.py:586-594)."""
+        p = self._gpu_params_struct()
         p.time_step0 = int(self.x_0.time_step)
         p.low_vel_mode = 1 if self._low_vel_mode else 0
         p.flags = flags
@@ -875,7 +880,7 @@ class ReactivePlanner(GpuBackendMixin):
             assert self.x_0_cl is not None, "<ReactivePlanner.plan(): Planner curvilinear initial state is empty!>"
             x_0_lon, x_0_lat = self.x_0_cl
         self._low_vel_mode = bool(x0.velocity < self.config.planning.low_vel_mode_threshold)
-        params = self._gpu_params(x_0_lon if x_0_lon is not None else _ZERO3, x_0_lat if x_0_lat is not None else _ZERO3, 0)
+        params = None   # (built where a call takes the struct filled in: _gpu_params; the single-level call fills it itself)
         stop = min(level + 1, self.sampling_level) if single_level else self.sampling_level
         self._reset_statistics()
         if level >= stop:
@@ -896,8 +901,10 @@ class ReactivePlanner(GpuBackendMixin):
                     if x_0_lon is None:
                         self.x_0_cl = self._compute_initial_states(x0)
                         x_0_lon, x_0_lat = self.x_0_cl
-                        params = self._gpu_params(x_0_lon, x_0_lat, 0)
+                        params = None
                 else:
+                    if params is None:
+                        params = self._gpu_params(x_0_lon if x_0_lon is not None else _ZERO3, x_0_lat if x_0_lat is not None else _ZERO3, 0)
                     res, blk, buf = plan_cycle(cyc, params, cost, levels)
                     if type(res) is int:   # the initial state could not be worked out: as _compute_initial_states raises
                         if res == _capi.E_DOMAIN:
@@ -911,14 +918,31 @@ class ReactivePlanner(GpuBackendMixin):
                         cyc.have_curvilinear = 1
                         if not self.always_plan_cycle:   # (levels still to come go through the separate calls: the state is at hand now)
                             cyc = None
-                            params = self._gpu_params(x_0_lon, x_0_lat, 0)
+                        params = None
                     decided = level + self._rp_cycle.level
                     level = upto
                     continue
-            levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)] if many else \
-                (sp.grids_at_level(level, x_0_lon, x_0_lat, mode),)
             packed = getattr(ctx, "plan_levels_packed" if many else "plan_packed", None) if hook is None else None
             begin = getattr(ctx, "plan_levels_begin", None) if (hook is not None or (many and packed is None)) else None
+            fastcall = getattr(ctx, "plan_packed_fast", None) if (packed is not None and not many) else None
+            if fastcall is not None:
+                # one level, no hook: the cycle's fields of rp_params, the grids and the call itself in the binding's extension module,
+                # which reads the velocity / lateral sample SETS themselves (no arrays built to be copied)
+                sets = getattr(sp, "grid_sets_at_level", None)
+                g4 = sets(level, x_0_lon, mode) if sets is not None else None
+                T, traj_len, L, D = g4 if g4 is not None else sp.grids_at_level(level, x_0_lon, x_0_lat, mode)
+                if len(T) and len(L):   # (D holds the current offset at least)
+                    res, blk, buf = fastcall(self._gpu_params_struct(), cost, T, traj_len, L, D, int(x0.time_step), self._low_vel_mode, 0,
+                                             x_0_lon, x_0_lat, x0.orientation)
+                else:
+                    res = None   # (an empty bundle: the reference's loop visits it and leaves the counters at zero)
+                decided = level
+                level = upto
+                continue
+            levels = [sp.grids_at_level(k, x_0_lon, x_0_lat, mode) for k in range(level, upto)] if many else \
+                (sp.grids_at_level(level, x_0_lon, x_0_lat, mode),)
+            if params is None:
+                params = self._gpu_params(x_0_lon, x_0_lat, 0)
             if packed is not None and many:
                 res, k, blk, buf = packed(params, cost, levels)
                 decided = level + k

@@ -143,14 +143,34 @@ class FixedIntervalSampling(SamplingSpace):
         else:
             L = self._cached_array(self._get_lon_samples(level_sampling, longitudinal_mode))
             L = L[L > x_0_lon[0]]   # ("stopping": anything else has raised)
-        d_set = self.samples_d._dict_level_to_sample_set[level_sampling]
-        d0 = x_0_lat[0]
-        if d0 in d_set:
-            D = self._cached_array(d_set)
-        else:   # set.union({d0}) keeps the iteration order of the copy and appends / hashes d0 in
-            u = d_set.union((d0,))
-            D = np.fromiter(u, np.float64, len(u))
+        # `samples_d.union({d0})` (sampling.py:226) is a COPY of the set with d0 hashed in, and the copy's iteration order is not always
+        # the set's own (a set of 5 / 17 / 65 floats grew into a table of another size than the one its copy is given): the union is
+        # formed here as the reference forms it, also when d0 is one of the samples (fixture arc_hv_l3_d0_on_sample)
+        u = self.samples_d._dict_level_to_sample_set[level_sampling].union((x_0_lat[0],))
+        D = np.fromiter(u, np.float64, len(u))
         return T, traj_len, L, D
+
+    def grid_sets_at_level(self, level_sampling: int, x_0_lon, longitudinal_mode: str):
+        """``grids_at_level`` for ``RpContext.plan_packed_fast``, whose extension module reads Python sets itself: (T, traj_len, L, d_set)
+        with the level's velocity sample SET for L (stopping mode: the array of the goals ahead, as ``grids_at_level``) and the lateral
+        sample SET -- the call unites it with the current lateral offset the way ``set.union`` does (sampling.py:226: the iteration
+        order of the COPY).  Saves the two arrays a cycle would build only to have them copied (the velocity set is new every cycle of a loop that
+        sets a desired velocity).  ``None``: foreign 1-D sample objects, take ``grids_at_level``."""
+        st, sv, sd = self.samples_t, self.samples_v, self.samples_d
+        if not (type(st) is TimeSampling and type(sv) is VelocitySampling and type(sd) is PositionSampling):
+            return None
+        t_set = st._dict_level_to_sample_set[level_sampling]
+        hit = self.__dict__.get("_t_cache", _EMPTY).get(id(t_set))
+        if hit is not None and hit[0] is t_set and len(hit[1]) == len(t_set):
+            T, traj_len = hit[1], hit[2]
+        else:
+            T, traj_len = self._cached_T(t_set)
+        if longitudinal_mode == "velocity_keeping":
+            L = sv._dict_level_to_sample_set[level_sampling]
+        else:
+            L = self._cached_array(self._get_lon_samples(level_sampling, longitudinal_mode))
+            L = L[L > x_0_lon[0]]   # ("stopping": anything else has raised)
+        return T, traj_len, L, sd._dict_level_to_sample_set[level_sampling]
 
     # ---- the same for ``rp_plan_cycle``: what does NOT depend on the vehicle's state ------------------------------------------
     def cycle_ok(self) -> bool:

@@ -1,5 +1,5 @@
-"""ReactivePlanner.plan() in closed loop (production mode, Python included): p50 / p90 per workload with rp_plan_cycle (one foreign call
-per cycle, round 5) and with the separate calls of round 4 (plan_cycle switched off).
+"""ReactivePlanner.plan() in closed loop (production mode, Python included): p50 / p90 per workload with the cycle's call made by the
+binding's extension module (_rpfast, the default), through ctypes (round 4), and with rp_plan_cycle allowed for Cartesian starts.
 usage (GPU box): python profiles/probe_plan_latency_r05.py [cfg2 cfg1 cfg3]"""
 import math, os, sys
 import numpy as np
@@ -12,6 +12,15 @@ from commonroad_rp_amd.harness import run_closed_loop
 
 class NoCycle(RpContext):
     plan_cycle = None
+
+
+class CtypesCall(RpContext):
+    """the cycle's call through ctypes (as without commonroad_rp_amd/_rpfast.so)"""
+    plan_cycle = None
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.plan_packed_fast = None
 
 
 def loop(w, factory, level_planner, n=260, warm=30):
@@ -37,6 +46,6 @@ for name in sys.argv[1:] or ["cfg2", "cfg1", "cfg3"]:
     level_planner = name == "cfg1"
     w = W.cfg1(level=1, road_boundary=True) if level_planner else W.WORKLOADS[name]()
     for rep in range(2):
-        for tag, fac in (("rp_plan_cycle", RpContext), ("separate calls", NoCycle)):
+        for tag, fac in (("extension call", NoCycle), ("ctypes call", CtypesCall), ("rp_plan_cycle", RpContext)):
             p50, p90, k = loop(w, fac, level_planner)
             print(f"{name:5s} {tag:15s} plan() p50 {p50:7.1f} us  p90 {p90:7.1f} us  ({k} replans)", flush=True)

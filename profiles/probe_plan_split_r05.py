@@ -42,10 +42,15 @@ def run(name):
         acc.clear()
         undo = []
         if instrument:
-            P = RPM.GpuBackendMixin
-            for owner, fn, tag in ((P, "_fast_path_ok", "fast_path_ok"), (P, "_gpu_cost", "gpu_cost"), (P, "_gpu_params", "gpu_params"), (P, "_gpu_ctx", "gpu_ctx"),
-                                   (P, "_reset_statistics", "reset_statistics"), (P, "_fast_output", "fast_output"), (P, "_plan_fast", "plan_fast (all)"),
-                                   (SM.FixedIntervalSampling, "grids_at_level", "grids_at_level"), (RpContext, "plan_packed", "plan_packed (all)")):
+            probe = W.make_planner(w, backend_factory=Shared, device=0)
+            names = (("_fast_path_ok", "fast_path_ok"), ("_gpu_cost", "gpu_cost"), ("_gpu_params", "gpu_params"), ("_gpu_params_struct", "gpu_params_struct"),
+                     ("_gpu_ctx", "gpu_ctx"), ("_reset_statistics", "reset_statistics"), ("_fast_output", "fast_output"), ("_plan_fast", "plan_fast (all)"))
+            for fn, tag in names:
+                owner = next((k for k in type(probe).__mro__ if fn in k.__dict__), None)   # (the class of the MRO that defines it)
+                if owner is not None:
+                    undo.append((owner, fn, wrap(owner, fn, tag)))
+            for owner, fn, tag in ((SM.FixedIntervalSampling, "grids_at_level", "grids_at_level"), (RpContext, "plan_packed", "plan_packed (all)"),
+                                   (RpContext, "plan_packed_fast", "plan_packed_fast (all)")):
                 if hasattr(owner, fn):
                     undo.append((owner, fn, wrap(owner, fn, tag)))
         lat, loops = [], 0

@@ -376,6 +376,13 @@ def cases():
     cs.append(dict(base, name="arc_all_collide", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.4, 0.2, -0.1],
                    x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, max_states=8,
                    obstacles=ObstacleTables(static_circ=[[20.0, 2.0, 30.0]])))
+    # 15 the vehicle sits exactly ON a lateral sample: `samples_d.union({d0})` (sampling.py:226) is then a COPY of the set, and a copy of
+    #    a CPython set of 5 / 17 / 65 floats iterates in another order than the set it was made from (its table is sized for the
+    #    final count, the original grew) -- the candidate order is the copy's
+    cs.append(dict(base, name="arc_hv_l1_d0_on_sample", ref_path=arc, level=1, x0_lon=[12.0, 9.0, 0.3], x0_lat=[0.0, 0.2, -0.1],
+                   x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3, max_states=16))
+    cs.append(dict(base, name="arc_hv_l3_d0_on_sample", ref_path=arc, level=3, x0_lon=[12.0, 9.0, 0.3], x0_lat=[1.5, 0.1, 0.0],
+                   x0_orientation=0.14, x0_velocity=9.0, desired_speed=10.0, time_step0=3, obstacles=obstacles_arc(), max_states=16))
     return cs + random_cases()
 
 

@@ -37,7 +37,10 @@ def test_sampling_grids_follow_reference_set_order():
     from _golden import Golden
     from commonroad_rp_amd.config import ReactivePlannerConfiguration
     from commonroad_rp_amd.sampling import FixedIntervalSampling, VelocitySampling
-    for name, level, t_min in (("arc_hv_l1", 1, 0.4), ("arc_hv_l2_obs", 2, 0.4), ("scurve_hv_l3", 3, 0.2)):
+    # (the *_d0_on_sample fixtures: the vehicle exactly on a lateral sample -- the reference iterates a COPY of the sample set then,
+    #  whose order at 17 samples is not the set's own)
+    for name, level, t_min in (("arc_hv_l1", 1, 0.4), ("arc_hv_l2_obs", 2, 0.4), ("scurve_hv_l3", 3, 0.2), ("arc_hv_l1_d0_on_sample", 1, 0.4),
+                               ("arc_hv_l3_d0_on_sample", 3, 0.4)):
         g = Golden(name)
         cfg = ReactivePlannerConfiguration.from_dict(dict(planning=dict(dt=0.1, time_steps_computation=20),
                                                           sampling=dict(t_min=t_min)))
