@@ -129,3 +129,61 @@ def test_opaque_collision_checker_is_refused_not_ignored():
     assert gpu.plan() is not None
     with pytest.raises(TypeError, match="road_boundary_obstacle"):
         gpu.set_collision_checker(scenario=scenario_from_tables(case["obstacles"]), road_boundary_obstacle=object())
+
+
+def test_candidate_order_matches_reference_sampling_on_random_configurations():
+    """``FixedIntervalSampling.grids_at_level`` / ``grid_sets_at_level`` (the batch views the device path is fed from) against the
+    REFERENCE's ``generate_trajectories_at_level`` (sampling.py:202-242) on random sampling configurations: the (T, lon, d) sequence of
+    the reference's candidate list must be the product order of the grids -- including vehicles that sit exactly on a lateral sample
+    (the union is then a copy of the set, whose iteration order may differ from the set's own), stopping mode with goals behind the
+    vehicle, and both velocity regimes."""
+    from types import SimpleNamespace as NS
+    from commonroad_rp.sampling import FixedIntervalSampling as RefSampling
+    from commonroad_rp_amd.sampling import FixedIntervalSampling as OurSampling
+    from commonroad_rp_amd import _capi
+    rng = np.random.default_rng(11)
+    checked = on_sample = 0
+    for trial in range(120):
+        dt = float(rng.choice([0.1, 0.2]))
+        N = int(rng.integers(10, 41))
+        stopping = trial % 4 == 3
+        levels = int(rng.integers(2, 5))
+        d_min, d_max = -float(rng.choice([1.0, 1.5, 2.0, 3.0])), float(rng.choice([1.0, 2.0, 2.5, 3.0]))
+        t_min = float(dt * int(rng.integers(2, max(3, N // 3))))
+        cfg = NS(planning=NS(dt=dt, time_steps_computation=N),
+                 sampling=NS(sampling_method=1, longitudinal_mode="stopping" if stopping else "velocity_keeping", num_sampling_levels=levels,
+                             t_min=t_min, v_min=float(rng.uniform(0, 4)), v_max=float(rng.uniform(6, 20)), s_min=-float(rng.uniform(1, 8)),
+                             s_max=float(rng.uniform(1, 8)), d_min=d_min, d_max=d_max))
+        ref, ours = RefSampling(cfg), OurSampling(cfg)
+        level = int(rng.integers(0, levels))
+        low_vel = bool(trial % 5 == 0)
+        x0_lon = [float(rng.uniform(0, 3)), float(rng.uniform(0.5, 3.0) if low_vel else rng.uniform(5, 15)), float(rng.normal(0, 0.3))]
+        d_samples = sorted(ours.samples_d.samples_at_level(level))
+        pick = trial % 3 == 0
+        x0_lat = [float(d_samples[int(rng.integers(0, len(d_samples)))]) if pick else float(rng.uniform(d_min, d_max)), float(rng.normal(0, 0.1)), 0.0]
+        on_sample += pick
+        mode = cfg.sampling.longitudinal_mode
+        cand = ref.generate_trajectories_at_level(level, x0_lon, x0_lat, mode, low_vel)
+        if stopping:   # what _get_optimal_trajectory does to the list first (reactive_planner.py:1076-1077, trajectories.py:545-550)
+            cand = [c for c in cand if c.trajectory_long.x_d[0] > x0_lon[0]]
+        got = np.array([[c.trajectory_long.delta_tau, c.trajectory_long.x_d[0] if stopping else c.trajectory_long.x_d[0], c.trajectory_lat.x_d[0]] for c in cand],
+                       dtype=float).reshape(-1, 3)
+        T, tl, L, D = ours.grids_at_level(level, x0_lon, x0_lat, mode)
+        want = np.array([[t, l, d] for t in T for l in L for d in D], dtype=float).reshape(-1, 3)
+        # (velocity keeping: a quartic's end condition is x_d = [v, 0]; stopping: a quintic's [s, 0, 0] -- the first entry either way;
+        #  a longitudinal polynomial without coefficients drops its lateral loop in the reference: none here, all solvable)
+        assert got.shape == want.shape, (trial, got.shape, want.shape)
+        np.testing.assert_array_equal(got, want, err_msg=f"trial {trial}: level {level}, mode {mode}, d0 on a sample: {pick}")
+        # the set view the extension module iterates itself: same sequences
+        g4 = ours.grid_sets_at_level(level, x0_lon, mode)
+        Ls = np.fromiter(g4[2], np.float64, len(g4[2])) if isinstance(g4[2], (set, frozenset)) else g4[2]
+        u = g4[3].union((x0_lat[0],))
+        np.testing.assert_array_equal(Ls, L)
+        np.testing.assert_array_equal(np.fromiter(u, np.float64, len(u)), D)
+        np.testing.assert_array_equal(g4[0], T)
+        # ... and rp_plan_cycle's emulation of the lateral set in C (the insertion sequence is the level's linspace)
+        lv = ours.cycle_level(level, mode)
+        if lv is not None and x0_lat[0] == 0.0:
+            np.testing.assert_array_equal(_capi.pyset_order(lv[3], True), D)
+        checked += len(want)
+    assert checked > 5000 and on_sample >= 30
