@@ -88,14 +88,15 @@ def plan_case_names():
     return sorted(n for n in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "plan_*.npz"))))
 
 
-def build_planner_from_plan_golden(name: str, backend_factory, planner_cls=None, overrides=None):
+def build_planner_from_plan_golden(name, backend_factory, planner_cls=None, overrides=None):
     """Set up a planner exactly as tests/golden/make_golden.py::make_planner did for the reference.  ``overrides``: entries that
-    replace / complete the fixture's (the loop fixtures carry no ``continuous`` / ``via_scenario`` / ``planned``)."""
+    replace / complete the fixture's (the loop fixtures carry no ``continuous`` / ``via_scenario`` / ``planned``).  ``name``: a fixture's
+    name, or the dictionary a fixture would hold (a reference run made by the test itself)."""
     from commonroad_rp_amd.config import ReactivePlannerConfiguration
     from commonroad_rp_amd.coordinate_system import CoordinateSystem
     from commonroad_rp_amd.reactive_planner import ReactivePlanner
     from commonroad_rp_amd.state import ReactivePlannerState
-    z = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    z = dict(name) if isinstance(name, dict) else dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     z.update(overrides or {})
     cfg = ReactivePlannerConfiguration.from_dict(dict(
         planning=dict(dt=float(z["dt"]), time_steps_computation=int(z["N"]), factor=int(z["factor"]),

@@ -386,12 +386,13 @@ def cases():
     return cs + random_cases()
 
 
-def random_cases(n=24):
+def random_cases(n=24, seed0=1000):
     """Seeded random scenarios through the same pipeline (paths, initial states, horizons, levels, modes, obstacles of
-    every kind, constraint subsets, planning.factor): widens what pins the oracle beyond the hand-made cases."""
+    every kind, constraint subsets, planning.factor): widens what pins the oracle beyond the hand-made cases.
+    (``seed0`` other than the fixtures': tests/test_planner_dropin.py runs further draws through the reference live.)"""
     cs = []
     for k in range(n):
-        rng = np.random.default_rng(1000 + k)
+        rng = np.random.default_rng(seed0 + k)
         kind = k % 3
         if kind == 0:
             ref = path_arc(radius=float(rng.uniform(40.0, 300.0)) * (1 if rng.random() < 0.5 else -1), length=float(rng.uniform(120, 220)))

@@ -187,3 +187,24 @@ def test_candidate_order_matches_reference_sampling_on_random_configurations():
             np.testing.assert_array_equal(_capi.pyset_order(lv[3], True), D)
         checked += len(want)
     assert checked > 5000 and on_sample >= 30
+
+
+def test_own_planner_matches_live_reference_plan_on_random_cases():
+    """This build's ``ReactivePlanner`` (oracle-backed context: host logic + restated arithmetic) against the reference's ``plan()`` run
+    HERE on further draws of make_golden.random_cases -- whole cycles: level loop, counters, output packing -- a third of them with the
+    vehicle exactly on a lateral sample of the level (candidate order = iteration order of a COPY of the sample set)."""
+    from _golden import build_planner_from_plan_golden, compare_plan_result
+    done = planned = 0
+    for k, case in enumerate(mg.random_cases(n=30, seed0=7000)):
+        case = dict(case, draw=False, cost_kind=0)
+        case.pop("constraints", None)
+        case.pop("level", None)
+        if k % 3 == 0:   # on a sample of the first level plan() visits (level 1: 5 samples of [-3, 3]; three of them also at level 2 / 3)
+            case["x0_lat"] = [float(np.linspace(-3, 3, 5)[1 + k % 3 + (k // 3) % 2]), case["x0_lat"][1], case["x0_lat"][2]]
+        out = mg.run_plan_case(dict(case))
+        rp, z = build_planner_from_plan_golden(out, OracleContext)
+        res = rp.plan()
+        compare_plan_result(res, rp, z, atol=1e-9)
+        done += 1
+        planned += res is not None
+    assert done == 30 and planned >= 10
