@@ -24,6 +24,8 @@ cp gpurun_out/bench_detail_n1.json $OUT/${TAG}_bench_detail.json
 # cfg2 as the headline workload (the headline of rounds 1-2; carries plan() latency on cfg2)
 python3 bench.py --workload cfg2 --no-configs --no-cpu-baseline > $OUT/${TAG}_bench_cfg2.json 2>> $OUT/bench.err
 cp gpurun_out/bench_detail_n1.json $OUT/${TAG}_bench_cfg2_detail.json
+# plan() in closed loop with the cycle's call made by the binding's extension module / through ctypes, on this box
+python3 profiles/probe_plan_latency_r05.py cfg2 cfg1 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_plan_latency_ab.txt
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/prof.err
