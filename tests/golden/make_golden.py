@@ -701,7 +701,8 @@ def run_loop_case(case):
     from _golden import record_plan_stats
     stats = record_plan_stats(rp)   # counters of every plan() call (reset() clears them before the loop's callback runs: the last
                                     # two columns of `flags` are zeros)
-    res = run_closed_loop(rp, max_steps=case["steps"], replanning_frequency=1, desired_velocity=ramp_schedule, on_step=on_step)
+    res = run_closed_loop(rp, max_steps=case["steps"], replanning_frequency=case.get("replanning_frequency", 1),
+                          desired_velocity=case.get("schedule", ramp_schedule), on_step=on_step)
     trace = np.array([[s.time_step, s.position[0], s.position[1], s.orientation, s.velocity, s.acceleration or 0.0, s.steering_angle or 0.0]
                       for s in res.states], dtype=float)
     return dict(inputs, completed=int(res.completed), n_replans=res.n_replans, trace=trace, flags=np.array(flags, dtype=np.int64),

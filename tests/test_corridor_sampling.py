@@ -114,11 +114,7 @@ def test_planner_with_corridor_sampling_cpu_glue(name):
     from _oracle_ctx import OracleContext
     z = _load(name)
     z.setdefault("low_vel_mode_threshold", np.float64(4.0))
-    np.savez(os.path.join(GOLDEN_DIR, "_tmp_corridor_plan.npz"), **dict(z, continuous=0, lon_mode=0, v_range=np.array([np.nan, np.nan])))
-    try:
-        rp, _ = build_planner_from_plan_golden("_tmp_corridor_plan", OracleContext)
-    finally:
-        os.remove(os.path.join(GOLDEN_DIR, "_tmp_corridor_plan.npz"))
+    rp, _ = build_planner_from_plan_golden(dict(z, continuous=0, lon_mode=0, v_range=np.array([np.nan, np.nan])), OracleContext)
     rp._draw_traj_set = bool(int(z["draw"]))
     rp.set_sampling_space(_space(z))
     bundle = rp._create_trajectory_bundle(rp.x_0_cl[0], rp.x_0_cl[1], samp_level=int(z["level"]))

@@ -15,11 +15,7 @@ from commonroad_rp_amd.harness import run_closed_loop
 def _run(backend):
     z = dict(np.load(os.path.join(GOLDEN_DIR, "loop_zam_ramp.npz")))
     hold, speed = int(z["hold_cycles"]), float(z["pull_away_speed"])
-    np.savez(os.path.join(GOLDEN_DIR, "_tmp_loop_plan.npz"), **dict(z, continuous=0, via_scenario=0, planned=1))
-    try:
-        rp, _ = build_planner_from_plan_golden("_tmp_loop_plan", backend)
-    finally:
-        os.remove(os.path.join(GOLDEN_DIR, "_tmp_loop_plan.npz"))
+    rp, _ = build_planner_from_plan_golden(dict(z, continuous=0, via_scenario=0, planned=1), backend)
     flags = []
     stats = record_plan_stats(rp)
 
