@@ -270,8 +270,12 @@ inline bool project(const std::vector<Pt> &ref, const std::vector<double> &pos, 
             const double disc = b * b - 4.0 * a * c;
             if (disc < 0.0) continue;
             const double sq = std::sqrt(disc);
-            roots[nr++] = (-b + sq) / (2.0 * a);
-            roots[nr++] = (-b - sq) / (2.0 * a);
+            // the roots (-b + sq) / 2a, (-b - sq) / 2a, in that order, without the cancellation of the textbook form: on a nearly straight
+            // stretch a is tiny and the admissible root is -c / b (1 + O(a)) -- (-b -+ sq) keeps a few digits of it (5e-5 m in s)
+            const double q = b >= 0.0 ? -0.5 * (b + sq) : -0.5 * (b - sq);
+            if (q == 0.0) { roots[nr++] = 0.0; roots[nr++] = 0.0; }
+            else if (b >= 0.0) { roots[nr++] = c / q; roots[nr++] = q / a; }
+            else { roots[nr++] = q / a; roots[nr++] = c / q; }
         }
         for (int r = 0; r < nr; ++r) {
             double lam = roots[r];

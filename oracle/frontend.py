@@ -103,7 +103,16 @@ def project(reference: np.ndarray, ref_pos: np.ndarray, x: float, y: float, d_li
             if disc < 0.0:
                 continue
             sq = math.sqrt(disc)
-            roots = [(-b + sq) / (2.0 * a), (-b - sq) / (2.0 * a)]
+            # the two roots (-b + sq) / 2a, (-b - sq) / 2a, in that order, WITHOUT the cancellation of the textbook form: on a nearly
+            # straight stretch a is tiny, the admissible root is -c / b (1 + O(a)), and (-b -+ sq) loses all but a few digits of it
+            # (round 5: 5e-5 m in s on random polylines, live sweep against the C++ side, whose fma rounds the difference another way)
+            q = -0.5 * (b + sq) if b >= 0.0 else -0.5 * (b - sq)
+            if q == 0.0:
+                roots = [0.0, 0.0]
+            elif b >= 0.0:
+                roots = [c / q, q / a]
+            else:
+                roots = [q / a, c / q]
         for lam in roots:
             if -1e-12 <= lam <= 1.0 + 1e-12:
                 lam = min(max(lam, 0.0), 1.0)

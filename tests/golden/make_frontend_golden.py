@@ -72,35 +72,41 @@ def states_for(co, rng):
     return out
 
 
+def run_case(poly, smooth, rng):
+    """the reference's CoordinateSystem.__init__ and _compute_initial_states on one polyline -> what a fixture holds"""
+    co = CoordinateSystem(reference=np.array(poly, dtype=float), smooth_reference=smooth)      # the reference's __init__
+    rp = object.__new__(ReactivePlanner)
+    rp._co = co
+    rp.vehicle_params = types.SimpleNamespace(wheelbase=WHEELBASE)
+    states, lon, lat, code = [], [], [], []
+    for (x, y, th, v, a, steer, low) in states_for(co, rng):
+        rp._low_vel_mode = bool(low)
+        x0 = ReactivePlannerState(time_step=0, position=np.array([x, y]), orientation=th, velocity=v, steering_angle=steer,
+                                  acceleration=a, yaw_rate=0.0)
+        try:
+            l1, l2 = rp._compute_initial_states(x0)                                             # the reference's method
+            c = 0
+        except ValueError:
+            l1, l2, c = [np.nan] * 3, [np.nan] * 3, -5
+        except Exception:
+            l1, l2, c = [np.nan] * 3, [np.nan] * 3, -6
+        states.append((x, y, th, v, a, steer, low)); lon.append(l1); lat.append(l2); code.append(c)
+    return dict(polyline=np.array(poly, dtype=float), smooth=int(smooth),
+                reference=np.asarray(co.reference), ref_pos=co.ref_pos, ref_theta=co.ref_theta, ref_curv=co.ref_curv,
+                ref_curv_d=co.ref_curv_d, wheelbase=WHEELBASE, states=np.array(states), x0_lon=np.array(lon, dtype=float),
+                x0_lat=np.array(lat, dtype=float), code=np.array(code, dtype=np.int32))
+
+
 def main():
     rng = np.random.default_rng(7)
     for name, poly in polylines().items():
         for smooth in (True, False):
             if not smooth and name not in ("scurve_dups", "short5"):
                 continue
-            co = CoordinateSystem(reference=np.array(poly, dtype=float), smooth_reference=smooth)      # the reference's __init__
-            rp = object.__new__(ReactivePlanner)
-            rp._co = co
-            rp.vehicle_params = types.SimpleNamespace(wheelbase=WHEELBASE)
-            states, lon, lat, code = [], [], [], []
-            for (x, y, th, v, a, steer, low) in states_for(co, rng):
-                rp._low_vel_mode = bool(low)
-                x0 = ReactivePlannerState(time_step=0, position=np.array([x, y]), orientation=th, velocity=v, steering_angle=steer,
-                                          acceleration=a, yaw_rate=0.0)
-                try:
-                    l1, l2 = rp._compute_initial_states(x0)                                             # the reference's method
-                    c = 0
-                except ValueError:
-                    l1, l2, c = [np.nan] * 3, [np.nan] * 3, -5
-                except Exception:
-                    l1, l2, c = [np.nan] * 3, [np.nan] * 3, -6
-                states.append((x, y, th, v, a, steer, low)); lon.append(l1); lat.append(l2); code.append(c)
+            out = run_case(poly, smooth, rng)
             tag = f"frontend_{name}" + ("" if smooth else "_raw")
-            np.savez_compressed(os.path.join(HERE, tag + ".npz"), polyline=np.array(poly, dtype=float), smooth=int(smooth),
-                                reference=np.asarray(co.reference), ref_pos=co.ref_pos, ref_theta=co.ref_theta, ref_curv=co.ref_curv,
-                                ref_curv_d=co.ref_curv_d, wheelbase=WHEELBASE, states=np.array(states), x0_lon=np.array(lon, dtype=float),
-                                x0_lat=np.array(lat, dtype=float), code=np.array(code, dtype=np.int32))
-            print(f"{tag:28s} in {len(poly):4d} -> {len(co.ref_pos):4d} vertices, length {co.ref_pos[-1]:8.2f} m, codes {sorted(set(code))}")
+            np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+            print(f"{tag:28s} in {len(poly):4d} -> {len(out['ref_pos']):4d} vertices, length {out['ref_pos'][-1]:8.2f} m, codes {sorted(set(out['code'].tolist()))}")
 
 
 if __name__ == "__main__":

@@ -109,3 +109,29 @@ def test_known_answers_straight_line_and_circle():
     with pytest.raises(ValueError):
         _capi.build_reference(np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]]), smooth=True)    # splprep needs m > k
     assert len(_capi.build_reference(np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]]), smooth=False)[1]) == 3
+
+
+def test_projection_on_a_nearly_straight_stretch_is_the_root():
+    """The foot point solves ((P - p0) - lam e) . ((1 - lam) t0 + lam t1) = 0 per segment: a quadratic in lam whose leading coefficient
+    vanishes as the stretch straightens.  With the textbook root formula both the oracle and the library were 5e-5 m off in s there
+    (and apart from each other: the C++ side's fma rounds the cancelling difference another way) -- found by the live sweep of round 5
+    (tests/sweeps/live_frontend.py).  Here: a polyline that bends by 1e-12 rad per metre, far from the origin; the returned (s, d) must
+    satisfy the defining equation, and the two implementations must agree."""
+    i = np.arange(0.0, 12.0)
+    ref = np.stack((4000.0 + i, -3000.0 + 0.5e-12 * i * i), axis=1)
+    pos = ofe.compute_pathlength_from_polyline(ref)
+    tan = ofe.compute_vertex_tangents(ref)
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(200):
+        x, y = 4000.0 + float(rng.uniform(0.5, 10.5)), -3000.0 + float(rng.uniform(-3, 3))
+        s_o, d_o = ofe.project(ref, pos, x, y)
+        s_n, d_n = _capi.project(ref, pos, x, y)
+        assert abs(s_o - s_n) < 1e-11 and abs(d_o - d_n) < 1e-11
+        k = min(int(np.searchsorted(pos, s_n, side="right")) - 1, len(ref) - 2)
+        lam = (s_n - pos[k]) / (pos[k + 1] - pos[k])
+        e, q = ref[k + 1] - ref[k], np.array([x, y]) - ref[k]
+        t = (1.0 - lam) * tan[k] + lam * tan[k + 1]
+        worst = max(worst, abs(float((q - lam * e) @ t)))
+        assert abs(s_n - (x - 4000.0)) < 1e-9 and abs(d_n - (y + 3000.0)) < 1e-9   # (the stretch is straight to 1e-10 m)
+    assert worst < 1e-12
