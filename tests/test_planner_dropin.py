@@ -236,3 +236,64 @@ def test_mixin_on_reference_class_matches_reference_on_random_cases():
         done += 1
         planned += r0 is not None
     assert done >= 20 and planned >= 8
+
+
+def test_setters_leave_the_same_sampling_sets_and_cost_parameters_as_the_reference():
+    """random sequences of the planner's setters (reactive_planner.py:274-376: time / lateral / velocity / position sampling, desired
+    velocity with and without the current speed and the stopping flag, desired longitudinal position with and without its deltas) on the
+    reference's planner and on this build's: the same sample sets at every level afterwards -- as SETS and in iteration order --, the
+    same desired speed / position and the same cost-function parameters"""
+    from _golden import build_planner_from_plan_golden
+    base = CASES["plan_arc_hv_obs"]
+    ref = _planner(base, RefPlanner)
+    out = mg.run_plan_case(dict(base))
+    ours, _ = build_planner_from_plan_golden(out, OracleContext)
+    rng = np.random.default_rng(21)
+
+    def same():
+        for kind in ("samples_t", "samples_d", "samples_v", "samples_s"):
+            a, b = getattr(ref.sampling_space, kind), getattr(ours.sampling_space, kind)
+            if a is None or b is None:
+                assert a is None and b is None, kind
+                continue
+            for level in range(ref.sampling_level):
+                sa, sb = a.samples_at_level(level), b.samples_at_level(level)
+                assert list(sa) == list(sb), (kind, level)
+        assert ref._desired_speed == ours._desired_speed and ref._desired_lon_position == ours._desired_lon_position
+        for k in ("desired_speed", "w_a", "desired_s", "desired_d"):
+            assert getattr(ref.cost_function, k) == getattr(ours.cost_function, k), k
+    same()
+    for step in range(300):
+        op = int(rng.integers(0, 7))
+        if op == 0:
+            a = (float(0.1 * int(rng.integers(2, 12))),)
+            name = "set_t_sampling_parameters"
+        elif op == 1:
+            lo = -float(rng.uniform(0.2, 4)); a = (lo, float(rng.uniform(0.2, 4)))
+            name = "set_d_sampling_parameters"
+        elif op == 2:
+            lo = float(rng.uniform(0, 10)); a = (lo, lo + float(rng.uniform(0, 12)))
+            name = "set_v_sampling_parameters"
+        elif op == 3:
+            lo = float(rng.uniform(-5, 30)); a = (lo, lo + float(rng.uniform(0.1, 12)))
+            name = "set_s_sampling_parameters"
+        elif op == 4:
+            name = "set_desired_velocity"
+            kw = {}
+            if rng.random() < 0.7:
+                kw["desired_velocity"] = float(rng.uniform(0, 20))
+            if rng.random() < 0.6:
+                kw["current_speed"] = float(rng.uniform(0, 20))
+            if rng.random() < 0.2:
+                kw["stopping"] = True
+            getattr(ref, name)(**kw); getattr(ours, name)(**kw)
+            same()
+            continue
+        elif op == 5:
+            name = "set_desired_lon_position"
+            a = (float(rng.uniform(5, 80)),) + ((-float(rng.uniform(0, 8)), float(rng.uniform(0, 8))) if rng.random() < 0.5 else ())
+        else:
+            name = "set_desired_velocity"
+            a = ()
+        getattr(ref, name)(*a); getattr(ours, name)(*a)
+        same()
