@@ -404,6 +404,9 @@ __device__ __forceinline__ bool coarse_near(const WaveBound &wb, double cx, doub
 // clusters reads member rows from there (broadcast reads, tens of cycles) instead of through chained scalar loads from device
 // memory (cluster descriptor -> member rows: a few hundred cycles per cluster with nothing to overlap them with when a SIMD
 // holds one or two wavefronts -- that chain, not the tests, was the cost of a road boundary on a small batch).
+#ifndef RP_KEEP_ADDRESS_MATH_IN_LOOP
+#define RP_KEEP_ADDRESS_MATH_IN_LOOP 1   // pose_collides: see the dynamic part
+#endif
 #ifndef RP_WALK_PRETEST
 #define RP_WALK_PRETEST 1        // batched circle pre-test of a lane's mask of dynamic obstacles (pose_collides)
 #endif
@@ -423,7 +426,7 @@ static __device__ unsigned long long *rp_walk_dbg = nullptr;   // diagnostic: cl
 // STATIC_MASKED: `near_static` holds this lane's bits of static clusters (the evaluation kernels: the pose's cell of the grid over
 // the static shapes, whatever the plan; MASKED only says whether `near` is a mask of DYNAMIC obstacles); else every static shape
 // is tested behind a wave-level bounding-circle rejection (the swept-volume check, whose boxes the grid was not built for).
-template <bool MASKED, bool STATIC, bool LDS_SLOTS = false, bool STATIC_MASKED = MASKED>
+template <bool MASKED, bool STATIC, bool LDS_SLOTS = false, bool STATIC_MASKED = MASKED, bool SIZES_IN_LOOP = true>
 __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &ego, double ego_r, int t, bool want, uint64_t near,
                                               uint64_t near_static, const double *lds_slot = nullptr) {
     bool hit = false;
@@ -558,10 +561,19 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
     }
     }
     // dynamic obstacles: only those whose bit is set in the (pair, step) mask of the longitudinal profile
+    // (The address arithmetic of this part -- seven plane offsets, the bases of the centre and radius tables, the mask of valid bits --
+    //  does not change over a kernel's step loop; hoisted out of it, it takes some thirty scalar registers the evaluation kernels do
+    //  not have: they are spilled into lanes of a vector register and every later use is a v_readlane -- a VECTOR instruction, 84 of
+    //  them in the 16-lane kernel's loop.  The two table sizes go through an empty asm here, so that what is derived from them stays
+    //  where it is used, as scalar multiplies and adds: 118 -> 79 v_readlane in the costs-only 16-lane kernel, 143 -> 61 in the lane
+    //  kernel with the query, cfg3 production kernel -1.9 % (same box); the variants that store state rows went the other way
+    //  (46 -> 54) and keep the hoisted form: SIZES_IN_LOOP.)
+    int nd_u = ob.n_dyn, ns_u = ob.n_steps;
+    if (RP_KEEP_ADDRESS_MATH_IN_LOOP && SIZES_IN_LOOP) asm volatile("" : "+s"(nd_u), "+s"(ns_u));
     const int k = t - ob.dyn_t0;
-    const bool k_ok = want && k >= 0 && k < ob.n_steps;
+    const bool k_ok = want && k >= 0 && k < ns_u;
     const int kc = k_ok ? k : 0;
-    const size_t plane = (size_t)ob.n_dyn * (size_t)ob.n_steps;
+    const size_t plane = (size_t)nd_u * (size_t)ns_u;
     uint64_t m = k_ok ? near : 0;
     if (!MASKED) {
         // no (pair, step) mask came with the pose (explicit-polynomial plans, the swept check): it is built here, from the table
@@ -573,19 +585,19 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         if (__any(k_ok)) {
             typedef double dbl2 __attribute__((ext_vector_type(2)));
             typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
-            const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
-            const gcdouble rmax = dyn + dyn_rmax_offset(ob.n_dyn, ob.n_steps);
+            const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(nd_u, ns_u));
+            const gcdouble rmax = dyn + dyn_rmax_offset(nd_u, ns_u);
             constexpr int kB = 8;
-            for (int j0 = 0; j0 < ob.n_dyn; j0 += kB) {
+            for (int j0 = 0; j0 < nd_u; j0 += kB) {
                 dbl2 oc[kB];
 #pragma unroll
                 for (int u = 0; u < kB; ++u) {   // (a batch's tail repeats the last obstacle: same circle, same bit)
-                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
-                    oc[u] = xy[(size_t)j * ob.n_steps + kc];
+                    const int j = j0 + u < nd_u ? j0 + u : nd_u - 1;
+                    oc[u] = xy[(size_t)j * ns_u + kc];
                 }
 #pragma unroll
                 for (int u = 0; u < kB; ++u) {
-                    const int j = j0 + u < ob.n_dyn ? j0 + u : ob.n_dyn - 1;
+                    const int j = j0 + u < nd_u ? j0 + u : nd_u - 1;
                     const double dx = oc[u].x - ego.cx, dy = oc[u].y - ego.cy, rr = ego_r + rmax[j];   // NaN centre: absent, no bit
                     m |= (uint64_t)(dx * dx + dy * dy <= rr * rr * 1.000001) << (j < 63 ? j : 63);
                 }
@@ -594,8 +606,8 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         if (!k_ok) m = 0;
     }
     RP_WSTAMP(10);
-    const bool overflow = (m >> 63) != 0 && ob.n_dyn > 63;
-    m &= ob.n_dyn >= 63 ? ~(1ull << 63) : (1ull << ob.n_dyn) - 1ull;
+    const bool overflow = (m >> 63) != 0 && nd_u > 63;
+    m &= nd_u >= 63 ? ~(1ull << 63) : (1ull << nd_u) - 1ull;
     if (MASKED && RP_WALK_PRETEST && __any(__popcll((unsigned long long)m) > RP_WALK_PRETEST_MIN)) {
         // The (pair, step) masks are exact to the lateral range of the pair's candidates only (~7 m): in traffic a lane's mask holds
         // several obstacles, few of which its own pose comes near, and the walk below costs one memory round trip per bit of the
@@ -605,7 +617,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         // visits the same obstacles it would have tested, and nothing else changes.  (cfg3: 4 - 8 bits per lane, 0 - 2 after this.)
         typedef double dbl2 __attribute__((ext_vector_type(2)));
         typedef const dbl2 __attribute__((address_space(4))) *gcdouble2;
-        const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(ob.n_dyn, ob.n_steps));
+        const gcdouble2 xy = (gcdouble2)(dyn + dyn_xy_offset(nd_u, ns_u));
         const double rr1 = ego_r + ob.dyn_rmax_all;
         const double lim = rr1 * rr1 * 1.000001;
         constexpr int kB = RP_WALK_PRETEST_BATCH;
@@ -617,7 +629,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
             for (int u = 0; u < kB; ++u) {   // (a lane with fewer bits repeats obstacle 0: tested, never kept)
                 const int j = r1 != 0 ? __ffsll((unsigned long long)r1) - 1 : 0;
                 r1 &= r1 - 1;
-                oc[u] = xy[(size_t)j * ob.n_steps + kc];
+                oc[u] = xy[(size_t)j * ns_u + kc];
             }
 #pragma unroll
             for (int u = 0; u < kB; ++u) {
@@ -633,7 +645,7 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         const bool act = m != 0;
         const int j = act ? __ffsll((unsigned long long)m) - 1 : 0;
         m &= m - 1;           // (0 stays 0)
-        const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
+        const gcdouble o = dyn + (size_t)j * ns_u + kc;
         // all seven loads are independent and issue back to back; NaN centre = obstacle absent
         const double cx = o[0], cy = o[plane], ux = o[2 * plane], uy = o[3 * plane], hl = o[4 * plane], hw = o[5 * plane],
                      rr = ego_r + o[6 * plane];
@@ -644,8 +656,8 @@ __device__ __forceinline__ bool pose_collides(const ObsTables &ob, const Obb &eg
         }
     }
     if (__any(overflow)) {    // more than 63 dynamic obstacles: the tail is tested one by one
-        for (int j = 63; j < ob.n_dyn; ++j) {
-            const gcdouble o = dyn + (size_t)j * ob.n_steps + kc;
+        for (int j = 63; j < nd_u; ++j) {
+            const gcdouble o = dyn + (size_t)j * ns_u + kc;
             const double cx = o[0], cy = o[plane], rr = ego_r + o[6 * plane];
             const double dx = cx - ego.cx, dy = cy - ego.cy;
             if (overflow && dx * dx + dy * dy <= rr * rr * 1.000001) {

@@ -2497,7 +2497,7 @@ __global__ __launch_bounds__(BLOCK, RP_WAVES_PER_SIMD) void rp_eval_kernel(const
                         ob.dyn_rmax_all = al.obs.dyn_rmax_all;
                         const Obb ego = {ego_cx, ego_cy, cos_gl, sin_gl, al.half_length, al.half_width};
                         RP_STAMP(45);
-                        hit = pose_collides<masked, COLL == 2, LON_FUSED && COLL == 2, true>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
+                        hit = pose_collides<masked, COLL == 2, LON_FUSED && COLL == 2, true, !MAT>(ob, ego, al.ego_radius, al.time_step0 + i * al.factor, ask,
                                                                                              near_dyn, near_sta, slot_lds) && ask;
                     }
                     RP_STAMP(46);
