@@ -17,6 +17,9 @@ class OracleContext:
         self._inp = None
         self._range = (0, 0)
         self._N = None
+        from commonroad_rp_amd import _capi
+        if _capi._rpfast is None:   # (extension not built: the planner asks with getattr and takes the ctypes-shaped call)
+            self.plan_packed_fast = None
 
     def close(self):
         pass
@@ -49,6 +52,36 @@ class OracleContext:
         if out.best_index < 0:
             return out, None, None
         return out, out.best_states, pack_trajectory(np.ascontiguousarray(out.best_states), params.dt, params.wheelbase, params.x0_orientation)
+
+    def plan_packed_fast(self, params, cost, T, traj_len, L, D, time_step0, low_vel_mode, flags, x0_lon, x0_lat, orientation):
+        """``RpContext.plan_packed_fast`` with the binding's REAL extension module (csrc/rp_pyfast.c) in front of the oracle: the module
+        writes the cycle's fields into ``params``, iterates the sample sets into a buffer and calls what it is given as ``rp_plan`` -- here
+        a callback that takes the grids out of that buffer; the oracle then plans on exactly what the library would have been handed.
+        (The planner's CPU tests, the live runs against the reference included, so go through the same Python and C as on the device.)"""
+        import ctypes as C
+        from commonroad_rp_amd import _capi
+        st = self.__dict__.get("_pk_state")
+        if st is None:
+            buf = (C.c_char * 32768)()
+            res = _capi.RpResult()
+            got = {}
+
+            def fake(ctx, p, cst, g, lo, hi, fl, result, out):
+                g = g.contents
+                nd = g.nT + g.nL + g.nD
+                f64, i32 = np.frombuffer(buf, dtype=np.float64), np.frombuffer(buf, dtype=np.int32)
+                got["grids"] = (f64[:g.nT].copy(), i32[2 * nd:2 * nd + g.nT].copy(), f64[g.nT:g.nT + g.nL].copy(), f64[g.nT + g.nL:nd].copy())
+                got["call"] = (lo, hi, fl)
+                return 0
+            fn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_capi.RpParams), C.POINTER(_capi.RpCost), C.POINTER(_capi.RpGrids), C.c_int64, C.c_int64,
+                             C.c_uint32, C.POINTER(_capi.RpResult), C.POINTER(C.c_double))(fake)
+            pk = _capi._rpfast.Packed(C.cast(fn, C.c_void_p).value, 1, C.addressof(buf), 32768, C.addressof(res))
+            st = self._pk_state = (pk, got, (fn, buf, res))
+        pk, got, _keep = st
+        out = np.empty((N_ARRAYS + 13, params.N + 1))
+        rc = pk.plan(params, cost, T, traj_len, L, D, out, time_step0, low_vel_mode, flags, x0_lon, x0_lat, orientation)
+        assert rc == 0 and got["call"] == (0, -1, _capi.PLAN_PACKED), (rc, got.get("call"))
+        return self.plan_packed(params, cost, *got["grids"])
 
     def plan_levels_packed(self, params, cost, levels):
         """the level loop, level by level (what rp_plan_levels does in one device round trip)"""
