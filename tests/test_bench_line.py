@@ -80,3 +80,31 @@ def test_numpy_loop_calibration_file():
     for c in cal["cases"].values():
         assert c["reference_candidates_per_s"] > 0 and c["numpy_loop_candidates_per_s"] > 0
     assert 0.5 < cal["ratio_numpy_loop_to_reference"] < 2.0   # the restatement runs the reference's kind of program
+
+
+def test_committed_round_records_belong_to_the_committed_library():
+    """the judged records under profiles/ name the library they were measured on (its source hash): they must be the library the committed
+    sources build -- a kernel change without a new measurement pass shows up here -- and the committed bench line must be what the driver
+    can parse (one object, < 4 KB, roofline consistent with its own numbers)."""
+    from commonroad_rp_amd import _capi
+    here = _capi.source_hash()
+    prof = os.path.join(REPO, "profiles")
+    for name in ("r05_pmc_traffic.json", "r05_fp64_flops.json"):
+        d = json.load(open(os.path.join(prof, name)))
+        hashes = {v.get("source_hash") for v in d.values() if isinstance(v, dict)}
+        assert hashes == {here}, (name, hashes, here)
+    for name in ("r05_sq_cfg3.json", "r05_sq_cfg5_fused.json"):
+        assert json.load(open(os.path.join(prof, name)))["source_hash"] == here, name
+    for name in ("r05_fuzz_parity.txt", "r05_full_scale_parity.txt"):
+        assert here in open(os.path.join(prof, name)).readline(), name
+    text = open(os.path.join(prof, "r05_bench.json")).read().strip()
+    assert "\n" not in text and len(text) < 4096
+    r = json.loads(text)
+    for k in CONTRACT + ("cpu_baseline",):
+        assert k in r, k
+    rf = r["roofline"]
+    assert rf["frac"] == pytest.approx(rf["achieved"] / rf["peak"], rel=1e-3)
+    assert rf["achieved"] == pytest.approx(rf["bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9, rel=1e-3)
+    assert rf["traffic"] is not None and rf["traffic"] >= rf["bytes_per_launch"]          # (counters of THIS library: else bench.py reports null)
+    assert r["value"] == pytest.approx(r["config"]["candidates_per_step"] / (r["ms_per_step"] * 1e-3), rel=1e-3)
+    assert rf["kernel_ms"] < r["ms_per_step"]
