@@ -67,6 +67,7 @@ struct Options {
     int table_window = 1;        // single-launch variant stages only the part of the reference tables a plan can touch
     int fold_threshold = kFoldThreshold;
     int lon_publish = 1, inline_grids = 1, event_bracket = 0, winner_lanes_as_batch = 0, zero_copy = 1, coeff_groups = 1;
+    int winner_skip_query = 1;   // the re-evaluation of a production-mode plan's winner (its state rows) runs without the collision query
     int lazy_trace = 0, print_stamps = 0, timing = 0;   // diagnostics on stderr
     int wait_mode = RP_WAIT_SPIN;   // how the host waits for a plan's completion ticket (rp_set_wait_mode)
 };
@@ -97,6 +98,7 @@ const OptionDesc kOptionTable[] = {
     {"inline_grids", &Options::inline_grids, "RP_AMD_NO_INLINE_GRIDS", true, 0, 1},
     {"event_bracket", &Options::event_bracket, "RP_AMD_EVENT_BRACKET", false, 0, 1},
     {"winner_lanes_as_batch", &Options::winner_lanes_as_batch, "RP_AMD_WINNER_G_AS_BATCH", false, 0, 1},
+    {"winner_skip_query", &Options::winner_skip_query, "RP_AMD_NO_WINNER_SKIP_QUERY", true, 0, 1},
     {"zero_copy", &Options::zero_copy, "RP_AMD_NO_ZERO_COPY", true, 0, 1},
     {"coeff_groups", &Options::coeff_groups, "RP_AMD_NO_COEFF_GROUPS", true, 0, 1},
     {"lazy_trace", &Options::lazy_trace, "RP_AMD_LAZY_TRACE", false, 0, 1},
@@ -1191,6 +1193,10 @@ int pipeline_begin(rp_ctx *c, KArgs &ka, bool mat, bool cin, bool skip_eval, boo
         kw.host_seq = ticket ? &hrb_dev->seq : nullptr;
         kw.seq_value = seq;
         kw.ticket_if_none = (!ka.gate || chain_last) ? 1 : 0;
+        // the winner IS collision-free (the selection has seen to that) and its label and cost are not read from this pass: the variant
+        // without the collision query writes the same rows, reads eleven profile rows instead of sixteen and no obstacle table
+        // (one workgroup, a chain of round trips: 11.1 -> 7.4 us on cfg3, behind every production-mode plan of the two-kernel path)
+        if (c->opt.winner_skip_query) { kw.flags |= RP_FLAG_SKIP_COLLISION; kw.has_obstacles = 0; }   // (has_obstacles: no broad phase in a single-launch prologue either)
         if (fused_lds) launch_eval_fused(c, kw, 1, true, cin, fused_lds, G);
         // (two-kernel path: one candidate is one workgroup whatever the lanes -- a whole wavefront per candidate makes its chain
         //  of step blocks four times shorter than the batch's 16 lanes: cfg3 19 -> ~10 us.  Nothing was materialised that these

@@ -205,7 +205,7 @@ int rp_get_wait_mode(const rp_ctx *ctx);
  *   "fused_lon_blocks"  RP_AMD_FUSED_LON_BLOCKS     -1 (4 workgroups per CU) | largest grid that takes it
  *   "auto_materialize"  RP_AMD_NO_AUTO_MATERIALIZE  1 | 0: small batches whose winner rows are wanted write every candidate's rows
  *   "stage_out", "row_padding", "row_align" (0 | 8 | 16), "tail_split"   RP_AMD_NO_STAGE_OUT, _NO_ROW_PADDING, _ROW_ALIGN, _NO_TAIL_SPLIT
- *   "table_window", "lon_publish", "inline_grids", "zero_copy", "coeff_groups"   RP_AMD_NO_<NAME>: 1 | 0
+ *   "table_window", "lon_publish", "inline_grids", "zero_copy", "coeff_groups", "winner_skip_query"   RP_AMD_NO_<NAME>: 1 | 0
  *   "fold_threshold"    RP_AMD_FOLD_THRESHOLD       block partials beyond which they are folded before the epilogue
  *   "event_bracket", "winner_lanes_as_batch", "lazy_trace", "print_stamps", "timing"   RP_AMD_<NAME>: 0 | 1 (measurement variants, diagnostics on stderr)
  *   "wait_mode"         RP_AMD_WAIT_MODE            RP_WAIT_* (as rp_set_wait_mode)
