@@ -37,6 +37,7 @@ rm -rf $OUT/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $ROOT/bench.py --no-cpu-baseline --no-configs > $OUT/${TAG}_headline_bench_under_rocprof.json 2>> $OUT/prof.err
 python3 $ROOT/profiles/summarize_trace.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_headline_kernel_trace_summary.txt
 python3 $ROOT/profiles/step_timeline.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) > $OUT/${TAG}_headline_step_timeline.txt 2>&1 || true
+python3 $ROOT/profiles/step_timeline.py $(ls $OUT/prof/*/*kernel_trace.csv | head -1) production > $OUT/${TAG}_production_step_timeline.txt 2>&1 || true
 rm -rf $OUT/prof
 echo "trace done"
 cd $ROOT
