@@ -1,0 +1,54 @@
+"""One candidate of one seed of the fuzz generator (tests/_fuzz.py) through the REFERENCE itself (its own _create_trajectory_bundle /
+_check_kinematics on this build's coordinate system object, the fuzz case's grids installed as sample sets) beside the oracle: the
+state rows of that candidate, array by array.  For cases the GPU-vs-oracle soak flags: which side does the reference take?
+Only where the reference is mounted.   usage: python tests/sweeps/fuzz_seed_vs_reference.py <seed> <candidate>"""
+import os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [REPO, os.path.join(REPO, "commonroad-reactive-planner_amd"), os.path.join(REPO, "tests"), os.path.join(REPO, "tests", "golden")]
+import make_golden as mg
+from _fuzz import random_case
+from oracle import oracle
+np.set_printoptions(precision=17, linewidth=250)
+seed, cand = int(sys.argv[1]), int(sys.argv[2])
+inp, co, obs, info = random_case(seed)
+p, c = inp.params, inp.cost
+nT, nL, nD = len(inp.T), len(inp.L), len(inp.D)
+iT, r = divmod(cand, nL * nD); iL, iD = divmod(r, nD)
+Tq, Lq, Dq = float(inp.T[iT]), float(inp.L[iL]), float(inp.D[iD])
+print("seed", seed, info, "candidate", cand, "= (T, L, D)", (Tq, Lq, Dq), "traj_len", int(inp.traj_len[iT]))
+v0 = float(p.x0_lon[1])
+low = bool(p.low_vel_mode)
+names = ["velocity", "acceleration", "kappa", "kappa_dot", "yaw_rate"]
+case = dict(name=f"fuzz_{seed}", dt=float(p.dt), N=int(p.N), factor=int(p.factor), coordinate_system=co, ref_path=co.reference,
+            x0_lon=list(p.x0_lon), x0_lat=list(p.x0_lat), x0_orientation=float(p.x0_orientation), x0_velocity=v0,
+            desired_speed=None if np.isnan(c.desired_speed) else abs(float(c.desired_speed)), time_step0=int(p.time_step0), obstacles=obs,
+            low_vel_mode_threshold=(v0 + 1.0) if low else 0.5 * max(v0, 1e-3), draw=bool(info["draw"]), cost_kind=int(c.kind),
+            constraints=[n for k, n in enumerate(names) if int(p.constraint_mask) & (1 << k)] or ["velocity", "acceleration"],
+            level=1, t_min=float(max(2 * p.dt, min(inp.T))), custom_T=[float(t) for t in inp.T], custom_L=[float(v) for v in inp.L],
+            custom_D=[float(d) for d in inp.D if d != p.x0_lat[0]] or [float(p.x0_lat[0])])
+if int(p.lon_mode) == 1:
+    case.update(lon_mode="stopping", desired_s=float(c.desired_s), delta_s_min=-5.0, delta_s_max=5.0)
+rp = mg.make_planner(case)
+if not np.isnan(c.desired_speed):   # (the generator draws desired speeds the reference's setter refuses: negative ones; the cost function takes them)
+    rp.cost_function.desired_speed = float(c.desired_speed)
+bundle = mg.sample(rp, case)
+trajs = list(bundle.trajectories)
+try:
+    rp._get_optimal_trajectory(bundle)
+except Exception as e:
+    print("(the reference's _get_optimal_trajectory raised", type(e).__name__, e, ")")
+hit = [t for t in trajs if t.trajectory_long.delta_tau == Tq and t.trajectory_long.x_d[0] == Lq and t.trajectory_lat.x_d[0] == Dq]
+print(len(trajs), "reference candidates;", len(hit), "match")
+t = hit[0]
+tb = oracle.OracleTables.from_coordinate_system(co, obs)
+ref = oracle.plan(inp, tb, want_states=True)
+rows = ["x", "y", "theta", "v", "a", "kappa", "kappa_dot", "s", "d", "theta_cl", "s_dot", "s_ddot", "d_dot", "d_ddot"]
+ca, cu = t.cartesian, t.curvilinear
+got = [ca.x, ca.y, ca.theta, ca.v, ca.a, ca.kappa, ca.kappa_dot, cu.s, cu.d, cu.theta, cu.s_dot, cu.s_ddot, cu.d_dot, cu.d_ddot]
+print("reference label", t.feasibility_label, "| oracle status", hex(int(ref.status[cand])))
+for k, nm in enumerate(rows):
+    a, b = np.asarray(got[k], dtype=float), ref.states[cand, k]
+    m = min(len(a), len(b))
+    print(f"{nm:9s} max |reference - oracle| {np.nanmax(np.abs(a[:m] - b[:m])):.3g}   reference tail {a[max(0, m - 3):m]}   oracle tail {b[max(0, m - 3):m]}")
