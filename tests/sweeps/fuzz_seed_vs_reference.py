@@ -24,8 +24,10 @@ names = ["velocity", "acceleration", "kappa", "kappa_dot", "yaw_rate"]
 case = dict(name=f"fuzz_{seed}", dt=float(p.dt), N=int(p.N), factor=int(p.factor), coordinate_system=co, ref_path=co.reference,
             x0_lon=list(p.x0_lon), x0_lat=list(p.x0_lat), x0_orientation=float(p.x0_orientation), x0_velocity=v0,
             desired_speed=None if np.isnan(c.desired_speed) else abs(float(c.desired_speed)), time_step0=int(p.time_step0), obstacles=obs,
-            low_vel_mode_threshold=(v0 + 1.0) if low else 0.5 * max(v0, 1e-3), draw=bool(info["draw"]), cost_kind=int(c.kind),
-            constraints=[n for k, n in enumerate(names) if int(p.constraint_mask) & (1 << k)] or ["velocity", "acceleration"],
+            low_vel_mode_threshold=(v0 + 1.0) if low else 0.5 * max(v0, 1e-3), draw=True, cost_kind=int(c.kind),
+            # (state rows are what is compared here: every candidate's are kept -- draw mode -- and the two checks the reference's
+            #  pre-filter cannot do without are in the list, whatever the seed's mask says: neither changes a state value)
+            constraints=sorted(set([n for k, n in enumerate(names) if int(p.constraint_mask) & (1 << k)] + ["velocity", "acceleration"]), key=names.index),
             level=1, t_min=float(max(2 * p.dt, min(inp.T))), custom_T=[float(t) for t in inp.T], custom_L=[float(v) for v in inp.L],
             custom_D=[float(d) for d in inp.D if d != p.x0_lat[0]] or [float(p.x0_lat[0])])
 if int(p.lon_mode) == 1:
